@@ -1,0 +1,386 @@
+/*
+ * mnn_oracle.c -- CPU restatement of the native arithmetic on batchelor's fastMNN / reducedMNN hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product (batchelor_amd/, include/) may import, link or execute
+ * this file.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, and only as the
+ * checker / the timed CPU baseline.
+ *
+ * Parity status: the reference is R + Rcpp; R, Rcpp.h and BiocNeighbors are absent from the build image, so the
+ * reference itself is UNBUILDABLE here (no stand-in headers are written for it).  This restatement is pinned
+ * against the known-answer tests the reference's own test-suite holds for the path (tests/test_oracle_*.py lists
+ * them with file:line) and against the dense "REF" specifications of tests/testthat/test-mnn-correct.R re-expressed
+ * in numpy.  The exact kNN (BiocNeighbors::queryKNN / findMutualNN, a third-party dependency whose source is not
+ * under /root/reference and whose version DESCRIPTION:17 leaves unpinned) is restated from its documented contract:
+ * exact Euclidean k nearest neighbours, ascending distance; tie order is "parity unpinned" upstream and is fixed
+ * here as (distance, then lowest index).
+ *
+ * All arithmetic is IEEE double, compiled with -ffp-contract=off so that a squared distance is the plain
+ * left-to-right sum of (a-b)*(a-b) over dimensions -- the HIP refine kernel reproduces it bit for bit.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_OK 0
+#define ORC_ERR_DIM_GENES (-2)
+#define ORC_ERR_DIM_CELLS (-3)
+#define ORC_ERR_SUBSET (-4)
+#define ORC_ERR_INDEX_LEN (-5)
+#define ORC_ERR_NOMEM (-6)
+
+/* ------------------------------------------------------------------------------------------------
+ * Exact brute-force kNN.  Contract of BiocNeighbors::queryKNN(X, query, k) as used at
+ * R/MNN_tree.R:129 (inside findMutualNN) and R/fastMNN.R:605: for every query row the k nearest rows
+ * of X by Euclidean distance, ascending.  Row-major inputs (cells x dims), 0-based indices out.
+ * dist receives Euclidean (not squared) distances, as queryKNN reports them.
+ * Reference rows are processed in transposed blocks so the inner loop vectorises ACROSS reference
+ * cells; each (query, ref) pair still sees the sequential sum over dimensions.
+ * ---------------------------------------------------------------------------------------------- */
+#define RB 256 /* reference cells per transposed block */
+
+typedef struct {
+    double d2;
+    int32_t idx;
+} cand_t;
+
+static inline int cand_less(double d2a, int32_t ia, double d2b, int32_t ib) {
+    return d2a < d2b || (d2a == d2b && ia < ib);
+}
+
+/* max-heap on (d2, idx): root = current worst of the k kept */
+static void heap_sift_down(cand_t* h, int n, int i) {
+    for (;;) {
+        int l = 2 * i + 1, r = l + 1, m = i;
+        if (l < n && cand_less(h[m].d2, h[m].idx, h[l].d2, h[l].idx)) m = l;
+        if (r < n && cand_less(h[m].d2, h[m].idx, h[r].d2, h[r].idx)) m = r;
+        if (m == i) return;
+        cand_t t = h[i];
+        h[i] = h[m];
+        h[m] = t;
+        i = m;
+    }
+}
+
+static int cand_cmp(const void* a, const void* b) {
+    const cand_t* x = (const cand_t*)a;
+    const cand_t* y = (const cand_t*)b;
+    if (x->d2 < y->d2) return -1;
+    if (x->d2 > y->d2) return 1;
+    return (x->idx > y->idx) - (x->idx < y->idx);
+}
+
+int orc_knn(const double* X, int32_t nr, const double* Q, int32_t nq, int32_t d, int32_t k, int32_t* idx,
+            double* dist, int32_t nthreads) {
+    if (k > nr) k = nr;
+    if (k <= 0 || nq <= 0) return ORC_OK;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+    int nblk = (nr + RB - 1) / RB;
+    /* transposed copy of the reference: Xt[blk][c][j] */
+    double* Xt = (double*)malloc((size_t)nblk * d * RB * sizeof(double));
+    if (!Xt) return ORC_ERR_NOMEM;
+    for (int b = 0; b < nblk; ++b)
+        for (int c = 0; c < d; ++c)
+            for (int j = 0; j < RB; ++j) {
+                int r = b * RB + j;
+                Xt[((size_t)b * d + c) * RB + j] = r < nr ? X[(size_t)r * d + c] : 0.0;
+            }
+    int fail = 0;
+#pragma omp parallel
+    {
+        cand_t* heap = (cand_t*)malloc((size_t)k * sizeof(cand_t));
+        double acc[RB];
+        if (!heap) {
+#pragma omp atomic write
+            fail = 1;
+        }
+#pragma omp for schedule(dynamic, 16)
+        for (int q = 0; q < nq; ++q) {
+            if (!heap) continue;
+            const double* qv = Q + (size_t)q * d;
+            int hn = 0;
+            for (int b = 0; b < nblk; ++b) {
+                const double* blk = Xt + (size_t)b * d * RB;
+                for (int j = 0; j < RB; ++j) acc[j] = 0.0;
+                for (int c = 0; c < d; ++c) {
+                    const double qc = qv[c];
+                    const double* row = blk + (size_t)c * RB;
+                    for (int j = 0; j < RB; ++j) {
+                        double t = qc - row[j];
+                        acc[j] += t * t;
+                    }
+                }
+                int lim = nr - b * RB;
+                if (lim > RB) lim = RB;
+                for (int j = 0; j < lim; ++j) {
+                    int32_t r = b * RB + j;
+                    if (hn < k) {
+                        heap[hn].d2 = acc[j];
+                        heap[hn].idx = r;
+                        ++hn;
+                        if (hn == k)
+                            for (int i = k / 2 - 1; i >= 0; --i) heap_sift_down(heap, k, i);
+                    } else if (cand_less(acc[j], r, heap[0].d2, heap[0].idx)) {
+                        heap[0].d2 = acc[j];
+                        heap[0].idx = r;
+                        heap_sift_down(heap, k, 0);
+                    }
+                }
+            }
+            qsort(heap, (size_t)hn, sizeof(cand_t), cand_cmp);
+            for (int j = 0; j < k; ++j) {
+                idx[(size_t)q * k + j] = heap[j].idx;
+                if (dist) dist[(size_t)q * k + j] = sqrt(heap[j].d2);
+            }
+        }
+        free(heap);
+    }
+    free(Xt);
+    return fail ? ORC_ERR_NOMEM : ORC_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * find_mutual_nns -- follows src/find_mutual_nns.cpp:8-41.
+ * left  : nL x k2 column-major (R IntegerMatrix), 1-based ids of right cells, row order = neighbour rank
+ * right : nR x k1 column-major, 1-based ids of left cells
+ * Emits (l, r) for l ascending and, inside l, in the row order of left[l, ] (:23-36), whenever l is found
+ * in the sorted copy of right[r, ] (:15-20, lower_bound :28-32).  Output arrays must hold nL*k2 entries.
+ * ---------------------------------------------------------------------------------------------- */
+static int int_cmp(const void* a, const void* b) {
+    int32_t x = *(const int32_t*)a, y = *(const int32_t*)b;
+    return (x > y) - (x < y);
+}
+
+int orc_find_mutual_nns(const int32_t* left, int32_t nL, int32_t k2, const int32_t* right, int32_t nR, int32_t k1,
+                        int32_t* outL, int32_t* outR, int64_t* npairs) {
+    int32_t* sorted = (int32_t*)malloc(((size_t)nR * k1 + 1) * sizeof(int32_t));
+    if (!sorted) return ORC_ERR_NOMEM;
+    for (int32_t r = 0; r < nR; ++r) {
+        int32_t* row = sorted + (size_t)r * k1;
+        for (int32_t j = 0; j < k1; ++j) row[j] = right[(size_t)j * nR + r];
+        qsort(row, (size_t)k1, sizeof(int32_t), int_cmp);
+    }
+    int64_t n = 0;
+    for (int32_t l = 0; l < nL; ++l) {
+        const int32_t want = l + 1;
+        for (int32_t j = 0; j < k2; ++j) {
+            const int32_t r1 = left[(size_t)j * nL + l];
+            const int32_t* row = sorted + (size_t)(r1 - 1) * k1;
+            int lo = 0, hi = k1; /* first position with row[pos] >= want */
+            while (lo < hi) {
+                int mid = (lo + hi) / 2;
+                if (row[mid] < want)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            if (lo != k1 && row[lo] == want) {
+                outL[n] = want;
+                outR[n] = r1;
+                ++n;
+            }
+        }
+    }
+    free(sorted);
+    *npairs = n;
+    return ORC_OK;
+}
+
+/* R::logspace_add (Rmath): log(exp(lx) + exp(ly)) */
+static inline double logspace_add(double lx, double ly) {
+    return (lx > ly ? lx : ly) + log1p(exp(-fabs(lx - ly)));
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * smooth_gaussian_kernel -- follows src/smooth_gaussian_kernel.cpp:11-118.
+ * averaged : g x U col-major; index : U (0-based columns of mat); mat : gd x n col-major; out : g x n.
+ * NB: no range check on 'index' upstream either (only the length check, :18-20).
+ * ---------------------------------------------------------------------------------------------- */
+int orc_smooth_gaussian_kernel(const double* averaged, int32_t g, int32_t U, const int32_t* index, int32_t index_len,
+                               const double* mat, int32_t gd, int32_t n, double sigma2, double* out) {
+    if (U != index_len) return ORC_ERR_INDEX_LEN; /* :18-20 */
+    size_t gn = (size_t)g * n;
+    double* expo = (double*)malloc((gn + 1) * sizeof(double));
+    double* logw = (double*)malloc(((size_t)n + 1) * sizeof(double));
+    double* total = (double*)malloc(((size_t)n + 1) * sizeof(double));
+    if (!expo || !logw || !total) {
+        free(expo);
+        free(logw);
+        free(total);
+        return ORC_ERR_NOMEM;
+    }
+    for (size_t i = 0; i < gn; ++i) {
+        out[i] = 0.0;
+        expo[i] = -INFINITY; /* :24-25 */
+    }
+    for (int32_t i = 0; i < U; ++i) {
+        const double* centre = mat + (size_t)index[i] * gd;
+        for (int32_t c = 0; c < n; ++c) { /* :36-52 */
+            const double* other = mat + (size_t)c * gd;
+            double s = 0.0;
+            for (int32_t x = 0; x < gd; ++x) {
+                double t = centre[x] - other[x];
+                s += t * t;
+            }
+            logw[c] = s / -sigma2;
+        }
+        double density = 0.0; /* :56-65 */
+        for (int32_t j = 0; j < U; ++j) density = j == 0 ? logw[index[j]] : logspace_add(density, logw[index[j]]);
+        const double* corr = averaged + (size_t)i * g;
+        for (int32_t c = 0; c < n; ++c) { /* :75-99 */
+            const double logmult = logw[c] - density;
+            total[c] = i == 0 ? logmult : logspace_add(total[c], logmult);
+            double* o = out + (size_t)c * g;
+            double* e = expo + (size_t)c * g;
+            for (int32_t x = 0; x < g; ++x) {
+                if (logmult > e[x]) {
+                    o[x] *= exp(e[x] - logmult);
+                    o[x] += corr[x];
+                    e[x] = logmult;
+                } else {
+                    o[x] += corr[x] * exp(logmult - e[x]);
+                }
+            }
+        }
+    }
+    for (int32_t c = 0; c < n; ++c) { /* :105-115; with U == 0 'totalprob' stays NA upstream */
+        const double lt = U > 0 ? total[c] : NAN;
+        for (int32_t x = 0; x < g; ++x) out[(size_t)c * g + x] *= exp(expo[(size_t)c * g + x] - lt);
+    }
+    free(expo);
+    free(logw);
+    free(total);
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * adjust_shift_variance -- follows src/adjust_shift_variance.cpp:9-164 (+ src/utils.cpp:6-13).
+ * data1 : g x n1 col-major; data2 : g x n2 col-major; vect : n2 x g col-major (R matrix, cell rows);
+ * restrict1/2 : 0-based cell ids.  out : n2.
+ * ---------------------------------------------------------------------------------------------- */
+static double dist2_to_line(const double* ref, const double* grad, const double* point, double* work, int32_t g) {
+    /* :9-27 */
+    double scale = 0.0;
+    for (int32_t x = 0; x < g; ++x) {
+        work[x] = ref[x] - point[x];
+    }
+    for (int32_t x = 0; x < g; ++x) scale += work[x] * grad[x];
+    double dist = 0.0;
+    for (int32_t x = 0; x < g; ++x) {
+        double w = work[x] - scale * grad[x];
+        dist += w * w;
+    }
+    return dist;
+}
+
+typedef struct {
+    double proj, logw;
+} pw_t;
+
+static int pw_cmp(const void* a, const void* b) { /* std::sort on pair<double,double>: lexicographic (:134) */
+    const pw_t* x = (const pw_t*)a;
+    const pw_t* y = (const pw_t*)b;
+    if (x->proj < y->proj) return -1;
+    if (x->proj > y->proj) return 1;
+    if (x->logw < y->logw) return -1;
+    if (x->logw > y->logw) return 1;
+    return 0;
+}
+
+static double dot(const double* a, const double* b, int32_t g) {
+    double s = 0.0;
+    for (int32_t x = 0; x < g; ++x) s += a[x] * b[x];
+    return s;
+}
+
+int orc_adjust_shift_variance(const double* data1, int32_t g1, int32_t n1, const double* data2, int32_t g2, int32_t n2,
+                              const double* vect, int32_t vrow, int32_t vcol, double sigma2, const int32_t* restrict1,
+                              int32_t nr1, const int32_t* restrict2, int32_t nr2, double* out) {
+    if (g1 != g2 || g1 != vcol) return ORC_ERR_DIM_GENES; /* :33-36 */
+    if (n2 != vrow) return ORC_ERR_DIM_CELLS;             /* :38-41 */
+    for (int32_t i = 0; i < nr1; ++i)
+        if (restrict1[i] == INT32_MIN || restrict1[i] < 0 || restrict1[i] >= n1) return ORC_ERR_SUBSET;
+    for (int32_t i = 0; i < nr2; ++i)
+        if (restrict2[i] == INT32_MIN || restrict2[i] < 0 || restrict2[i] >= n2) return ORC_ERR_SUBSET;
+    const int32_t g = g1;
+    int fail = 0;
+#pragma omp parallel
+    {
+        double* work = (double*)malloc(((size_t)g + 1) * sizeof(double));
+        double* grad = (double*)malloc(((size_t)g + 1) * sizeof(double));
+        pw_t* d1 = (pw_t*)malloc(((size_t)nr1 + 1) * sizeof(pw_t));
+        if (!work || !grad || !d1) {
+#pragma omp atomic write
+            fail = 1;
+        }
+#pragma omp for schedule(dynamic, 4)
+        for (int32_t cell = 0; cell < n2; ++cell) {
+            if (!work || !grad || !d1) continue;
+            const double* cur = data2 + (size_t)cell * g;
+            double l2 = 0.0; /* :57-68 */
+            for (int32_t x = 0; x < g; ++x) {
+                grad[x] = vect[(size_t)x * n2 + cell];
+                l2 += grad[x] * grad[x];
+            }
+            l2 = sqrt(l2);
+            if (l2 != 0.0)
+                for (int32_t x = 0; x < g; ++x) grad[x] /= l2;
+            const double curproj = dot(grad, cur, g); /* :70 */
+
+            double prob2 = 0.0, tot2 = 0.0; /* :74-112 */
+            int first_p = 1, first_t = 1;
+            for (int32_t s = 0; s < nr2; ++s) {
+                const int32_t same = restrict2[s];
+                int add = 1;
+                double lp = 0.0;
+                if (same != cell) {
+                    const double* sc = data2 + (size_t)same * g;
+                    const double sproj = dot(grad, sc, g);
+                    const double sd = dist2_to_line(cur, grad, sc, work, g);
+                    lp = -sd / sigma2;
+                    if (sproj > curproj) add = 0;
+                }
+                if (add) {
+                    prob2 = first_p ? lp : logspace_add(prob2, lp);
+                    first_p = 0;
+                }
+                tot2 = first_t ? lp : logspace_add(tot2, lp);
+                first_t = 0;
+            }
+            prob2 -= tot2;
+
+            double tot1 = 0.0; /* :115-135 */
+            for (int32_t o = 0; o < nr1; ++o) {
+                const double* oc = data1 + (size_t)restrict1[o] * g;
+                d1[o].proj = dot(grad, oc, g);
+                d1[o].logw = -dist2_to_line(cur, grad, oc, work, g) / sigma2;
+                tot1 = o == 0 ? d1[o].logw : logspace_add(tot1, d1[o].logw);
+            }
+            qsort(d1, (size_t)nr1, sizeof(pw_t), pw_cmp);
+
+            double ref_quan = NAN; /* :138-157 */
+            if (nr1 > 0) {
+                const double target = prob2 + tot1;
+                double cum = 0.0;
+                ref_quan = d1[nr1 - 1].proj;
+                for (int32_t o = 0; o < nr1; ++o) {
+                    cum = o == 0 ? d1[o].logw : logspace_add(cum, d1[o].logw);
+                    if (cum >= target) {
+                        ref_quan = d1[o].proj;
+                        break;
+                    }
+                }
+            }
+            out[cell] = (ref_quan - curproj) / l2; /* :160 */
+        }
+        free(work);
+        free(grad);
+        free(d1);
+    }
+    return fail ? ORC_ERR_NOMEM : ORC_OK;
+}
