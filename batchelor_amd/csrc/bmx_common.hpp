@@ -1,0 +1,86 @@
+// Shared host-side helpers for the MI355X fastMNN hot path (gfx950 only; no CUDA paths).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/batchelor_mi355x.h"
+
+namespace bmx {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define BMX_HIP(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            throw bmx::Error(BMX_ERR_HIP, std::string(#expr) + " failed: " + hipGetErrorString(e_));    \
+    } while (0)
+
+#define BMX_LAUNCH_CHECK() BMX_HIP(hipGetLastError())
+
+inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+// Grow-only device buffer: the engine keeps these across calls so a steady-state run allocates nothing.
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept {
+        if (this != &o) { release(); p = o.p; cap = o.cap; o.p = nullptr; o.cap = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    T* reserve(size_t n) {
+        if (n > cap) {
+            release();
+            size_t want = n + n / 8 + 64;
+            BMX_HIP(hipMalloc((void**)&p, want * sizeof(T)));
+            cap = want;
+        }
+        return p;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// Device-level operations (all on `stream`, all pointers device pointers, matrices row-major cells x dims)
+// ---------------------------------------------------------------------------------------------------
+struct KnnWorkspace {
+    DevBuf<float> pq, pr;          // prepared (centred, f32, augmented) queries / references
+    DevBuf<double> qn2, rn2, mean, red;
+    DevBuf<int32_t> cand;          // [nq][C][KS]
+    DevBuf<float> tau;             // [nq][C]
+    DevBuf<int32_t> flagged;       // [nq + 1] compact list of queries needing the exact path (+ counter)
+    DevBuf<double> drow;           // exact-path distance rows
+    DevBuf<int32_t> idx_tmp;
+    DevBuf<double> dist_tmp;
+    int64_t last_flagged = 0;      // diagnostics: queries that took the exact path in the last call
+    int force_exact = 0;           // testing hook: route every query through the exact path
+};
+
+// For rows q in [q_begin, q_end) of the query list: the k nearest rows of the reference list (exact, FP64 Euclidean,
+// ties by lowest position).  X/Q are row-major [*, d]; ref_rows / q_rows (0-based, may be null = identity) select
+// nr / nq rows.  idx_out [nq][k] receives 0-based POSITIONS in the reference list; dist_out [nq][k] Euclidean
+// distances (may be null).  Only rows [q_begin, q_end) of the outputs are written.
+void knn_device(hipStream_t stream, KnnWorkspace& ws, const double* X, const int32_t* ref_rows, int nr,
+                const double* Q, const int32_t* q_rows, int nq, int d, int k, int32_t* idx_out, double* dist_out,
+                int q_begin, int q_end);
+
+}  // namespace bmx

@@ -1,0 +1,61 @@
+"""GPU parity: HIP exact kNN (through the C ABI) vs the CPU oracle -- indices bit-exact, distances bitwise."""
+import numpy as np
+import pytest
+
+from tests.conftest import synth_batches
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nb():
+    from batchelor_amd import neighbors
+    return neighbors
+
+
+@pytest.mark.parametrize("nx,nq,d,k", [(2000, 2000, 50, 20), (5000, 3000, 50, 20), (700, 1300, 10, 5),
+                                       (4000, 1000, 100, 20), (3000, 500, 20, 30), (300, 300, 2, 1)])
+def test_query_knn_matches_oracle(oracle, nb, nx, nq, d, k):
+    X, Q = synth_batches(1, [nx, nq], d)
+    idx, dist = nb.query_knn(X, Q, k)
+    oi, od = oracle.query_knn(X, Q, k)
+    assert np.array_equal(idx, oi)
+    assert np.array_equal(dist, od)  # same FP64 summation order -> bitwise
+    assert nb.last_knn_exact_fallbacks() <= nq // 100
+
+
+def test_query_knn_exact_path_and_ties(oracle, nb):
+    # duplicated points: every query is a tie; lowest index must win
+    core = np.column_stack([np.repeat(np.arange(1, 11), 10), np.tile(np.arange(1, 11), 10)]).astype(np.float64)
+    X = np.vstack([core, core, core])
+    idx, dist = nb.query_knn(X, core, 3)
+    oi, od = oracle.query_knn(X, core, 3)
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+    # forced exact path on ordinary data gives the same answer as the MFMA path
+    X, Q = synth_batches(2, [1500, 900], 50)
+    a = nb.query_knn(X, Q, 20)
+    nb.set_force_exact_knn(True)
+    try:
+        b = nb.query_knn(X, Q, 20)
+    finally:
+        nb.set_force_exact_knn(False)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_query_knn_small_and_edge_shapes(oracle, nb):
+    X, Q = synth_batches(3, [37, 5], 7)
+    for k in (1, 20, 37):
+        idx, dist = nb.query_knn(X, Q, k)
+        oi, od = oracle.query_knn(X, Q, k)
+        assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+    with pytest.raises(RuntimeError, match="exceeds"):
+        nb.query_knn(X, Q, 38)
+    idx, dist = nb.query_knn(X, Q[:0], 3)
+    assert idx.shape == (0, 3)
+
+
+def test_query_knn_large_k_uses_exact_scan(oracle, nb):
+    X, Q = synth_batches(4, [400, 100], 10)
+    idx, dist = nb.query_knn(X, Q, 80)
+    oi, od = oracle.query_knn(X, Q, 80)
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od)
