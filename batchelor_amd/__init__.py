@@ -5,3 +5,5 @@ arithmetic runs in hand-written HIP kernels for gfx950 behind the C ABI of inclu
 """
 from ._lib import BatchelorMI355XError, device_count  # noqa: F401
 from .neighbors import query_knn  # noqa: F401
+from .reduced_mnn import MnnEngine, MnnResult, divideIntoBatches, reducedMNN  # noqa: F401
+from .natives import (adjust_shift_variance, find_mutual_nn, find_mutual_nns, smooth_gaussian_kernel)  # noqa: F401

@@ -73,6 +73,9 @@ struct KnnWorkspace {
     DevBuf<double> dist_tmp;
     int64_t last_flagged = 0;      // diagnostics: queries that took the exact path in the last call
     int force_exact = 0;           // testing hook: route every query through the exact path
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;  // profiling: recorded around the MFMA top-k launch when set
+    bool topk_launched = false;
+    unsigned long long* flag_total = nullptr;  // device counter accumulating exact-path queries (optional)
 };
 
 // For rows q in [q_begin, q_end) of the query list: the k nearest rows of the reference list (exact, FP64 Euclidean,

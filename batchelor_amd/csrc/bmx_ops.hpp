@@ -1,6 +1,68 @@
 // Device-level building blocks of the merge loop (implemented in pairs.hip / correct.hip / legacy.hip).
+// All pointers are device pointers, all matrices row-major [cells x d] FP64, all launches go to `stream`.
 #pragma once
 #include "bmx_common.hpp"
 
 namespace bmx {
+
+// ---- scan / small utilities (pairs.hip) ------------------------------------------------------------
+struct ScanWorkspace {
+    DevBuf<int32_t> block_sums, block_offs;
+};
+// out[i] = sum_{j<i} in[j] for i in [0, n]; out has n + 1 entries (out[n] = total).  in/out may not alias.
+void exclusive_scan_i32(hipStream_t stream, ScanWorkspace& ws, const int32_t* in, int32_t* out, int n);
+
+// ---- mutual nearest neighbours (pairs.hip) ---------------------------------------------------------
+// idxLR [nL][k2]: for each left cell the positions of its nearest right cells (rank order);
+// idxRL [nR][k1]: for each right cell the positions of its nearest left cells.
+// cntL[l]  = number of mutual partners of left cell l;   flags via the emit kernel.
+// partR [nR][k1]: mutual left partners of each right cell, ascending; cntR[r] their number.
+void mutual_counts(hipStream_t stream, const int32_t* idxLR, int nL, int k2, const int32_t* idxRL, int nR, int k1,
+                   int32_t* cntL, int32_t* partR, int32_t* cntR);
+// Pairs in the reference order (src/find_mutual_nns.cpp:23-36): left ascending, then the left cell's neighbour rank.
+// offL = exclusive scan of cntL.  Ids written are lrows[l] + 1 / rrows[r] + 1 (1-based rows in the node; identity if null).
+void emit_pairs(hipStream_t stream, const int32_t* idxLR, int nL, int k2, const int32_t* idxRL, int k1,
+                const int32_t* offL, const int32_t* lrows, const int32_t* rrows, int32_t* first, int32_t* second);
+// second_u = ascending positions r with cntR[r] > 0 (offR = exclusive scan of the 0/1 flags, computed here).
+void compact_mnn_cells(hipStream_t stream, ScanWorkspace& ws, const int32_t* cntR, int nR, int32_t* flagR,
+                       int32_t* offR, int32_t* second_u);
+
+// ---- correction primitives (correct.hip) -----------------------------------------------------------
+struct ReduceWorkspace {
+    DevBuf<double> partial;
+};
+// mode 0: sum x, 1: sum x^2, 2: sum (x - centre[c])^2 over rows [r0, r1) of X (optionally through a row list).
+// out[c] = scale * sum.  Deterministic two-stage reduction.
+void col_reduce(hipStream_t stream, ReduceWorkspace& ws, const double* X, const int32_t* rows, int r0, int r1, int d,
+                int mode, const double* centre, double scale, double* out);
+// out[0] = scale * sum_c in[c]   (single thread; d is tiny)
+void sum_vector(hipStream_t stream, const double* in, int d, double scale, double* out);
+
+// .average_correction (R/fastMNN.R:567-580): for the u-th MNN-involved right cell (position second_u[u]) the mean of
+// L[lrows[l]] - R[rrows[r]] over its partners l (ascending).  averaged [U][d].
+void average_correction(hipStream_t stream, const double* L, const int32_t* lrows, const double* R,
+                        const int32_t* rrows, int d, const int32_t* second_u, int U, const int32_t* partR,
+                        const int32_t* cntR, int k1, double* averaged);
+
+// .center_along_batch_vector (R/fastMNN.R:626-640) in place on X [n][d]; vec [d] un-normalised; the centre is the
+// mean projection over the restrict rows (or all rows when restrict == nullptr).  loc: scratch [n].
+void center_along_batch_vector(hipStream_t stream, ReduceWorkspace& ws, double* X, int n, int d, const double* vec,
+                               const int32_t* restrict_rows, int n_restrict, double* loc, double* scratch3);
+
+// .compute_tricube_average + add (R/utils_tricube.R:1-27, R/fastMNN.R:606-607) in place on X [n][d].
+// idx [n][k] positions into `averaged` rows, dist [n][k] ascending Euclidean distances.
+void tricube_apply(hipStream_t stream, double* X, int n, int d, const double* averaged, const int32_t* idx,
+                   const double* dist, int k, double ndist);
+
+// layout helpers
+void transpose_cm_to_rm(hipStream_t stream, const double* cm, int n, int d, double* rm);  // [n x d] col-major -> row-major
+void transpose_rm_to_cm(hipStream_t stream, const double* rm, int n, int d, double* cm, int ld_cm, int row_off);
+
+// ---- legacy natives (legacy.hip) -------------------------------------------------------------------
+void smooth_gaussian_kernel_device(hipStream_t stream, const double* averaged, int g, int U, const int32_t* index,
+                                   const double* mat, int gd, int n, double sigma2, double* out, double* ws_density);
+void adjust_shift_variance_device(hipStream_t stream, const double* data1, int g, int n1, const double* data2, int n2,
+                                  const double* vect, double sigma2, const int32_t* restrict1, int nr1,
+                                  const int32_t* restrict2, int nr2, double* out, double* ws_pairs);
+
 }  // namespace bmx

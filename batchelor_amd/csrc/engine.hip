@@ -1,0 +1,632 @@
+// Merge engine (host orchestration of the HIP kernels): R/fastMNN.R:398-562, R/MNN_tree.R:61-77,113-226.
+#include "engine.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+
+namespace bmx {
+namespace {
+
+__global__ void gather_rows_i32(const int32_t* __restrict__ pos, int n, const int32_t* __restrict__ rows,
+                                int32_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = rows ? rows[pos[i]] : pos[i];
+}
+
+__global__ void iota_offset(int32_t* __restrict__ out, int n, int off) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = off + i;
+}
+
+__global__ void add_offset_copy(const int32_t* __restrict__ in, int n, int off, int32_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i] + off;
+}
+
+// .choose_k (R/MNN_tree.R:140-146); R's round() is half-to-even = nearbyint in the default rounding mode
+int choose_k(int k, double prop_k, int N) {
+    if (std::isnan(prop_k)) return k;
+    const double r = std::nearbyint(prop_k * (double)N);
+    const double m = std::max((double)k, r);
+    return (int)std::min((double)N, m);
+}
+
+}  // namespace
+
+void bmx_shard_range_impl(int64_t n, int rank, int world, int64_t* begin, int64_t* end) {
+    const int64_t per = world > 0 ? (n + world - 1) / world : n;
+    const int64_t b = std::min<int64_t>(n, per * rank);
+    *begin = b;
+    *end = std::min<int64_t>(n, b + per);
+}
+
+Engine::Engine(int device) : device_(device) {
+    BMX_HIP(hipSetDevice(device_));
+    BMX_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    unsigned long long* tot = reinterpret_cast<unsigned long long*>(scal_.reserve(4096));
+    (void)tot;
+}
+
+Engine::~Engine() {
+    for (auto& e : events_) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+void Engine::set_shard(int rank, int world, bmx_allgather_fn fn, void* ctx) {
+    if (world < 1 || rank < 0 || rank >= world) throw Error(BMX_ERR_ARG, "invalid rank / world size");
+    if (world > 1 && !fn) throw Error(BMX_ERR_ARG, "a multi-rank engine needs an all-gather callback");
+    rank_ = rank;
+    world_ = world;
+    gather_fn_ = fn;
+    gather_ctx_ = ctx;
+}
+
+void Engine::exchange(void* buf, int64_t bytes_per_rank) {
+    if (world_ == 1) return;
+    BMX_HIP(hipStreamSynchronize(stream_));
+    const int rc = gather_fn_(gather_ctx_, buf, bytes_per_rank);
+    if (rc != 0) throw Error(BMX_ERR_EXCHANGE, "the all-gather callback failed with code " + std::to_string(rc));
+}
+
+void Engine::upload(int nbatches, int d, const double* const* data, const int32_t* nrows,
+                    const int32_t* const* restrict_idx, const int32_t* n_restrict) {
+    BMX_HIP(hipSetDevice(device_));
+    if (nbatches < 2) throw Error(BMX_ERR_ARG, "at least two batches must be specified");  // R/fastMNN.R:345
+    if (d < 1 || d > 256) throw Error(BMX_ERR_ARG, "number of dimensions must be in [1, 256]");
+    B_ = nbatches;
+    d_ = d;
+    N_ = 0;
+    nrows_.assign(nrows, nrows + nbatches);
+    inputs_cm_.clear();
+    inputs_cm_.resize(nbatches);
+    inputs_restrict_.clear();
+    inputs_restrict_.resize(nbatches);
+    n_restrict_.assign(nbatches, -1);
+    for (int b = 0; b < nbatches; ++b) {
+        if (nrows[b] < 1) throw Error(BMX_ERR_ARG, "every batch needs at least one cell");
+        N_ += nrows[b];
+        double* p = inputs_cm_[b].reserve((size_t)nrows[b] * d);
+        BMX_HIP(hipMemcpyAsync(p, data[b], (size_t)nrows[b] * d * sizeof(double), hipMemcpyHostToDevice, stream_));
+        const bool has = restrict_idx && restrict_idx[b] && n_restrict && n_restrict[b] >= 0;
+        if (has) {
+            const int m = n_restrict[b];
+            if (m == 0) throw Error(BMX_ERR_ARG, "no cells remaining in a batch after restriction");  // R/checkInputs.R:116
+            std::vector<int32_t> z(m);
+            for (int i = 0; i < m; ++i) {
+                const int32_t v = restrict_idx[b][i];
+                if (v < 1 || v > nrows[b]) throw Error(BMX_ERR_SUBSET, "subset indices out of range");
+                if (i > 0 && v <= restrict_idx[b][i - 1])
+                    throw Error(BMX_ERR_ARG, "'restrict' must be strictly increasing within each batch");
+                z[i] = v - 1;
+            }
+            int32_t* rp = inputs_restrict_[b].reserve(m);
+            BMX_HIP(hipMemcpyAsync(rp, z.data(), (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+            BMX_HIP(hipStreamSynchronize(stream_));  // z goes out of scope
+            n_restrict_[b] = m;
+        }
+    }
+    if (N_ > std::numeric_limits<int32_t>::max() / 2) throw Error(BMX_ERR_ARG, "too many cells for int32 indices");
+    BMX_HIP(hipStreamSynchronize(stream_));
+}
+
+void Engine::knn(const double* X, const int32_t* ref_rows, int nr, const double* Q, const int32_t* q_rows, int nq,
+                 int k, int32_t* idx, double* dist) {
+    // query rows are split over ranks; the padded per-rank slices are contiguous, so the all-gather is in place
+    int64_t b = 0, e = nq;
+    bmx_shard_range_impl(nq, rank_, world_, &b, &e);
+    if (profiling_) {
+        if (events_used_ == events_.size()) {
+            hipEvent_t a, c;
+            BMX_HIP(hipEventCreate(&a));
+            BMX_HIP(hipEventCreate(&c));
+            events_.emplace_back(a, c);
+        }
+        knn_ws_.ev_begin = events_[events_used_].first;
+        knn_ws_.ev_end = events_[events_used_].second;
+    } else {
+        knn_ws_.ev_begin = knn_ws_.ev_end = nullptr;
+    }
+    knn_device(stream_, knn_ws_, X, ref_rows, nr, Q, q_rows, nq, d_, k, idx, dist, (int)b, (int)e);
+    if (profiling_ && knn_ws_.topk_launched) ++events_used_;
+    if (world_ > 1) {
+        const int64_t per = (nq + world_ - 1) / world_;
+        exchange(idx, per * k * (int64_t)sizeof(int32_t));
+        if (dist) exchange(dist, per * k * (int64_t)sizeof(double));
+    }
+}
+
+Engine::MnnOut Engine::find_mnn(const Node& left, const Node& right, int k, double prop_k) {
+    // .restricted_mnn (R/MNN_tree.R:113-133): search among the restricted rows only
+    const int nL = left.has_restrict ? left.n_restrict : left.n;
+    const int nR = right.has_restrict ? right.n_restrict : right.n;
+    const int32_t* lrows = left.has_restrict ? left.restrict_rows.p : nullptr;
+    const int32_t* rrows = right.has_restrict ? right.restrict_rows.p : nullptr;
+    MnnOut o;
+    o.k1 = std::min(choose_k(k, prop_k, nL), nL);  // neighbours sought in LEFT for each right cell
+    o.k2 = std::min(choose_k(k, prop_k, nR), nR);  // neighbours sought in RIGHT for each left cell
+    if (o.k1 < 1 || o.k2 < 1) throw Error(BMX_ERR_ARG, "'k' must be positive");
+    const int64_t perL = (nL + world_ - 1) / world_ * (int64_t)world_;
+    const int64_t perR = (nR + world_ - 1) / world_ * (int64_t)world_;
+    int32_t* idxLR = idxLR_.reserve((size_t)perL * o.k2);
+    int32_t* idxRL = idxRL_.reserve((size_t)perR * o.k1);
+    knn(right.data.p, rrows, nR, left.data.p, lrows, nL, o.k2, idxLR, nullptr);
+    knn(left.data.p, lrows, nL, right.data.p, rrows, nR, o.k1, idxRL, nullptr);
+    int32_t* cntL = cntL_.reserve(nL);
+    int32_t* offL = offL_.reserve((size_t)nL + 1);
+    int32_t* partR = partR_.reserve((size_t)nR * o.k1);
+    int32_t* cntR = cntR_.reserve(nR);
+    int32_t* flagR = flagR_.reserve(nR);
+    int32_t* offR = offR_.reserve((size_t)nR + 1);
+    int32_t* second_u = second_u_.reserve(nR);
+    mutual_counts(stream_, idxLR, nL, o.k2, idxRL, nR, o.k1, cntL, partR, cntR);
+    exclusive_scan_i32(stream_, scan_ws_, cntL, offL, nL);
+    compact_mnn_cells(stream_, scan_ws_, cntR, nR, flagR, offR, second_u);
+    int32_t h[2] = {0, 0};
+    BMX_HIP(hipMemcpyAsync(&h[0], offL + nL, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+    BMX_HIP(hipMemcpyAsync(&h[1], offR + nR, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+    BMX_HIP(hipStreamSynchronize(stream_));
+    o.P = h[0];
+    o.U = h[1];
+    return o;
+}
+
+void Engine::perbatch_var(const Node& node, int scal_off) {
+    // .compute_perbatch_var (R/fastMNN.R:651-658): per original batch, sum over dims of the sample variance
+    double* tmp = vecs_.p + (size_t)(2 * B_ + 4) * d_;  // two scratch vectors behind the extras pool
+    int r0 = 0;
+    int slot = scal_off;
+    for (const Segment& s : node.origin) {
+        col_reduce(stream_, red_ws_, node.data.p, nullptr, r0, r0 + s.n, d_, 0, nullptr, 1.0 / (double)s.n, tmp);
+        col_reduce(stream_, red_ws_, node.data.p, nullptr, r0, r0 + s.n, d_, 2, tmp, 1.0 / (double)(s.n - 1),
+                   tmp + d_);
+        sum_vector(stream_, tmp + d_, d_, 1.0, scal_.p + slot);
+        r0 += s.n;
+        slot += 2;
+    }
+}
+
+void Engine::orthogonalize(Node& node, const std::vector<int>& extras) {
+    // .orthogonalize_other (R/fastMNN.R:642-647): sequentially, each on the result of the previous
+    double* loc = loc_.reserve((size_t)node.n + 8);
+    for (int id : extras)
+        center_along_batch_vector(stream_, red_ws_, node.data.p, node.n, d_, vecs_.p + (size_t)id * d_,
+                                  node.has_restrict ? node.restrict_rows.p : nullptr, node.n_restrict, loc,
+                                  loc + node.n);
+}
+
+std::unique_ptr<Node> Engine::clone_node(const Node& src) {
+    auto n = std::make_unique<Node>();
+    n->index = src.index;
+    n->n = src.n;
+    n->origin = src.origin;
+    n->extras = src.extras;
+    n->has_restrict = src.has_restrict;
+    n->n_restrict = src.n_restrict;
+    double* p = n->data.reserve((size_t)src.n * d_);
+    BMX_HIP(hipMemcpyAsync(p, src.data.p, (size_t)src.n * d_ * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+    if (src.has_restrict) {
+        int32_t* r = n->restrict_rows.reserve(src.n_restrict);
+        BMX_HIP(hipMemcpyAsync(r, src.restrict_rows.p, (size_t)src.n_restrict * sizeof(int32_t),
+                               hipMemcpyDeviceToDevice, stream_));
+    }
+    return n;
+}
+
+int Engine::count_mnn_pairs(const Node& left, const Node& right, const bmx_params_t& p) {
+    // one (left, right) evaluation of .count_mnn_pairs (R/MNN_tree.R:171-193) on orthogonalised COPIES
+    const Node* l = &left;
+    const Node* r = &right;
+    std::unique_ptr<Node> lc, rc;
+    if (!left.extras.empty()) {
+        rc = clone_node(right);
+        orthogonalize(*rc, left.extras);
+        r = rc.get();
+    }
+    if (!right.extras.empty()) {
+        lc = clone_node(left);
+        orthogonalize(*lc, right.extras);
+        l = lc.get();
+    }
+    const MnnOut o = find_mnn(*l, *r, p.k, p.prop_k);
+    return (int)o.P;
+}
+
+void Engine::merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p, std::unique_ptr<Node>& merged) {
+    MergeRecord& rec = merges_[mdx];
+    rec.left_set = left.index;
+    rec.right_set = right.index;
+    const int nseg = (int)(left.origin.size() + right.origin.size());
+    rec.var_batches.clear();
+    for (const Segment& s : left.origin) rec.var_batches.push_back(s.batch);
+    for (const Segment& s : right.origin) rec.var_batches.push_back(s.batch);
+    const int off_l = rec.scal_off, off_r = rec.scal_off + 2 * (int)left.origin.size();
+    (void)nseg;
+
+    perbatch_var(left, off_l);   // "old" variances (R/fastMNN.R:467-468)
+    perbatch_var(right, off_r);
+
+    orthogonalize(right, left.extras);  // R/fastMNN.R:473-474
+    orthogonalize(left, right.extras);
+
+    const MnnOut mo = find_mnn(left, right, p.k, p.prop_k);  // R/fastMNN.R:476-477
+    if (mo.P == 0) throw Error(BMX_ERR_NO_PAIRS, "no mutual nearest neighbours found between batches");
+    const int nLs = left.has_restrict ? left.n_restrict : left.n;
+    const int nRs = right.has_restrict ? right.n_restrict : right.n;
+    const int32_t* lrows = left.has_restrict ? left.restrict_rows.p : nullptr;
+    const int32_t* rrows = right.has_restrict ? right.restrict_rows.p : nullptr;
+    rec.npairs = mo.P;
+    rec.stats[0] = nLs;
+    rec.stats[1] = nRs;
+    rec.stats[2] = mo.U;
+    rec.stats[3] = mo.P;
+    rec.stats[4] = left.n;
+    rec.stats[5] = right.n;
+    int32_t* first = rec.first.reserve((size_t)mo.P);
+    int32_t* second = rec.second.reserve((size_t)mo.P);
+    emit_pairs(stream_, idxLR_.p, nLs, mo.k2, idxRL_.p, mo.k1, offL_.p, lrows, rrows, first, second);
+
+    // .average_correction + overall.batch (R/fastMNN.R:480-481)
+    double* averaged = averaged_.reserve((size_t)mo.U * d_);
+    average_correction(stream_, left.data.p, lrows, right.data.p, rrows, d_, second_u_.p, mo.U, partR_.p, cntR_.p,
+                       mo.k1, averaged);
+    const int vid = n_extras_;  // slot of this merge's overall.batch in the pool
+    double* overall = vecs_.p + (size_t)vid * d_;
+    col_reduce(stream_, red_ws_, averaged, nullptr, 0, mo.U, d_, 0, nullptr, 1.0 / (double)mo.U, overall);
+
+    bool do_correct = true;
+    rec.batch_size_na = std::isnan(p.min_batch_skip);
+    rec.skipped = false;
+    if (!rec.batch_size_na) {
+        // .get_batch_magnitude (R/fastMNN.R:582-595): sqrt(sum(ave^2) / sum(colMeans(correction^2)))
+        double* msq = vecs_.p + (size_t)(2 * B_ + 4) * d_;
+        col_reduce(stream_, red_ws_, averaged, nullptr, 0, mo.U, d_, 1, nullptr, 1.0 / (double)mo.U, msq);
+        std::vector<double> h(2 * (size_t)d_);
+        BMX_HIP(hipMemcpyAsync(h.data(), overall, d_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        BMX_HIP(hipMemcpyAsync(h.data() + d_, msq, d_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        BMX_HIP(hipStreamSynchronize(stream_));
+        double l2sq = 0.0, ave_l2sq = 0.0;
+        for (int c = 0; c < d_; ++c) {
+            ave_l2sq += h[d_ + c];
+            l2sq += h[c] * h[c];
+        }
+        rec.batch_size = ave_l2sq == 0.0 ? 0.0 : std::sqrt(l2sq / ave_l2sq);
+        if (rec.batch_size < p.min_batch_skip) {
+            do_correct = false;
+            rec.skipped = true;
+        }
+    }
+
+    if (do_correct) {
+        double* loc = loc_.reserve((size_t)std::max(left.n, right.n) + 8);
+        center_along_batch_vector(stream_, red_ws_, left.data.p, left.n, d_, overall, lrows, nLs, loc,
+                                  loc + std::max(left.n, right.n));  // R/fastMNN.R:496-497
+        center_along_batch_vector(stream_, red_ws_, right.data.p, right.n, d_, overall, rrows, nRs, loc,
+                                  loc + std::max(left.n, right.n));
+        perbatch_var(left, off_l + 1);  // "new" variances (R/fastMNN.R:500-501)
+        perbatch_var(right, off_r + 1);
+
+        // R/fastMNN.R:505-507: re-average on the centred data, then the tricube-smoothed correction of the right batch
+        average_correction(stream_, left.data.p, lrows, right.data.p, rrows, d_, second_u_.p, mo.U, partR_.p,
+                           cntR_.p, mo.k1, averaged);
+        const int k_tc = choose_k(p.k, p.prop_k, right.n);  // unrestricted size of the right batch
+        const int safe_k = std::min(k_tc, mo.U);
+        int32_t* srows = second_rows_.reserve(mo.U);
+        hipLaunchKernelGGL(gather_rows_i32, dim3(cdiv(mo.U, 256)), dim3(256), 0, stream_, second_u_.p, mo.U, rrows,
+                           srows);
+        BMX_LAUNCH_CHECK();
+        const int64_t per = (right.n + world_ - 1) / world_ * (int64_t)world_;
+        int32_t* idxT = idxT_.reserve((size_t)per * safe_k);
+        double* distT = distT_.reserve((size_t)per * safe_k);
+        knn(right.data.p, srows, mo.U, right.data.p, nullptr, right.n, safe_k, idxT, distT);
+        tricube_apply(stream_, right.data.p, right.n, d_, averaged, idxT, distT, safe_k, p.ndist);
+        ++n_extras_;
+    } else {
+        perbatch_var(left, off_l + 1);
+        perbatch_var(right, off_r + 1);
+    }
+
+    // UPDATE (R/fastMNN.R:520-525): rbind, combine restrict, concatenate origin / extras
+    merged = std::make_unique<Node>();
+    Node& m = *merged;
+    m.index = left.index;
+    m.index.insert(m.index.end(), right.index.begin(), right.index.end());
+    m.n = left.n + right.n;
+    double* md = m.data.reserve((size_t)m.n * d_);
+    BMX_HIP(hipMemcpyAsync(md, left.data.p, (size_t)left.n * d_ * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+    BMX_HIP(hipMemcpyAsync(md + (size_t)left.n * d_, right.data.p, (size_t)right.n * d_ * sizeof(double),
+                           hipMemcpyDeviceToDevice, stream_));
+    m.origin = left.origin;
+    m.origin.insert(m.origin.end(), right.origin.begin(), right.origin.end());
+    m.extras = left.extras;
+    m.extras.insert(m.extras.end(), right.extras.begin(), right.extras.end());
+    if (do_correct) m.extras.push_back(vid);
+    if (left.has_restrict || right.has_restrict) {  // .combine_restrict (R/fastMNN.R:610-622)
+        m.has_restrict = true;
+        m.n_restrict = nLs + nRs;
+        int32_t* mr = m.restrict_rows.reserve(m.n_restrict);
+        if (left.has_restrict)
+            BMX_HIP(hipMemcpyAsync(mr, left.restrict_rows.p, (size_t)nLs * sizeof(int32_t), hipMemcpyDeviceToDevice,
+                                   stream_));
+        else
+            hipLaunchKernelGGL(iota_offset, dim3(cdiv(nLs, 256)), dim3(256), 0, stream_, mr, nLs, 0);
+        if (right.has_restrict)
+            hipLaunchKernelGGL(add_offset_copy, dim3(cdiv(nRs, 256)), dim3(256), 0, stream_, right.restrict_rows.p,
+                               nRs, left.n, mr + nLs);
+        else
+            hipLaunchKernelGGL(iota_offset, dim3(cdiv(nRs, 256)), dim3(256), 0, stream_, mr + nLs, nRs, left.n);
+        BMX_LAUNCH_CHECK();
+    }
+    // the copies above read left/right data: the caller frees those nodes only after the stream has drained them
+    BMX_HIP(hipStreamSynchronize(stream_));
+}
+
+void Engine::run(const bmx_params_t& p, const int32_t* tree, int tree_len) {
+    BMX_HIP(hipSetDevice(device_));
+    if (B_ < 2) throw Error(BMX_ERR_ARG, "at least two batches must be specified");
+    if (p.k < 1) throw Error(BMX_ERR_ARG, "'k' must be positive");
+    const int nmerges = B_ - 1;
+    merges_.clear();
+    merges_.resize(nmerges);
+    n_extras_ = 0;
+    events_used_ = 0;
+    vecs_.reserve((size_t)(2 * B_ + 8) * d_);
+    // variance scalars: every merge records (old, new) for at most B segments
+    {
+        int off = 8;  // slot 0 doubles as the exact-path counter
+        for (int m = 0; m < nmerges; ++m) {
+            merges_[m].scal_off = off;
+            off += 2 * B_;
+        }
+        scal_.reserve(off);
+        BMX_HIP(hipMemsetAsync(scal_.p, 0, (size_t)off * sizeof(double), stream_));
+        scal_host_.assign(off, 0.0);
+    }
+    knn_ws_.flag_total = reinterpret_cast<unsigned long long*>(scal_.p);
+
+    // leaves: row-major working copies of the resident inputs
+    std::vector<TreeSlot> slots;
+    auto make_leaf = [&](int b) {
+        auto n = std::make_unique<Node>();
+        n->index = {b + 1};
+        n->n = nrows_[b];
+        n->origin = {Segment{b + 1, nrows_[b]}};
+        double* dp = n->data.reserve((size_t)n->n * d_);
+        transpose_cm_to_rm(stream_, inputs_cm_[b].p, n->n, d_, dp);
+        if (n_restrict_[b] >= 0) {
+            n->has_restrict = true;
+            n->n_restrict = n_restrict_[b];
+            int32_t* r = n->restrict_rows.reserve(n->n_restrict);
+            BMX_HIP(hipMemcpyAsync(r, inputs_restrict_[b].p, (size_t)n->n_restrict * sizeof(int32_t),
+                                   hipMemcpyDeviceToDevice, stream_));
+        }
+        return n;
+    };
+
+    if (!p.auto_merge) {
+        // rebuild the binary tree from its post-order encoding and validate the leaves (R/MNN_tree.R:96-105)
+        std::vector<int> stack;
+        std::vector<char> seen(B_ + 1, 0);
+        for (int i = 0; i < tree_len; ++i) {
+            const int v = tree[i];
+            if (v == 0) {
+                if (stack.size() < 2) throw Error(BMX_ERR_TREE, "merge tree structure should contain two children per node");
+                TreeSlot s;
+                s.right = stack.back();
+                stack.pop_back();
+                s.left = stack.back();
+                stack.pop_back();
+                slots.push_back(std::move(s));
+                stack.push_back((int)slots.size() - 1);
+            } else {
+                if (v < 1 || v > B_ || seen[v]) throw Error(BMX_ERR_TREE, "invalid leaf nodes specified in 'merge.order'");
+                seen[v] = 1;
+                TreeSlot s;
+                s.node = make_leaf(v - 1);
+                slots.push_back(std::move(s));
+                stack.push_back((int)slots.size() - 1);
+            }
+        }
+        int nleaves = 0;
+        for (int b = 1; b <= B_; ++b) nleaves += seen[b];
+        if (stack.size() != 1 || nleaves != B_) throw Error(BMX_ERR_TREE, "invalid leaf nodes specified in 'merge.order'");
+        const int root = stack.back();
+        for (int mdx = 0; mdx < nmerges; ++mdx) {
+            // .get_next_merge (R/MNN_tree.R:61-69): both children leaves -> merge; else descend into child 2 if it
+            // is still a list, otherwise into child 1
+            int cur = root;
+            for (;;) {
+                TreeSlot& s = slots[cur];
+                const bool l_leaf = (bool)slots[s.left].node, r_leaf = (bool)slots[s.right].node;
+                if (l_leaf && r_leaf) break;
+                cur = !r_leaf ? s.right : s.left;
+            }
+            TreeSlot& s = slots[cur];
+            std::unique_ptr<Node> merged;
+            merge_step(mdx, *slots[s.left].node, *slots[s.right].node, p, merged);
+            slots[s.left].node.reset();
+            slots[s.right].node.reset();
+            s.node = std::move(merged);  // .update_tree (R/MNN_tree.R:71-77)
+        }
+        root_ = std::move(slots[root].node);
+    } else {
+        // auto-merge (R/MNN_tree.R:154-226)
+        std::vector<std::unique_ptr<Node>> rem;
+        for (int b = 0; b < B_; ++b) rem.push_back(make_leaf(b));
+        std::vector<std::vector<int64_t>> stats(B_, std::vector<int64_t>(B_, 0));
+        for (int i = 0; i < B_; ++i)
+            for (int j = 0; j < i; ++j) stats[i][j] = count_mnn_pairs(*rem[i], *rem[j], p);
+        for (int mdx = 0; mdx < nmerges; ++mdx) {
+            // .pick_best_merge: first maximum in column-major order; left = row, right = column
+            const int R = (int)rem.size();
+            int64_t best = -1;
+            int bi = 0, bj = 0;
+            for (int j = 0; j < R; ++j)
+                for (int i = 0; i < R; ++i)
+                    if (stats[i][j] > best) {
+                        best = stats[i][j];
+                        bi = i;
+                        bj = j;
+                    }
+            if (best <= 0) throw Error(BMX_ERR_NO_PAIRS, "no mutual nearest neighbours found between batches");
+            std::unique_ptr<Node> merged;
+            merge_step(mdx, *rem[bi], *rem[bj], p, merged);
+            // .update_remainders: drop both, recount the new node against every remaining one
+            std::vector<std::unique_ptr<Node>> nrem;
+            std::vector<int> keep;
+            for (int i = 0; i < R; ++i)
+                if (i != bi && i != bj) {
+                    keep.push_back(i);
+                    nrem.push_back(std::move(rem[i]));
+                }
+            const int K = (int)keep.size();
+            std::vector<std::vector<int64_t>> ns(K + 1, std::vector<int64_t>(K + 1, 0));
+            for (int a = 0; a < K; ++a)
+                for (int c = 0; c < K; ++c) ns[a][c] = stats[keep[a]][keep[c]];
+            if (K > 0) {
+                // upstream keeps orthogonalising the SAME left copy across j (R/MNN_tree.R:185-186)
+                std::unique_ptr<Node> lcopy = clone_node(*merged);
+                for (int c = 0; c < K; ++c) {
+                    const Node* r = nrem[c].get();
+                    std::unique_ptr<Node> rc;
+                    if (!merged->extras.empty()) {
+                        rc = clone_node(*nrem[c]);
+                        orthogonalize(*rc, merged->extras);
+                        r = rc.get();
+                    }
+                    orthogonalize(*lcopy, nrem[c]->extras);
+                    ns[K][c] = find_mnn(*lcopy, *r, p.k, p.prop_k).P;
+                }
+            }
+            nrem.push_back(std::move(merged));
+            rem = std::move(nrem);
+            stats = std::move(ns);
+        }
+        root_ = std::move(rem[0]);
+    }
+    BMX_HIP(hipMemcpyAsync(scal_host_.data(), scal_.p, scal_host_.size() * sizeof(double), hipMemcpyDeviceToHost,
+                           stream_));
+    BMX_HIP(hipStreamSynchronize(stream_));
+    unsigned long long tot = 0;
+    std::memcpy(&tot, scal_host_.data(), sizeof(tot));
+    fallbacks_ = (int64_t)tot;
+}
+
+void Engine::download(double* corrected, int32_t* batch, int32_t* merge_left, int32_t* merge_right,
+                      double* batch_size, int32_t* skipped, double* lost_var) {
+    BMX_HIP(hipSetDevice(device_));
+    if (!root_) throw Error(BMX_ERR_ARG, "no finished run to download");
+    const int nmerges = B_ - 1;
+    if (corrected) {
+        // rows back in input batch order (R/fastMNN.R:541-547): batch b starts at the sum of earlier batch sizes
+        std::vector<int64_t> start(B_ + 1, 0);
+        for (int b = 0; b < B_; ++b) start[b + 1] = start[b] + nrows_[b];
+        DevBuf<double> out_cm;
+        double* oc = out_cm.reserve((size_t)N_ * d_);
+        int r0 = 0;
+        for (const Segment& s : root_->origin) {
+            transpose_rm_to_cm(stream_, root_->data.p + (size_t)r0 * d_, s.n, d_, oc, (int)N_, (int)start[s.batch - 1]);
+            r0 += s.n;
+        }
+        BMX_HIP(hipMemcpyAsync(corrected, oc, (size_t)N_ * d_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        BMX_HIP(hipStreamSynchronize(stream_));
+    }
+    if (batch) {
+        int64_t o = 0;
+        for (int b = 0; b < B_; ++b)
+            for (int i = 0; i < nrows_[b]; ++i) batch[o++] = b + 1;
+    }
+    for (int m = 0; m < nmerges; ++m) {
+        const MergeRecord& rec = merges_[m];
+        if (merge_left)
+            for (int j = 0; j < B_; ++j) merge_left[(size_t)m * B_ + j] = j < (int)rec.left_set.size() ? rec.left_set[j] : 0;
+        if (merge_right)
+            for (int j = 0; j < B_; ++j)
+                merge_right[(size_t)m * B_ + j] = j < (int)rec.right_set.size() ? rec.right_set[j] : 0;
+        if (batch_size) batch_size[m] = rec.batch_size_na ? std::numeric_limits<double>::quiet_NaN() : rec.batch_size;
+        if (skipped) skipped[m] = rec.skipped ? 1 : 0;
+        if (lost_var) {
+            for (int b = 0; b < B_; ++b) lost_var[(size_t)b * nmerges + m] = 0.0;  // 1 - var.kept, var.kept starts at 1
+            for (size_t s = 0; s < rec.var_batches.size(); ++s) {
+                const double oldv = scal_host_[rec.scal_off + 2 * s], newv = scal_host_[rec.scal_off + 2 * s + 1];
+                lost_var[(size_t)(rec.var_batches[s] - 1) * nmerges + m] = 1.0 - newv / oldv;
+            }
+        }
+    }
+}
+
+void Engine::pairs(int merge, int32_t** left, int32_t** right, int64_t* npairs) {
+    BMX_HIP(hipSetDevice(device_));
+    if (!root_ || merge < 0 || merge >= B_ - 1) throw Error(BMX_ERR_ARG, "merge index out of range");
+    const MergeRecord& rec = merges_[merge];
+    const int64_t P = rec.npairs;
+    std::vector<int32_t> f((size_t)P), s((size_t)P);
+    if (P) {
+        BMX_HIP(hipMemcpyAsync(f.data(), rec.first.p, (size_t)P * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+        BMX_HIP(hipMemcpyAsync(s.data(), rec.second.p, (size_t)P * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+        BMX_HIP(hipStreamSynchronize(stream_));
+    }
+    // R/fastMNN.R:533-547: shift to the node's place in the final merged order, then to the input batch order.
+    // Every node is a contiguous run of whole batches in the root's row order, starting with its first batch.
+    std::vector<int64_t> root_start(B_ + 1, 0), in_start(B_ + 1, 0);
+    {
+        int64_t o = 0;
+        for (const Segment& sg : root_->origin) {
+            root_start[sg.batch] = o;
+            o += sg.n;
+        }
+        for (int b = 0; b < B_; ++b) in_start[b + 1] = in_start[b] + nrows_[b];
+    }
+    auto remap = [&](std::vector<int32_t>& v, const std::vector<int>& set) {
+        // position inside the node -> (batch, row in batch) -> input-order row
+        std::vector<int64_t> seg_start(set.size() + 1, 0);
+        for (size_t i = 0; i < set.size(); ++i) seg_start[i + 1] = seg_start[i] + nrows_[set[i] - 1];
+        for (auto& x : v) {
+            const int64_t pos = x - 1;
+            size_t sgi = std::upper_bound(seg_start.begin(), seg_start.end(), pos) - seg_start.begin() - 1;
+            const int b = set[sgi];
+            x = (int32_t)(in_start[b - 1] + (pos - seg_start[sgi]) + 1);
+        }
+    };
+    remap(f, rec.left_set);
+    remap(s, rec.right_set);
+    int32_t* L = (int32_t*)std::malloc(std::max<size_t>(1, (size_t)P) * sizeof(int32_t));
+    int32_t* R = (int32_t*)std::malloc(std::max<size_t>(1, (size_t)P) * sizeof(int32_t));
+    if (!L || !R) {
+        std::free(L);
+        std::free(R);
+        throw std::bad_alloc();
+    }
+    if (P) {
+        std::memcpy(L, f.data(), (size_t)P * sizeof(int32_t));
+        std::memcpy(R, s.data(), (size_t)P * sizeof(int32_t));
+    }
+    *left = L;
+    *right = R;
+    *npairs = P;
+    (void)root_start;
+}
+
+void Engine::merge_stats(int merge, int64_t* out6) const {
+    if (merge < 0 || merge >= (int)merges_.size()) throw Error(BMX_ERR_ARG, "merge index out of range");
+    for (int i = 0; i < 6; ++i) out6[i] = merges_[merge].stats[i];
+}
+
+void Engine::profile(double* topk_ms, int64_t* launches, int64_t* fallbacks) {
+    double ms = 0.0;
+    for (size_t i = 0; i < events_used_; ++i) {
+        float t = 0.f;
+        BMX_HIP(hipEventElapsedTime(&t, events_[i].first, events_[i].second));
+        ms += t;
+    }
+    if (topk_ms) *topk_ms = ms;
+    if (launches) *launches = (int64_t)events_used_;
+    if (fallbacks) *fallbacks = fallbacks_;
+}
+
+}  // namespace bmx

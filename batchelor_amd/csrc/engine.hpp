@@ -1,0 +1,116 @@
+// The device-resident merge engine: .fast_mnn / .fast_mnn_core (R/fastMNN.R:398-562) with the merge tree of
+// R/MNN_tree.R, driven from one host thread.  Host code only decides sizes and control flow (the merge order, k,
+// whether a merge is skipped); every cell x dimension value stays in HBM from upload to download.
+#pragma once
+#include <memory>
+
+#include "bmx_common.hpp"
+#include "bmx_ops.hpp"
+
+namespace bmx {
+
+struct Segment {
+    int batch;  // 1-based original batch id
+    int n;      // rows
+};
+
+struct Node {
+    std::vector<int> index;  // batch ids in this node, in row order (MNN_treenode@index)
+    DevBuf<double> data;     // [n][d] row-major
+    int n = 0;
+    bool has_restrict = false;
+    DevBuf<int32_t> restrict_rows;  // 0-based, strictly increasing
+    int n_restrict = 0;
+    std::vector<Segment> origin;  // MNN_treenode@origin as run lengths
+    std::vector<int> extras;      // ids of batch vectors in the engine's pool (MNN_treenode@extras)
+};
+
+struct TreeSlot {
+    int left = -1, right = -1;  // children (indices into the slot vector), -1 for a leaf
+    std::unique_ptr<Node> node; // set for leaves (original batches or finished merges)
+};
+
+struct MergeRecord {
+    std::vector<int> left_set, right_set;
+    DevBuf<int32_t> first, second;  // 1-based rows within the left / right node at merge time
+    int64_t npairs = 0;
+    int64_t stats[6] = {0, 0, 0, 0, 0, 0};
+    double batch_size = 0.0;
+    bool batch_size_na = true;
+    bool skipped = false;
+    int scal_off = 0;  // offset of this merge's variance scalars in the device scalar buffer
+    std::vector<int> var_batches;  // batch id of each (old, new) scalar pair, left segments first
+};
+
+void bmx_shard_range_impl(int64_t n, int rank, int world, int64_t* begin, int64_t* end);
+
+class Engine {
+  public:
+    explicit Engine(int device);
+    ~Engine();
+    void set_shard(int rank, int world, bmx_allgather_fn fn, void* ctx);
+    void upload(int nbatches, int d, const double* const* data, const int32_t* nrows,
+                const int32_t* const* restrict_idx, const int32_t* n_restrict);
+    void run(const bmx_params_t& p, const int32_t* tree, int tree_len);
+    void download(double* corrected, int32_t* batch, int32_t* merge_left, int32_t* merge_right, double* batch_size,
+                  int32_t* skipped, double* lost_var);
+    void pairs(int merge, int32_t** left, int32_t** right, int64_t* npairs);
+    void merge_stats(int merge, int64_t* out6) const;
+    void set_profiling(bool on) { profiling_ = on; }
+    void profile(double* topk_ms, int64_t* launches, int64_t* fallbacks);
+    int nbatches() const { return B_; }
+    int64_t total_cells() const { return N_; }
+    hipStream_t stream() const { return stream_; }
+
+    // single primitives (also used by the host-pointer parity entry points)
+    void knn(const double* X, const int32_t* ref_rows, int nr, const double* Q, const int32_t* q_rows, int nq, int k,
+             int32_t* idx, double* dist);
+    struct MnnOut {
+        int64_t P = 0;
+        int U = 0;
+        int k1 = 0, k2 = 0;
+    };
+    // findMutualNN on (restricted) left / right rows; leaves idxLR_, idxRL_, cntL_, offL_, partR_, cntR_, second_u_
+    MnnOut find_mnn(const Node& left, const Node& right, int k, double prop_k);
+
+    int d_ = 0;
+    KnnWorkspace knn_ws_;
+    ScanWorkspace scan_ws_;
+    ReduceWorkspace red_ws_;
+    DevBuf<int32_t> idxLR_, idxRL_, cntL_, offL_, partR_, cntR_, flagR_, offR_, second_u_, second_rows_, idxT_;
+    DevBuf<double> distT_, averaged_, loc_, vecs_, scal_;
+
+  private:
+    void merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p, std::unique_ptr<Node>& merged);
+    void perbatch_var(const Node& node, int scal_off);
+    void orthogonalize(Node& node, const std::vector<int>& extras);
+    int count_mnn_pairs(const Node& left, const Node& right, const bmx_params_t& p);
+    std::unique_ptr<Node> clone_node(const Node& src);
+    void exchange(void* buf, int64_t bytes_per_rank);
+
+    int device_ = 0;
+    hipStream_t stream_ = nullptr;
+    int rank_ = 0, world_ = 1;
+    bmx_allgather_fn gather_fn_ = nullptr;
+    void* gather_ctx_ = nullptr;
+    bool profiling_ = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events_;
+    size_t events_used_ = 0;
+    int64_t fallbacks_ = 0;
+
+    int B_ = 0;
+    int64_t N_ = 0;
+    std::vector<int> nrows_;
+    std::vector<DevBuf<double>> inputs_cm_;        // resident inputs, column-major as uploaded
+    std::vector<DevBuf<int32_t>> inputs_restrict_; // 0-based
+    std::vector<int> n_restrict_;                  // -1 = NULL
+
+    // results of the last run
+    std::unique_ptr<Node> root_;
+    std::vector<MergeRecord> merges_;
+    int n_extras_ = 0;
+    std::vector<double> scal_host_;
+    friend struct EngineAccess;
+};
+
+}  // namespace bmx

@@ -415,6 +415,10 @@ __global__ __launch_bounds__(256) void knn_exact(const double* __restrict__ X, c
     }
 }
 
+__global__ void accumulate_flagged(const int32_t* __restrict__ flagged, unsigned long long* __restrict__ total) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *total += (unsigned long long)flagged[0];
+}
+
 template <int KP, int KS>
 void launch_topk(hipStream_t stream, const float* pq, const float* pr, int nq_pad, int nr_pad, int chunk_len,
                  int nchunks, int32_t* cand, float* tau) {
@@ -486,6 +490,7 @@ void knn_device(hipStream_t stream, KnnWorkspace& ws, const double* X, const int
     const int KS = k <= 20 ? 24 : (k <= 36 ? 40 : 0);
     const bool use_mfma = !ws.force_exact && KP != 0 && KS != 0 && nr > 2 * KS;
 
+    ws.topk_launched = false;
     int32_t* flagged = ws.flagged.reserve((size_t)nq + 1);
     BMX_HIP(hipMemsetAsync(flagged, 0, sizeof(int32_t), stream));
 
@@ -525,9 +530,12 @@ void knn_device(hipStream_t stream, KnnWorkspace& ws, const double* X, const int
                            pq, qn2, maxbits);
         BMX_LAUNCH_CHECK();
 
+        if (ws.ev_begin) BMX_HIP(hipEventRecord(ws.ev_begin, stream));
         bool ok = KS == 24 ? dispatch_kp<24>(KP, stream, pq, pr, nq_pad, nr_pad, chunk_len, nchunks, cand, tau)
                            : dispatch_kp<40>(KP, stream, pq, pr, nq_pad, nr_pad, chunk_len, nchunks, cand, tau);
         if (!ok) throw Error(BMX_ERR_ARG, "kNN: unsupported padded dimension");
+        if (ws.ev_end) BMX_HIP(hipEventRecord(ws.ev_end, stream));
+        ws.topk_launched = true;
 
         hipLaunchKernelGGL(knn_refine, dim3(cdiv(nq, 4)), dim3(256), 0, stream, X, ref_rows, Qs, qrs, nq, d, k, KS,
                            nchunks, KP, cand, tau, qn2, maxbits, io, dout, flagged);
@@ -544,8 +552,10 @@ void knn_device(hipStream_t stream, KnnWorkspace& ws, const double* X, const int
                            use_mfma ? 0 : 1, drow, io, dout);
         BMX_LAUNCH_CHECK();
     }
-    // diagnostics only (host sync is outside any timed steady-state path: callers may skip it)
-    ws.last_flagged = -1;
+    if (ws.flag_total && use_mfma) {
+        hipLaunchKernelGGL(accumulate_flagged, dim3(1), dim3(64), 0, stream, flagged, ws.flag_total);
+        BMX_LAUNCH_CHECK();
+    }
 }
 
 }  // namespace bmx

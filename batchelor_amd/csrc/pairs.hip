@@ -1,0 +1,178 @@
+// Mutual-nearest-neighbour intersection on the device: the arithmetic of src/find_mutual_nns.cpp:8-41 without its
+// per-row sort + binary search (rows are <= a few dozen ids, a linear probe of the partner's row is cheaper), plus
+// the ordered stream compaction that reproduces the reference's pair order (left ascending, then neighbour rank).
+#include "bmx_ops.hpp"
+
+namespace bmx {
+namespace {
+
+constexpr int SCAN_ITEMS = 8;                     // per thread
+constexpr int SCAN_BLOCK = 256 * SCAN_ITEMS;      // per block
+
+__global__ __launch_bounds__(256) void scan_blocks(const int32_t* __restrict__ in, int32_t* __restrict__ out, int n,
+                                                   int32_t* __restrict__ block_sums) {
+    __shared__ int32_t wave_tot[4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int base = blockIdx.x * SCAN_BLOCK + tid * SCAN_ITEMS;
+    int32_t v[SCAN_ITEMS];
+    int32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        v[i] = base + i < n ? in[base + i] : 0;
+        s += v[i];
+    }
+    int32_t inc = s;  // inclusive scan of per-thread sums across the wave
+    for (int o = 1; o < 64; o <<= 1) {
+        const int32_t t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) wave_tot[w] = inc;
+    __syncthreads();
+    int32_t woff = 0;
+    for (int i = 0; i < w; ++i) woff += wave_tot[i];
+    int32_t run = woff + inc - s;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        if (base + i < n) out[base + i] = run;
+        run += v[i];
+    }
+    if (tid == 255) block_sums[blockIdx.x] = woff + inc;
+}
+
+__global__ void scan_block_sums(const int32_t* __restrict__ sums, int32_t* __restrict__ offs, int nblocks,
+                                int32_t* __restrict__ total_slot) {
+    // one thread: nblocks is n / 2048 (a few thousand at most)
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int32_t run = 0;
+    for (int b = 0; b < nblocks; ++b) {
+        offs[b] = run;
+        run += sums[b];
+    }
+    *total_slot = run;
+}
+
+__global__ __launch_bounds__(256) void scan_add_offsets(int32_t* __restrict__ out, int n,
+                                                        const int32_t* __restrict__ offs) {
+    const int i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+    const int32_t o = offs[blockIdx.x];
+#pragma unroll
+    for (int t = 0; t < SCAN_ITEMS; ++t) {
+        const int idx = i + t * 256;
+        if (idx < n) out[idx] += o;
+    }
+}
+
+__device__ __forceinline__ bool row_contains(const int32_t* __restrict__ row, int k, int32_t want) {
+    bool f = false;
+    for (int t = 0; t < k; ++t) f |= row[t] == want;
+    return f;
+}
+
+__global__ void mutual_left(const int32_t* __restrict__ idxLR, int nL, int k2, const int32_t* __restrict__ idxRL, int k1,
+                            int32_t* __restrict__ cntL) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= nL) return;
+    int c = 0;
+    for (int j = 0; j < k2; ++j) {
+        const int32_t r = idxLR[(int64_t)l * k2 + j];
+        c += row_contains(idxRL + (int64_t)r * k1, k1, l) ? 1 : 0;
+    }
+    cntL[l] = c;
+}
+
+__global__ void mutual_right(const int32_t* __restrict__ idxLR, int k2, const int32_t* __restrict__ idxRL, int nR,
+                             int k1, int32_t* __restrict__ partR, int32_t* __restrict__ cntR) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nR) return;
+    int32_t* row = partR + (int64_t)r * k1;
+    int m = 0;
+    for (int j = 0; j < k1; ++j) {
+        const int32_t l = idxRL[(int64_t)r * k1 + j];
+        if (!row_contains(idxLR + (int64_t)l * k2, k2, r)) continue;
+        int p = m++;  // insertion keeps the partners ascending = the order `rowsum` adds them in
+        while (p > 0 && row[p - 1] > l) {
+            row[p] = row[p - 1];
+            --p;
+        }
+        row[p] = l;
+    }
+    cntR[r] = m;
+}
+
+__global__ void emit_pairs_kernel(const int32_t* __restrict__ idxLR, int nL, int k2, const int32_t* __restrict__ idxRL,
+                                  int k1, const int32_t* __restrict__ offL, const int32_t* __restrict__ lrows,
+                                  const int32_t* __restrict__ rrows, int32_t* __restrict__ first,
+                                  int32_t* __restrict__ second) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= nL) return;
+    int o = offL[l];
+    const int32_t lid = (lrows ? lrows[l] : l) + 1;
+    for (int j = 0; j < k2; ++j) {
+        const int32_t r = idxLR[(int64_t)l * k2 + j];
+        if (row_contains(idxRL + (int64_t)r * k1, k1, l)) {
+            first[o] = lid;
+            second[o] = (rrows ? rrows[r] : r) + 1;
+            ++o;
+        }
+    }
+}
+
+__global__ void flag_positive(const int32_t* __restrict__ cnt, int n, int32_t* __restrict__ flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = cnt[i] > 0 ? 1 : 0;
+}
+
+__global__ void scatter_positions(const int32_t* __restrict__ flag, const int32_t* __restrict__ off, int n,
+                                  int32_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && flag[i]) out[off[i]] = i;
+}
+
+}  // namespace
+
+void exclusive_scan_i32(hipStream_t stream, ScanWorkspace& ws, const int32_t* in, int32_t* out, int n) {
+    const int nb = std::max(1, cdiv(n, SCAN_BLOCK));
+    int32_t* sums = ws.block_sums.reserve(nb);
+    int32_t* offs = ws.block_offs.reserve(nb);
+    hipLaunchKernelGGL(scan_blocks, dim3(nb), dim3(256), 0, stream, in, out, n, sums);
+    BMX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scan_block_sums, dim3(1), dim3(64), 0, stream, sums, offs, nb, out + n);
+    BMX_LAUNCH_CHECK();
+    if (nb > 1) {
+        hipLaunchKernelGGL(scan_add_offsets, dim3(nb), dim3(256), 0, stream, out, n, offs);
+        BMX_LAUNCH_CHECK();
+    }
+}
+
+void mutual_counts(hipStream_t stream, const int32_t* idxLR, int nL, int k2, const int32_t* idxRL, int nR, int k1,
+                   int32_t* cntL, int32_t* partR, int32_t* cntR) {
+    if (nL > 0) {
+        hipLaunchKernelGGL(mutual_left, dim3(cdiv(nL, 256)), dim3(256), 0, stream, idxLR, nL, k2, idxRL, k1, cntL);
+        BMX_LAUNCH_CHECK();
+    }
+    if (nR > 0) {
+        hipLaunchKernelGGL(mutual_right, dim3(cdiv(nR, 256)), dim3(256), 0, stream, idxLR, k2, idxRL, nR, k1, partR,
+                           cntR);
+        BMX_LAUNCH_CHECK();
+    }
+}
+
+void emit_pairs(hipStream_t stream, const int32_t* idxLR, int nL, int k2, const int32_t* idxRL, int k1,
+                const int32_t* offL, const int32_t* lrows, const int32_t* rrows, int32_t* first, int32_t* second) {
+    if (nL <= 0) return;
+    hipLaunchKernelGGL(emit_pairs_kernel, dim3(cdiv(nL, 256)), dim3(256), 0, stream, idxLR, nL, k2, idxRL, k1, offL,
+                       lrows, rrows, first, second);
+    BMX_LAUNCH_CHECK();
+}
+
+void compact_mnn_cells(hipStream_t stream, ScanWorkspace& ws, const int32_t* cntR, int nR, int32_t* flagR,
+                       int32_t* offR, int32_t* second_u) {
+    if (nR <= 0) return;
+    hipLaunchKernelGGL(flag_positive, dim3(cdiv(nR, 256)), dim3(256), 0, stream, cntR, nR, flagR);
+    BMX_LAUNCH_CHECK();
+    exclusive_scan_i32(stream, ws, flagR, offR, nR);
+    hipLaunchKernelGGL(scatter_positions, dim3(cdiv(nR, 256)), dim3(256), 0, stream, flagR, offR, nR, second_u);
+    BMX_LAUNCH_CHECK();
+}
+
+}  // namespace bmx

@@ -1,0 +1,256 @@
+"""reducedMNN() / the `.fast_mnn` cut, served by the MI355X engine.
+
+Mirrors R/reducedMNN.R:61-95 and the argument handling of R/fastMNN.R:398-429 (names, merge.order, restrict), the
+batch splitting of R/divideIntoBatches.R:36-84 and the re-ordering of R/utils_reorder.R.  Conventions follow R:
+cells x dims matrices, 1-based batch ids / cell indices in the result, `None` for NULL / NA.
+
+All arithmetic happens in HIP kernels behind include/batchelor_mi355x.h; there is no CPU path here.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Any, List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .merge_tree import encode_postorder, resolve_merge_order
+
+
+class BmxParams(ctypes.Structure):
+    _fields_ = [("k", ctypes.c_int32), ("prop_k", ctypes.c_double), ("ndist", ctypes.c_double),
+                ("min_batch_skip", ctypes.c_double), ("auto_merge", ctypes.c_int32)]
+
+
+ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64)
+
+
+@dataclass
+class MergeInfo:
+    """metadata(output)$merge.info (R/fastMNN.R:551-560)."""
+    left: List[List[Any]]
+    right: List[List[Any]]
+    pairs: List[Any]          # per merge: (left, right) 1-based output-row indices
+    batch_size: np.ndarray
+    skipped: np.ndarray
+    lost_var: np.ndarray      # (B-1) x B, columns in input batch order
+
+
+@dataclass
+class MnnResult:
+    corrected: np.ndarray     # N x d, rows in input order
+    batch: np.ndarray         # batch id (1-based) or name per row
+    merge_info: MergeInfo
+    stats: Optional[list] = None   # per merge {nL, nR, U, P, nL_all, nR_all}: sizes behind the flop / byte counts
+
+
+class MnnEngine:
+    """A device-resident engine (bmx_engine_t): upload once, run many times, download when needed."""
+
+    def __init__(self, device: int = 0):
+        _lib.require_gpu()
+        self._h = ctypes.c_void_p()
+        _lib.check(_lib.lib().bmx_engine_create(int(device), ctypes.byref(self._h)))
+        self._keep = None
+        self._cb = None
+        self.nbatches = 0
+        self.nrows: List[int] = []
+        self.d = 0
+
+    def close(self):
+        if self._h:
+            _lib.lib().bmx_engine_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_shard(self, rank, world, allgather):
+        """allgather(buf_ptr: int, bytes_per_rank: int) -> None; in-place all-gather of a device buffer."""
+        def _tramp(_ctx, buf, nbytes):
+            try:
+                allgather(int(buf), int(nbytes))
+                return 0
+            except Exception as exc:  # never unwind into C
+                self._cb_error = exc
+                return 1
+        self._cb_error = None
+        self._cb = ALLGATHER_FN(_tramp) if world > 1 else ctypes.cast(None, ALLGATHER_FN)
+        _lib.check(_lib.lib().bmx_engine_set_shard(self._h, int(rank), int(world), self._cb, None))
+
+    def upload(self, batches: Sequence[np.ndarray], restrict=None):
+        mats = [_lib.as_f(b) for b in batches]
+        if len(mats) < 2:
+            raise ValueError("at least two batches must be specified")  # R/fastMNN.R:345
+        d = mats[0].shape[1]
+        for m in mats:
+            if m.ndim != 2 or m.shape[1] != d:
+                raise ValueError("number of columns is not the same across batches")  # R/checkInputs.R:64-71
+        B = len(mats)
+        data = (ctypes.c_void_p * B)(*[m.ctypes.data for m in mats])
+        nrows = np.asarray([m.shape[0] for m in mats], dtype=np.int32)
+        rlist, rptr, rn = [], (ctypes.c_void_p * B)(), np.full(B, -1, dtype=np.int32)
+        if restrict is not None:
+            if len(restrict) != B:
+                raise ValueError("'restrictions' must of length equal to the number of batches")
+            for b, r in enumerate(restrict):
+                if r is None:
+                    rlist.append(None)
+                    continue
+                r = np.asarray(r)
+                r = (np.flatnonzero(r) + 1) if r.dtype == bool else r
+                r = np.ascontiguousarray(r, dtype=np.int32)
+                if r.size == 0:
+                    raise ValueError("no cells remaining in a batch after restriction")
+                rlist.append(r)
+                rptr[b] = r.ctypes.data
+                rn[b] = r.size
+        _lib.check(_lib.lib().bmx_engine_upload(self._h, B, d, data, _lib.i32p(nrows),
+                                                rptr if restrict is not None else None, _lib.i32p(rn)))
+        self._keep = (mats, rlist)
+        self.nbatches, self.nrows, self.d = B, nrows.tolist(), d
+
+    def run(self, k=20, prop_k=None, ndist=3.0, min_batch_skip=0.0, merge_tree=None, auto_merge=False):
+        p = BmxParams(int(k), float("nan") if prop_k is None else float(prop_k), float(ndist),
+                      float("nan") if min_batch_skip is None else float(min_batch_skip), 1 if auto_merge else 0)
+        code = encode_postorder(merge_tree if merge_tree is not None
+                                else resolve_merge_order(self.nbatches))
+        rc = _lib.lib().bmx_engine_run(self._h, ctypes.byref(p), _lib.i32p(code), int(code.size))
+        if rc != 0 and getattr(self, "_cb_error", None) is not None:
+            err, self._cb_error = self._cb_error, None
+            raise err
+        _lib.check(rc)
+
+    def set_profiling(self, on=True):
+        _lib.check(_lib.lib().bmx_engine_set_profiling(self._h, 1 if on else 0))
+
+    def profile(self):
+        ms, n, fb = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_int64(0)
+        _lib.check(_lib.lib().bmx_engine_profile(self._h, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fb)))
+        return {"topk_ms": ms.value, "topk_launches": n.value, "exact_fallbacks": fb.value}
+
+    def merge_stats(self):
+        out = []
+        for m in range(self.nbatches - 1):
+            a = np.zeros(6, dtype=np.int64)
+            _lib.check(_lib.lib().bmx_engine_merge_stats(self._h, m, a.ctypes.data_as(_lib.c_i64p)))
+            out.append(dict(zip(("nL", "nR", "U", "P", "nL_all", "nR_all"), a.tolist())))
+        return out
+
+    def download(self, with_pairs=True) -> MnnResult:
+        B, d = self.nbatches, self.d
+        N = int(sum(self.nrows))
+        nm = B - 1
+        corrected = np.zeros((N, d), dtype=np.float64, order="F")
+        batch = np.zeros(N, dtype=np.int32)
+        ml = np.zeros((nm, B), dtype=np.int32)
+        mr = np.zeros((nm, B), dtype=np.int32)
+        bs = np.zeros(nm, dtype=np.float64)
+        sk = np.zeros(nm, dtype=np.int32)
+        lv = np.zeros((nm, B), dtype=np.float64, order="F")
+        _lib.check(_lib.lib().bmx_engine_download(self._h, _lib.f64p(corrected), _lib.i32p(batch), _lib.i32p(ml),
+                                                  _lib.i32p(mr), _lib.f64p(bs), _lib.i32p(sk), _lib.f64p(lv)))
+        pairs = []
+        if with_pairs:
+            for m in range(nm):
+                pl, pr, n = _lib.c_i32p(), _lib.c_i32p(), ctypes.c_int64(0)
+                _lib.check(_lib.lib().bmx_engine_pairs(self._h, m, ctypes.byref(pl), ctypes.byref(pr), ctypes.byref(n)))
+                pairs.append((_lib.take_i32(pl, n.value).astype(np.int64), _lib.take_i32(pr, n.value).astype(np.int64)))
+        info = MergeInfo(left=[[int(x) for x in row if x] for row in ml], right=[[int(x) for x in row if x] for row in mr],
+                         pairs=pairs, batch_size=bs, skipped=sk.astype(bool), lost_var=np.ascontiguousarray(lv))
+        return MnnResult(corrected=np.ascontiguousarray(corrected), batch=batch, merge_info=info,
+                         stats=self.merge_stats())
+
+
+def _fast_mnn(batches, k, prop_k, restrict, ndist, merge_order, auto_merge, min_batch_skip, names, device=0):
+    """.fast_mnn (R/fastMNN.R:398-429)."""
+    if names is not None and len(set(names)) != len(names):
+        raise ValueError("names of batches should be unique")  # R/fastMNN.R:422
+    eng = MnnEngine(device)
+    try:
+        eng.upload(batches, restrict)
+        tree = None if auto_merge else resolve_merge_order(len(batches), merge_order, names)
+        eng.run(k=k, prop_k=prop_k, ndist=ndist, min_batch_skip=min_batch_skip, merge_tree=tree,
+                auto_merge=auto_merge)
+        out = eng.download()
+    finally:
+        eng.close()
+    if names is not None:  # R/fastMNN.R:419-427
+        nm = np.asarray(list(names), dtype=object)
+        out.batch = nm[out.batch - 1]
+        out.merge_info.left = [[names[i - 1] for i in s] for s in out.merge_info.left]
+        out.merge_info.right = [[names[i - 1] for i in s] for s in out.merge_info.right]
+    return out
+
+
+def divideIntoBatches(x, batch, restrict=None):
+    """R/divideIntoBatches.R:36-84 with byrow=TRUE: levels are the sorted unique values of `batch`."""
+    x = np.asarray(x, dtype=np.float64)
+    batch = np.asarray(batch)
+    if batch.shape[0] != x.shape[0]:
+        raise ValueError("'length(batch)' and 'nrow(x)' are not the same")
+    levels = sorted(set(batch.tolist()))
+    mask = None
+    if restrict is not None:
+        r = np.asarray(restrict)
+        mask = np.zeros(x.shape[0], dtype=bool)
+        if r.dtype == bool:
+            mask[:] = r
+        else:
+            mask[r.astype(np.int64) - 1] = True
+    out, restricted = [], ([] if mask is not None else None)
+    reorder = np.zeros(x.shape[0], dtype=np.int64)
+    last = 0
+    for lev in levels:
+        keep = batch == lev
+        cur = x[keep]
+        if mask is not None:
+            cr = np.flatnonzero(mask[keep]) + 1
+            if cr.size == 0:
+                raise ValueError("no cells remaining in a batch after restriction")
+            restricted.append(cr.astype(np.int32))
+        out.append(cur)
+        reorder[keep] = last + np.arange(1, cur.shape[0] + 1)
+        last += cur.shape[0]
+    return {"batches": out, "levels": levels, "reorder": reorder, "restricted": restricted}
+
+
+def _reindex_pairings(pairings, new_order):
+    """R/utils_reorder.R:23-36."""
+    new_order = np.asarray(new_order, dtype=np.int64)
+    rev = np.zeros(new_order.size + 1, dtype=np.int64)
+    rev[new_order] = np.arange(1, new_order.size + 1)
+    return [(rev[l], rev[r]) for l, r in pairings]
+
+
+def reducedMNN(*batches, batch=None, k=20, prop_k=None, restrict=None, ndist=3, merge_order=None, auto_merge=False,
+               min_batch_skip=0.0, names=None, device=0) -> MnnResult:
+    """reducedMNN(..., batch=, k=, prop.k=, restrict=, ndist=, merge.order=, auto.merge=, min.batch.skip=)
+    (R/reducedMNN.R:61-95).  `names` plays the role of the argument names of `...`."""
+    if len(batches) == 1 and isinstance(batches[0], (list, tuple)):
+        batches = tuple(batches[0])
+    if len(batches) == 0:
+        raise ValueError("at least two batches must be specified")
+    d = np.asarray(batches[0]).shape[1]
+    for b in batches:
+        if np.asarray(b).ndim != 2 or np.asarray(b).shape[1] != d:
+            raise ValueError("number of columns is not the same across batches")
+    if restrict is not None and len(restrict) != len(batches):
+        raise ValueError("'restrictions' must of length equal to the number of batches")
+    if len(batches) == 1:
+        if batch is None:
+            raise ValueError("'batch' must be specified if '...' has only one object")  # R/checkInputs.R:128
+        div = divideIntoBatches(batches[0], batch, None if restrict is None else restrict[0])
+        out = _fast_mnn(div["batches"], k, prop_k, div["restricted"], ndist, merge_order, auto_merge, min_batch_skip,
+                        [str(l) for l in div["levels"]], device)
+        reo = div["reorder"]
+        out.corrected = out.corrected[reo - 1]
+        out.batch = out.batch[reo - 1]
+        out.merge_info.pairs = _reindex_pairings(out.merge_info.pairs, reo)
+        return out
+    return _fast_mnn([np.asarray(b, dtype=np.float64) for b in batches], k, prop_k, restrict, ndist, merge_order,
+                     auto_merge, min_batch_skip, names, device)

@@ -77,6 +77,84 @@ int64_t bmx_last_knn_exact_fallbacks(void);
 /* Testing hook: non-zero routes every kNN query through the exact FP64 re-scan. */
 void bmx_set_force_exact_knn(int32_t on);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * The merge engine: replaces .fast_mnn / .fast_mnn_core (R/fastMNN.R:398-562) and everything they call
+ * (R/MNN_tree.R, R/utils_tricube.R, R/utils_reorder.R) with one device-resident run.  The natural cut is the call
+ * `.fast_mnn(batches, k, prop.k, restrict, ndist, merge.order, auto.merge, min.batch.skip)` made from
+ * R/fastMNN.R:356,380 and R/reducedMNN.R:83,89.
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct bmx_engine bmx_engine_t;
+
+typedef struct {
+    int32_t k;             /* k = 20 */
+    double prop_k;         /* NaN = NULL (R/MNN_tree.R:140-146) */
+    double ndist;          /* ndist = 3 */
+    double min_batch_skip; /* NaN = NA_real_: batch.size not computed, nothing skipped (R/fastMNN.R:484) */
+    int32_t auto_merge;    /* non-zero: R/MNN_tree.R:154-226 instead of the predefined tree */
+} bmx_params_t;
+
+/* Multi-GPU exchange: called by the engine when `buf` (a DEVICE buffer of world * bytes_per_rank bytes whose slice
+ * [rank * bytes_per_rank, +bytes_per_rank) this rank has filled) must become identical on all ranks (an in-place
+ * all-gather; RCCL over xGMI in production).  The engine's stream is idle when it is called.  Return 0 on success. */
+typedef int32_t (*bmx_allgather_fn)(void* ctx, void* buf, int64_t bytes_per_rank);
+
+/* Creates an engine on HIP device `device` (its workspaces persist across runs). */
+int32_t bmx_engine_create(int32_t device, bmx_engine_t** out);
+void bmx_engine_destroy(bmx_engine_t* e);
+/* Every kNN search is split by query rows over `world` ranks and completed with `fn`; all ranks hold all batches. */
+int32_t bmx_engine_set_shard(bmx_engine_t* e, int32_t rank, int32_t world, bmx_allgather_fn fn, void* ctx);
+/* Copies the batches to HBM.  data[b]: nrows[b] x d column-major; restrict_idx[b]: 1-based, strictly increasing,
+ * n_restrict[b] entries, or NULL / n_restrict[b] < 0 for "all cells" (R/checkInputs.R:96-120 normalises them). */
+int32_t bmx_engine_upload(bmx_engine_t* e, int32_t nbatches, int32_t d, const double* const* data,
+                          const int32_t* nrows, const int32_t* const* restrict_idx, const int32_t* n_restrict);
+/* Runs all merges on the resident inputs (asynchronous launches; returns after the final stream synchronisation).
+ * tree: the binary merge tree in post-order, leaf = 1-based batch id, 0 = "merge the two nodes on top of the stack,
+ * deeper one is the left/reference child" -- e.g. list(list(1,2),3) is {1,2,0,3,0}.  Ignored when auto_merge. */
+int32_t bmx_engine_run(bmx_engine_t* e, const bmx_params_t* params, const int32_t* tree, int32_t tree_len);
+/* Results of the last run.  corrected: N x d column-major, rows in input batch order (R/fastMNN.R:541-547);
+ * batch: N batch ids (1-based); merge_left / merge_right: (B-1) x B row-major, batch ids of each merge's left and
+ * right sets padded with 0; batch_size, skipped: B-1; lost_var: (B-1) x B column-major.  Any pointer may be NULL. */
+int32_t bmx_engine_download(bmx_engine_t* e, double* corrected, int32_t* batch, int32_t* merge_left,
+                            int32_t* merge_right, double* batch_size, int32_t* skipped, double* lost_var);
+/* MNN pairs of merge `merge` (0-based), 1-based OUTPUT-row indices (R/fastMNN.R:533-547); malloc'ed (bmx_free). */
+int32_t bmx_engine_pairs(bmx_engine_t* e, int32_t merge, int32_t** left, int32_t** right, int64_t* npairs);
+/* Sizes of merge `merge`: out[0..5] = {cells searched on the left, on the right, MNN-involved right cells U,
+ * pairs P, all left cells, all right cells} -- the inputs of the algorithmic flop / byte counts. */
+int32_t bmx_engine_merge_stats(bmx_engine_t* e, int32_t merge, int64_t* out6);
+/* With profiling on, every launch of the dominant kernel (knn_topk_mfma) is bracketed by HIP events on the engine's
+ * stream; after a run: total milliseconds, number of launches, and queries that needed the exact re-scan. */
+int32_t bmx_engine_set_profiling(bmx_engine_t* e, int32_t on);
+int32_t bmx_engine_profile(bmx_engine_t* e, double* topk_ms, int64_t* topk_launches, int64_t* exact_fallbacks);
+
+/* One-shot convenience (what the R shim calls): create + upload + run + download + pairs stay queryable on *out_engine
+ * until bmx_engine_destroy. */
+int32_t bmx_fast_mnn(int32_t nbatches, int32_t d, const double* const* data, const int32_t* nrows,
+                     const int32_t* const* restrict_idx, const int32_t* n_restrict, const bmx_params_t* params,
+                     const int32_t* tree, int32_t tree_len, double* corrected, int32_t* batch, int32_t* merge_left,
+                     int32_t* merge_right, double* batch_size, int32_t* skipped, double* lost_var,
+                     bmx_engine_t** out_engine);
+
+/* Row range [begin, end) of `n` query rows owned by `rank` of `world` (pure host arithmetic, no GPU). */
+void bmx_shard_range(int64_t n, int32_t rank, int32_t world, int64_t* begin, int64_t* end);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Single primitives of the merge step, host in / host out, for parity tests that read like the reference's own
+ * (tests/testthat/test-fast-mnn.R:7-92).  Same kernels as the engine.
+ * ---------------------------------------------------------------------------------------------------------------- */
+/* .center_along_batch_vector (R/fastMNN.R:626-640): mat [n x d] column-major in/out; restrict 1-based or NULL. */
+int32_t bmx_center_along_batch_vector(double* mat, int32_t n, int32_t d, const double* batch_vec,
+                                      const int32_t* restrict_idx, int32_t n_restrict);
+/* .tricube_weighted_correction (R/fastMNN.R:599-608): curdata [n x d] in/out, correction [U x d], in_mnn [U] 1-based. */
+int32_t bmx_tricube_weighted_correction(double* curdata, int32_t n, int32_t d, const double* correction,
+                                        const int32_t* in_mnn, int32_t U, int32_t k, double ndist);
+/* .average_correction (R/fastMNN.R:567-580) fed by findMutualNN on the same data: averaged [U x d] and second [U]
+ * are malloc'ed; also returns the pairs. */
+int32_t bmx_mnn_average_correction(const double* refdata, int32_t n1, const double* curdata, int32_t n2, int32_t d,
+                                   int32_t k1, int32_t k2, int32_t** first, int32_t** second, int64_t* npairs,
+                                   double** averaged, int32_t** second_u, int32_t* U);
+/* .compute_perbatch_var (R/fastMNN.R:651-658) for one batch: sum over dims of the sample variance of data [n x d]. */
+int32_t bmx_total_variance(const double* data, int32_t n, int32_t d, double* out);
+
 #ifdef __cplusplus
 }
 #endif
