@@ -1,0 +1,87 @@
+"""Multi-GPU plumbing: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI) for the single
+exchange step of the path -- the all-gather of per-rank kNN candidate lists before the mutual-pair intersection.
+
+Every rank holds all batches (8 x 100k x 50 doubles = 320 MB, nothing next to 288 GB of HBM); each kNN search is
+split by query rows (bmx_shard_range), so the per-merge distance block is spread evenly over all ranks whatever the
+merge tree looks like, and the only traffic is the gathered index / distance lists.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+def shard_range(n, rank, world):
+    """Row range [begin, end) of `n` query rows owned by `rank` (same arithmetic the engine uses)."""
+    b, e = ctypes.c_int64(0), ctypes.c_int64(0)
+    _lib.lib().bmx_shard_range(ctypes.c_int64(int(n)), int(rank), int(world), ctypes.byref(b), ctypes.byref(e))
+    return b.value, e.value
+
+
+class _RawDeviceBuffer:
+    """Exposes a raw device pointer to torch through the CUDA array interface (no copy)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False),
+                                         "version": 2}
+
+
+class TorchExchange:
+    """In-place all-gather of a device buffer over an initialised torch.distributed process group.
+
+    nccl (RCCL): the buffer is aliased as a torch tensor and gathered in place on the GPU.
+    gloo: staged through host memory (used for tests on boxes without several GPUs).
+    """
+
+    def __init__(self, device_index=0, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
+        self.device = torch.device("cuda", device_index)
+        self.calls = 0
+        self.bytes = 0
+
+    def allgather_tensor_(self, full, per):
+        """full: 1-D uint8 tensor of world * per bytes whose slice `rank` is valid; gathers in place."""
+        mine = full[self.rank * per:(self.rank + 1) * per]
+        if self.backend == "nccl":
+            self.dist.all_gather_into_tensor(full, mine, group=self.group)
+        else:
+            host = mine.cpu() if full.is_cuda else mine.clone()
+            parts = [self.torch.empty_like(host) for _ in range(self.world)]
+            self.dist.all_gather(parts, host, group=self.group)
+            full.copy_(self.torch.cat(parts).to(full.device))
+        self.calls += 1
+        self.bytes += per * self.world
+
+    def __call__(self, ptr, bytes_per_rank):
+        torch = self.torch
+        per = int(bytes_per_rank)
+        full = torch.as_tensor(_RawDeviceBuffer(ptr, per * self.world), device=self.device)
+        self.allgather_tensor_(full, per)
+        torch.cuda.synchronize(self.device)
+
+
+def sharded_knn_reference(knn_fn, X, Q, k, exchange_tensor_fn, rank, world):
+    """Host-side statement of the sharded search: rank-local kNN on its query slice, then the in-place all-gather of
+    the padded per-rank slices.  `knn_fn(X, Qslice, k) -> (idx, dist)`.  Used by the CPU (gloo) tests."""
+    import torch
+    nq = Q.shape[0]
+    per = (nq + world - 1) // world
+    b, e = shard_range(nq, rank, world)
+    idx = np.zeros((per * world, k), dtype=np.int32)
+    dist = np.zeros((per * world, k), dtype=np.float64)
+    if e > b:
+        i, dd = knn_fn(X, Q[b:e], k)
+        idx[b:e], dist[b:e] = i, dd
+    for arr in (idx, dist):
+        t = torch.from_numpy(arr.reshape(-1).view(np.uint8))
+        exchange_tensor_fn(t, per * k * arr.itemsize)
+    return idx[:nq], dist[:nq]
