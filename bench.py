@@ -60,20 +60,26 @@ def cpu_baseline(batches, stats, d, k):
     on this box) on a bounded sample: the three exact searches of the merge with 2048 sampled query rows each
     against the FULL reference sets, all host cores; extrapolated by pair evaluations to the whole job."""
     from oracle import fastmnn_oracle as orc
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     L, R = batches[0], batches[1]
-    ns = 2048
     rng = np.random.default_rng(0)
-    ql = L[rng.choice(L.shape[0], min(ns, L.shape[0]), replace=False)]
-    qr = R[rng.choice(R.shape[0], min(ns, R.shape[0]), replace=False)]
     U = max(k, int(stats[0]["U"]))
     sub = R[rng.choice(R.shape[0], min(U, R.shape[0]), replace=False)]
-    t0 = time.perf_counter()
-    orc.query_knn(R, ql, k, nthreads=cores)
-    orc.query_knn(L, qr, k, nthreads=cores)
-    orc.query_knn(sub, qr, k, nthreads=cores)
-    dt = time.perf_counter() - t0
-    sampled = ql.shape[0] * R.shape[0] + qr.shape[0] * L.shape[0] + qr.shape[0] * sub.shape[0]
+
+    def timed(ns):
+        ql = L[rng.choice(L.shape[0], min(ns, L.shape[0]), replace=False)]
+        qr = R[rng.choice(R.shape[0], min(ns, R.shape[0]), replace=False)]
+        t0 = time.perf_counter()
+        orc.query_knn(R, ql, k, nthreads=cores)
+        orc.query_knn(L, qr, k, nthreads=cores)
+        orc.query_knn(sub, qr, k, nthreads=cores)
+        dt = time.perf_counter() - t0
+        return ql, qr, dt, ql.shape[0] * R.shape[0] + qr.shape[0] * L.shape[0] + qr.shape[0] * sub.shape[0]
+
+    # calibrate with a small sample, then size the timed sample for ~15 s of CPU work (bounded by the full job)
+    _, _, dt0, ev0 = timed(max(1024, 8 * cores))
+    ns = int(min(L.shape[0], max(2048, 8 * cores) * max(1.0, 15.0 / max(dt0, 1e-3))))
+    ql, qr, dt, sampled = timed(ns)
     rate = sampled / dt
     total = sum(2.0 * m["nL"] * m["nR"] + m["nR_all"] * m["U"] for m in stats)  # two searches per block on the CPU
     n_cells = sum(b.shape[0] for b in batches)
