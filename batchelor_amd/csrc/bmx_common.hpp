@@ -67,14 +67,32 @@ struct KnnWorkspace {
     DevBuf<double> qn2, rn2, mean, red;
     DevBuf<int32_t> cand;          // [nq][C][KS]
     DevBuf<float> tau;             // [nq][C]
+    DevBuf<uint64_t> seed;         // [nq][KS + 1] kept list of the sample range (wave-per-workgroup kernel)
     DevBuf<int32_t> flagged;       // [nq + 1] compact list of queries needing the exact path (+ counter)
     DevBuf<double> drow;           // exact-path distance rows
     DevBuf<int32_t> idx_tmp;
     DevBuf<double> dist_tmp;
     int64_t last_flagged = 0;      // diagnostics: queries that took the exact path in the last call
     int force_exact = 0;           // testing hook: route every query through the exact path
-    hipEvent_t ev_begin = nullptr, ev_end = nullptr;  // profiling: recorded around the MFMA top-k launch when set
-    bool topk_launched = false;
+    // profiling: when on, every launch of the MFMA top-k kernel is bracketed by an event pair from this pool
+    bool profile = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t events_used = 0;
+    std::pair<hipEvent_t, hipEvent_t> next_events() {
+        if (events_used == events.size()) {
+            hipEvent_t a, b;
+            BMX_HIP(hipEventCreate(&a));
+            BMX_HIP(hipEventCreate(&b));
+            events.emplace_back(a, b);
+        }
+        return events[events_used++];
+    }
+    ~KnnWorkspace() {
+        for (auto& e : events) {
+            (void)hipEventDestroy(e.first);
+            (void)hipEventDestroy(e.second);
+        }
+    }
     unsigned long long* flag_total = nullptr;  // device counter accumulating exact-path queries (optional)
 };
 

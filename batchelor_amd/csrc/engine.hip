@@ -51,10 +51,6 @@ Engine::Engine(int device) : device_(device) {
 }
 
 Engine::~Engine() {
-    for (auto& e : events_) {
-        (void)hipEventDestroy(e.first);
-        (void)hipEventDestroy(e.second);
-    }
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -120,20 +116,7 @@ void Engine::knn(const double* X, const int32_t* ref_rows, int nr, const double*
     // query rows are split over ranks; the padded per-rank slices are contiguous, so the all-gather is in place
     int64_t b = 0, e = nq;
     bmx_shard_range_impl(nq, rank_, world_, &b, &e);
-    if (profiling_) {
-        if (events_used_ == events_.size()) {
-            hipEvent_t a, c;
-            BMX_HIP(hipEventCreate(&a));
-            BMX_HIP(hipEventCreate(&c));
-            events_.emplace_back(a, c);
-        }
-        knn_ws_.ev_begin = events_[events_used_].first;
-        knn_ws_.ev_end = events_[events_used_].second;
-    } else {
-        knn_ws_.ev_begin = knn_ws_.ev_end = nullptr;
-    }
     knn_device(stream_, knn_ws_, X, ref_rows, nr, Q, q_rows, nq, d_, k, idx, dist, (int)b, (int)e);
-    if (profiling_ && knn_ws_.topk_launched) ++events_used_;
     if (world_ > 1) {
         const int64_t per = (nq + world_ - 1) / world_;
         exchange(idx, per * k * (int64_t)sizeof(int32_t));
@@ -374,7 +357,7 @@ void Engine::run(const bmx_params_t& p, const int32_t* tree, int tree_len) {
     merges_.clear();
     merges_.resize(nmerges);
     n_extras_ = 0;
-    events_used_ = 0;
+    knn_ws_.events_used = 0;
     vecs_.reserve((size_t)(2 * B_ + 8) * d_);
     // variance scalars: every merge records (old, new) for at most B segments
     {
@@ -619,13 +602,13 @@ void Engine::merge_stats(int merge, int64_t* out6) const {
 
 void Engine::profile(double* topk_ms, int64_t* launches, int64_t* fallbacks) {
     double ms = 0.0;
-    for (size_t i = 0; i < events_used_; ++i) {
+    for (size_t i = 0; i < knn_ws_.events_used; ++i) {
         float t = 0.f;
-        BMX_HIP(hipEventElapsedTime(&t, events_[i].first, events_[i].second));
+        BMX_HIP(hipEventElapsedTime(&t, knn_ws_.events[i].first, knn_ws_.events[i].second));
         ms += t;
     }
     if (topk_ms) *topk_ms = ms;
-    if (launches) *launches = (int64_t)events_used_;
+    if (launches) *launches = (int64_t)knn_ws_.events_used;
     if (fallbacks) *fallbacks = fallbacks_;
 }
 

@@ -56,7 +56,7 @@ class Engine {
                   int32_t* skipped, double* lost_var);
     void pairs(int merge, int32_t** left, int32_t** right, int64_t* npairs);
     void merge_stats(int merge, int64_t* out6) const;
-    void set_profiling(bool on) { profiling_ = on; }
+    void set_profiling(bool on) { knn_ws_.profile = on; }
     void profile(double* topk_ms, int64_t* launches, int64_t* fallbacks);
     int nbatches() const { return B_; }
     int64_t total_cells() const { return N_; }
@@ -93,9 +93,6 @@ class Engine {
     int rank_ = 0, world_ = 1;
     bmx_allgather_fn gather_fn_ = nullptr;
     void* gather_ctx_ = nullptr;
-    bool profiling_ = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> events_;
-    size_t events_used_ = 0;
     int64_t fallbacks_ = 0;
 
     int B_ = 0;

@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace bmx {
 namespace {
@@ -32,7 +33,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int QB = 128;          // queries per workgroup: 4 waves x one 32-query MFMA column tile
 constexpr int RT = 64;           // references per staged LDS tile (two 32-row MFMA tiles)
 constexpr int THREADS = 256;
-constexpr int SLACK = 24;        // candidate-buffer slots beyond KS
 constexpr int MAX_CHUNKS = 8;
 
 __device__ __forceinline__ uint32_t f32_orderable(float v) {
@@ -80,15 +80,23 @@ __global__ void colsum_final(const double* __restrict__ partial, int nblocks, in
 // ---------------------------------------------------------------------------------------------------
 // 1. prep: FP64 rows -> centred f32 rows [n_pad][KP] with the augmented column; exact norm^2 of the rounded row
 // ---------------------------------------------------------------------------------------------------
+// frag != 0 writes the MFMA-fragment-major layout of the wave-per-workgroup kernel: for every 32-row tile and every
+// group m of four K elements, the 64 lanes' 16-byte pieces are contiguous (lane = 32 * K-half + row), so each
+// global_load_dwordx4 of a wave is one fully coalesced 1 KiB read:  P[((tile * KP/8 + m) * 64 + lane) * 4 + x].
 __global__ void knn_prep(const double* __restrict__ X, const int32_t* __restrict__ rows, int n, int n_pad, int d,
-                         int KP, const double* __restrict__ mean, int is_query, float* __restrict__ P,
+                         int KP, const double* __restrict__ mean, int is_query, int frag, float* __restrict__ P,
                          double* __restrict__ n2, unsigned long long* __restrict__ max_n2_bits) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_pad) return;
-    float* out = P + (int64_t)r * KP;
+    const int HK = KP / 2;
+    auto at = [&](int c) -> float& {
+        if (!frag) return P[(int64_t)r * KP + c];
+        const int hh = c / HK, m = (c % HK) >> 2, x = c & 3;
+        return P[(((int64_t)(r >> 5) * (HK >> 2) + m) * 64 + hh * 32 + (r & 31)) * 4 + x];
+    };
     if (r >= n) {
-        for (int c = 0; c < KP; ++c) out[c] = 0.f;
-        if (!is_query) out[d] = __builtin_inff();  // padded references can never pass a threshold
+        for (int c = 0; c < KP; ++c) at(c) = 0.f;
+        if (!is_query) at(d) = __builtin_inff();  // padded references can never pass a threshold
         return;
     }
     const int64_t row = rows ? rows[r] : r;
@@ -97,10 +105,10 @@ __global__ void knn_prep(const double* __restrict__ X, const int32_t* __restrict
     for (int c = 0; c < d; ++c) {
         const float f = (float)(x[c] - mean[c]);
         s += (double)f * (double)f;
-        out[c] = is_query ? -2.f * f : f;
+        at(c) = is_query ? -2.f * f : f;
     }
-    out[d] = is_query ? 1.f : (float)s;
-    for (int c = d + 1; c < KP; ++c) out[c] = 0.f;
+    at(d) = is_query ? 1.f : (float)s;
+    for (int c = d + 1; c < KP; ++c) at(c) = 0.f;
     n2[r] = s;
     if (!is_query) atomicMax(max_n2_bits, (unsigned long long)__double_as_longlong(s));
 }
@@ -108,14 +116,24 @@ __global__ void knn_prep(const double* __restrict__ X, const int32_t* __restrict
 // ---------------------------------------------------------------------------------------------------
 // 2. MFMA distance tiles + per-query threshold / buffer selection
 // ---------------------------------------------------------------------------------------------------
-// One wave compacts the candidate buffer of query slot `qs` (n <= 64 entries, one per lane): rank by counting over
-// the unique 64-bit keys, keep the KS smallest in sorted order, publish the new threshold.
-template <int KS, int CAP>
-__device__ __forceinline__ void compact_slot(unsigned long long* buf, int* cnt, float* tau_s, int qs, int lane) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    const int n = cnt[qs];
-    unsigned long long* b = buf + qs * CAP;
-    const unsigned long long key = lane < n ? b[lane] : ~0ull;
+// Per query slot the LDS holds KS "kept" entries (sorted, shared by the two lanes that own the query's two K-halves)
+// followed by two lane-private pending lists of PL entries each: a lane appends with a plain ds_write (no atomics, no
+// returned value to wait for).  When a pending list fills, one wave merges kept + both pending lists by rank-counting
+// over the unique 64-bit keys (orderable value << 32 | reference index), keeps the KS smallest and tightens tau.
+constexpr int PL = 12;
+
+template <int KS>
+__device__ __forceinline__ void compact_slot(unsigned long long* buf, int* kcnt, float* tau_s, int slot, int jj,
+                                             int lane, int& mycnt) {
+    constexpr int CAP = KS + 2 * PL;
+    const int nk = kcnt[slot];
+    const int n0 = __builtin_amdgcn_readlane(mycnt, jj);
+    const int n1 = __builtin_amdgcn_readlane(mycnt, jj + 32);
+    const int n = nk + n0 + n1;
+    unsigned long long* b = buf + slot * CAP;
+    int src = lane;  // kept entries sit at [0, nk)
+    if (lane >= nk) src = lane < nk + n0 ? KS + (lane - nk) : KS + PL + (lane - nk - n0);
+    const unsigned long long key = lane < n ? b[src] : ~0ull;
     const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
     int rank = 0;
     for (int f = 0; f < n; ++f) {
@@ -124,10 +142,11 @@ __device__ __forceinline__ void compact_slot(unsigned long long* buf, int* cnt, 
         const unsigned long long fk = ((unsigned long long)fhi << 32) | flo;
         rank += fk < key ? 1 : 0;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // every lane holds its key before slots are rewritten
     if (lane < n && rank < KS) b[rank] = key;
-    if (n >= KS && lane < n && rank == KS - 1) tau_s[qs] = orderable_f32(khi);
-    if (lane == 0) cnt[qs] = n < KS ? n : KS;
+    if (n >= KS && lane < n && rank == KS - 1) tau_s[slot] = orderable_f32(khi);
+    if (lane == 0) kcnt[slot] = n < KS ? n : KS;
+    if (lane == jj || lane == jj + 32) mycnt = 0;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
@@ -151,13 +170,16 @@ __device__ __forceinline__ void stage_store(const StageRegs<N>& s, f32x4* dst, i
     if constexpr (N > 1) stage_store<N - 1, TOTAL>(s.rest, dst, e + THREADS);
 }
 
+// grid = (query blocks, reference ranges).  Range c covers prepared reference rows [r_begin[c], r_end[c]) (tile
+// multiples); tau_init (nullable) holds a valid starting threshold per query (from the sample pre-pass).
 template <int KP, int KS>
 __global__ __launch_bounds__(THREADS, 2) void knn_topk_mfma(const float* __restrict__ Pq, const float* __restrict__ Pr,
-                                                            int nq_pad, int nr_pad, int chunk_len, int nchunks,
+                                                            int first_begin, int range_len, int r_limit,
+                                                            int out_chunk0, int out_nchunks,
+                                                            const float* __restrict__ tau_init,
                                                             int32_t* __restrict__ cand, float* __restrict__ tau_out) {
-    constexpr int CAP = KS + SLACK;
-    constexpr int TRIG = CAP - 2;  // at most two lanes (the two K-halves of a query) append per register step
-    constexpr int HK = KP / 2;     // K elements per lane half
+    constexpr int CAP = KS + 2 * PL;
+    constexpr int HK = KP / 2;  // K elements per lane half
     constexpr int TILE_F4 = RT * KP / 4;
     constexpr int NST = (TILE_F4 + THREADS - 1) / THREADS;
     static_assert(CAP <= 64, "one candidate per lane during compaction");
@@ -165,20 +187,21 @@ __global__ __launch_bounds__(THREADS, 2) void knn_topk_mfma(const float* __restr
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* As = reinterpret_cast<float*>(smem);                                               // [2][RT][KP]
     unsigned long long* buf = reinterpret_cast<unsigned long long*>(smem + 2 * RT * KP * 4);  // [QB][CAP]
-    int* cnt = reinterpret_cast<int*>(buf + QB * CAP);                                        // [QB]
-    float* tau_s = reinterpret_cast<float*>(cnt + QB);                                        // [QB]
+    int* kcnt = reinterpret_cast<int*>(buf + QB * CAP);                                       // [QB]
+    float* tau_s = reinterpret_cast<float*>(kcnt + QB);                                       // [QB]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int qs = wave * 32 + j;
     const int q = blockIdx.x * QB + qs;
-    const int chunk = blockIdx.y;
-    const int r_begin = chunk * chunk_len;
-    const int r_end = min(nr_pad, r_begin + chunk_len);
+    const int r_begin = first_begin + blockIdx.y * range_len;
+    const int r_end = min(r_limit, r_begin + range_len);
+    const int out_chunk = out_chunk0 + blockIdx.y;
 
-    if (tid < QB) {
-        cnt[tid] = 0;
-        tau_s[tid] = __builtin_inff();
+    float tau = tau_init ? tau_init[(int64_t)q * out_nchunks] : __builtin_inff();  // column 0 = the sample range
+    if (h == 0) {
+        kcnt[qs] = 0;
+        tau_s[qs] = tau;
     }
 
     // this lane's half of its query row stays in registers for the whole sweep
@@ -203,7 +226,9 @@ __global__ __launch_bounds__(THREADS, 2) void knn_topk_mfma(const float* __restr
     BMX_STAGE_STORE(0)
     __syncthreads();
 
-    float tau = __builtin_inff();
+    // lane-private pending list: slot base + kept region + this lane's half
+    unsigned long long* pend = buf + qs * CAP + KS + h * PL;
+    int mycnt = 0;
     int cur = 0;
     for (int r0 = r_begin; r0 < r_end; r0 += RT) {
         const bool more = r0 + RT < r_end;
@@ -235,6 +260,12 @@ __global__ __launch_bounds__(THREADS, 2) void knn_topk_mfma(const float* __restr
         // staging registers are dead during the selection below
         if (more) BMX_STAGE_STORE(cur ^ 1)
 
+#ifdef BMX_ABLATE_SELECT
+#pragma unroll
+        for (int t = 0; t < RT / 32; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) asm volatile("" ::"v"(acc[t][e]));
+#else
         // lane (j, h) now holds, for ITS query j, the values of references r0 + 32 t + (e&3) + 8 (e>>2) + 4 h
 #pragma unroll
         for (int t = 0; t < RT / 32; ++t) {
@@ -248,45 +279,193 @@ __global__ __launch_bounds__(THREADS, 2) void knn_topk_mfma(const float* __restr
                 const float v = acc[t][e];
                 const bool pass = v < tau;
                 if (__builtin_amdgcn_ballot_w64(pass) == 0) continue;
-                bool flush = false;
                 if (pass) {
                     const int ridx = r0 + t * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    const int pos = atomicAdd(&cnt[qs], 1);
-                    buf[qs * CAP + pos] = ((unsigned long long)f32_orderable(v) << 32) | (uint32_t)ridx;
-                    flush = pos + 1 >= TRIG;
+                    pend[mycnt] = ((unsigned long long)f32_orderable(v) << 32) | (uint32_t)ridx;
+                    ++mycnt;
                 }
-                unsigned long long fm = __builtin_amdgcn_ballot_w64(flush);
+                unsigned long long fm = __builtin_amdgcn_ballot_w64(mycnt >= PL);
                 if (fm) {
                     fm = (fm | (fm >> 32)) & 0xFFFFFFFFull;  // both K-halves of a query share one slot
                     while (fm) {
                         const int jj = __builtin_ctzll(fm);
                         fm &= fm - 1;
-                        compact_slot<KS, CAP>(buf, cnt, tau_s, wave * 32 + jj, lane);
+                        compact_slot<KS>(buf, kcnt, tau_s, wave * 32 + jj, jj, lane, mycnt);
                     }
                     tau = tau_s[qs];
                 }
             }
         }
+#endif
 
         __syncthreads();
         cur ^= 1;
     }
 
     // final compaction of every slot of this wave, then write candidates + threshold
-    for (int jj = 0; jj < 32; ++jj) compact_slot<KS, CAP>(buf, cnt, tau_s, wave * 32 + jj, lane);
+    for (int jj = 0; jj < 32; ++jj) compact_slot<KS>(buf, kcnt, tau_s, wave * 32 + jj, jj, lane, mycnt);
     for (int jj = 0; jj < 32; ++jj) {
         const int s = wave * 32 + jj;
         const int qq = blockIdx.x * QB + s;
-        const int n = cnt[s];
+        const int n = kcnt[s];
         if (lane < KS) {
             const unsigned long long key = buf[s * CAP + lane];
-            cand[((int64_t)qq * nchunks + chunk) * KS + lane] = lane < n ? (int32_t)(uint32_t)key : -1;
+            cand[((int64_t)qq * out_nchunks + out_chunk) * KS + lane] = lane < n ? (int32_t)(uint32_t)key : -1;
         }
-        if (lane == 0) tau_out[(int64_t)qq * nchunks + chunk] = n >= KS ? tau_s[s] : __builtin_inff();
+        // a range that never filled its kept list rejected nothing below its starting threshold
+        if (lane == 0) tau_out[(int64_t)qq * out_nchunks + out_chunk] = tau_s[s];
     }
-    (void)nq_pad;
 #undef BMX_STAGE_LOAD
 #undef BMX_STAGE_STORE
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 2b. wave-per-workgroup variant: no LDS staging, no barriers.  Each wave owns 32 queries and streams the reference
+// tiles straight from L2 into its MFMA A-fragments (fragment-major prepared layout: every load is a coalesced 1 KiB
+// read), double-buffered in registers.  Waves never wait for each other, so a wave that is compacting a candidate
+// buffer does not stall its neighbours, and 3 waves per SIMD overlap selection with the matrix pipe.
+// ---------------------------------------------------------------------------------------------------
+template <int KP, int KS>
+__global__ __launch_bounds__(64, 3) void knn_topk_w1(const float* __restrict__ Pq, const float* __restrict__ PrF,
+                                                     int first_begin, int range_len, int r_limit, int out_chunk0,
+                                                     int out_nchunks,
+                                                     const unsigned long long* __restrict__ seed_in,
+                                                     unsigned long long* __restrict__ seed_out,
+                                                     int32_t* __restrict__ cand, float* __restrict__ tau_out) {
+    // seed_in  (nullable): [nq_pad][KS + 1] keys of the sample range's kept list (+ its length) -- every range starts
+    //                      from it, so its threshold tightens from the first tile on;
+    // seed_out (nullable): this launch IS the sample range: write the kept list there instead of cand / tau_out.
+    constexpr int CAP = KS + 2 * PL;
+    constexpr int HK = KP / 2;
+    constexpr int NM = HK / 4;  // 16-byte pieces per lane per 32-row tile
+    static_assert(CAP <= 64, "one candidate per lane during compaction");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long* buf = reinterpret_cast<unsigned long long*>(smem);  // [32][CAP]
+    int* kcnt = reinterpret_cast<int*>(buf + 32 * CAP);                     // [32]
+    float* tau_s = reinterpret_cast<float*>(kcnt + 32);                     // [32]
+
+    const int lane = threadIdx.x;
+    const int j = lane & 31, h = lane >> 5;
+    const int q = blockIdx.x * 32 + j;
+    const int r_begin = first_begin + blockIdx.y * range_len;
+    const int r_end = min(r_limit, r_begin + range_len);
+    const int out_chunk = out_chunk0 + blockIdx.y;
+
+    float tau = __builtin_inff();
+    if (seed_in) {
+        for (int jj = 0; jj < 32; ++jj) {
+            const unsigned long long* sp = seed_in + ((int64_t)blockIdx.x * 32 + jj) * (KS + 1);
+            const int n = (int)sp[KS];
+            if (lane < KS) buf[jj * CAP + lane] = sp[lane];
+            if (lane == 0) {
+                kcnt[jj] = n;
+                tau_s[jj] = n >= KS ? orderable_f32((uint32_t)(sp[KS - 1] >> 32)) : __builtin_inff();
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        tau = tau_s[j];
+    } else if (h == 0) {
+        kcnt[j] = 0;
+        tau_s[j] = tau;
+    }
+
+    float bq[HK];
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(Pq + (int64_t)q * KP + h * HK);
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const f32x4 v = src[m];
+            bq[4 * m + 0] = v.x;
+            bq[4 * m + 1] = v.y;
+            bq[4 * m + 2] = v.z;
+            bq[4 * m + 3] = v.w;
+        }
+    }
+
+    unsigned long long* pend = buf + j * CAP + KS + h * PL;
+    int mycnt = 0;
+
+    auto tile_ptr = [&](int r0) {
+        return reinterpret_cast<const f32x4*>(PrF) + ((int64_t)(r0 >> 5) * NM) * 64 + lane;
+    };
+    // two register sets: the loads for tile t + 1 are issued before tile t computes (the last prefetch runs into
+    // the tail padding of the prepared references)
+    f32x4 a0[NM], a1[NM];
+#define BMX_LOAD_TILE(A, R0)                                  \
+    {                                                         \
+        const f32x4* p_ = tile_ptr(R0);                       \
+        _Pragma("unroll") for (int m = 0; m < NM; ++m) A[m] = p_[m * 64]; \
+    }
+    BMX_LOAD_TILE(a0, r_begin)
+
+    auto tile = [&](const f32x4 (&a)[NM], int r0) {
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].x, bq[4 * m + 0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].y, bq[4 * m + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].z, bq[4 * m + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].w, bq[4 * m + 3], acc, 0, 0, 0);
+        }
+#ifdef BMX_ABLATE_SELECT
+#pragma unroll
+        for (int e = 0; e < 16; ++e) asm volatile("" ::"v"(acc[e]));
+#else
+        float mn = acc[0];
+#pragma unroll
+        for (int e = 1; e < 16; ++e) mn = fminf(mn, acc[e]);
+        if (__builtin_amdgcn_ballot_w64(mn < tau) == 0) return;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float v = acc[e];
+            const bool pass = v < tau;
+            if (__builtin_amdgcn_ballot_w64(pass) == 0) continue;
+            if (pass) {
+                const int ridx = r0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                pend[mycnt] = ((unsigned long long)f32_orderable(v) << 32) | (uint32_t)ridx;
+                ++mycnt;
+            }
+            unsigned long long fm = __builtin_amdgcn_ballot_w64(mycnt >= PL);
+            if (fm) {
+                fm = (fm | (fm >> 32)) & 0xFFFFFFFFull;
+                while (fm) {
+                    const int jj = __builtin_ctzll(fm);
+                    fm &= fm - 1;
+                    compact_slot<KS>(buf, kcnt, tau_s, jj, jj, lane, mycnt);
+                }
+                tau = tau_s[j];
+            }
+        }
+#endif
+    };
+
+    for (int r0 = r_begin; r0 < r_end; r0 += 64) {
+        BMX_LOAD_TILE(a1, r0 + 32)
+        tile(a0, r0);
+        BMX_LOAD_TILE(a0, r0 + 64)
+        tile(a1, r0 + 32);
+    }
+#undef BMX_LOAD_TILE
+
+    for (int jj = 0; jj < 32; ++jj) compact_slot<KS>(buf, kcnt, tau_s, jj, jj, lane, mycnt);
+    for (int jj = 0; jj < 32; ++jj) {
+        const int qq = blockIdx.x * 32 + jj;
+        const int n = kcnt[jj];
+        if (seed_out) {
+            unsigned long long* sp = seed_out + (int64_t)qq * (KS + 1);
+            if (lane < KS) sp[lane] = buf[jj * CAP + lane];
+            if (lane == 0) sp[KS] = (unsigned long long)n;
+            continue;
+        }
+        if (lane < KS) {
+            const unsigned long long key = buf[jj * CAP + lane];
+            cand[((int64_t)qq * out_nchunks + out_chunk) * KS + lane] = lane < n ? (int32_t)(uint32_t)key : -1;
+        }
+        if (lane == 0) tau_out[(int64_t)qq * out_nchunks + out_chunk] = tau_s[jj];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -330,6 +509,20 @@ __global__ __launch_bounds__(256) void knn_refine(const double* __restrict__ X, 
         si[w][m] = id >= 0 ? id : 0x7FFFFFFF;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (nchunks > 1) {
+        // seeded ranges can carry the same sample reference in several lists: keep the first copy only
+        for (int m = lane; m < M; m += 64) {
+            const int im = si[w][m];
+            bool dup = false;
+            if (im != 0x7FFFFFFF)
+                for (int f = 0; f < m; ++f) dup |= si[w][f] == im;
+            if (dup) sd[w][m] = __builtin_inf();
+            // the index is voided after every lane has finished comparing against it
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (dup) si[w][m] = 0x7FFFFFFF;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
     double kth = 0.0;
     for (int m = lane; m < M; m += 64) {
         const double dm = sd[w][m];
@@ -419,30 +612,70 @@ __global__ void accumulate_flagged(const int32_t* __restrict__ flagged, unsigned
     if (threadIdx.x == 0 && blockIdx.x == 0) *total += (unsigned long long)flagged[0];
 }
 
+struct TopkLaunch {
+    const float* pq;
+    const float* pr;
+    int nqb;          // query blocks
+    int first_begin;  // first prepared reference row of range 0
+    int range_len;    // rows per range (tile multiple)
+    int nranges;
+    int r_limit;      // end of the last range
+    int out_chunk0;   // candidate-list column of range 0
+    int out_nchunks;  // candidate-list columns in total
+    const float* tau_init;
+    int32_t* cand;
+    float* tau;
+    int variant;      // 0: workgroup-shared LDS staging, 1: wave-per-workgroup streaming
+    int lds_pad;      // extra dynamic LDS requested by variant 1 to cap resident waves per CU
+    const unsigned long long* seed_in = nullptr;  // variant 1
+    unsigned long long* seed_out = nullptr;       // variant 1
+};
+
 template <int KP, int KS>
-void launch_topk(hipStream_t stream, const float* pq, const float* pr, int nq_pad, int nr_pad, int chunk_len,
-                 int nchunks, int32_t* cand, float* tau) {
-    constexpr int CAP = KS + SLACK;
-    const size_t lds = (size_t)2 * RT * KP * 4 + (size_t)QB * CAP * 8 + QB * 4 + QB * 4;
+size_t topk_lds_bytes() {
+    return (size_t)2 * RT * KP * 4 + (size_t)QB * (KS + 2 * PL) * 8 + QB * 4 + QB * 4;
+}
+
+template <int KP, int KS>
+void launch_topk(hipStream_t stream, KnnWorkspace& ws, const TopkLaunch& L) {
+    const size_t lds = topk_lds_bytes<KP, KS>();
     static bool attr_set = false;
     if (!attr_set) {
         BMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_topk_mfma<KP, KS>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    dim3 grid(nq_pad / QB, nchunks);
-    hipLaunchKernelGGL((knn_topk_mfma<KP, KS>), grid, dim3(THREADS), lds, stream, pq, pr, nq_pad, nr_pad, chunk_len,
-                       nchunks, cand, tau);
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    if (ws.profile) {
+        ev = ws.next_events();
+        BMX_HIP(hipEventRecord(ev.first, stream));
+    }
+    if (L.variant == 1) {
+        const size_t lds1 = (size_t)32 * (KS + 2 * PL) * 8 + 256 + (size_t)L.lds_pad;
+        static size_t attr1 = 0;
+        if (lds1 > attr1) {
+            BMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_topk_w1<KP, KS>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+            attr1 = lds1;
+        }
+        hipLaunchKernelGGL((knn_topk_w1<KP, KS>), dim3(L.nqb, L.nranges), dim3(64), lds1, stream, L.pq, L.pr,
+                           L.first_begin, L.range_len, L.r_limit, L.out_chunk0, L.out_nchunks, L.seed_in, L.seed_out,
+                           L.cand, L.tau);
+    } else {
+        hipLaunchKernelGGL((knn_topk_mfma<KP, KS>), dim3(L.nqb, L.nranges), dim3(THREADS), lds, stream, L.pq, L.pr,
+                           L.first_begin, L.range_len, L.r_limit, L.out_chunk0, L.out_nchunks, L.tau_init, L.cand,
+                           L.tau);
+    }
     BMX_LAUNCH_CHECK();
+    if (ws.profile) BMX_HIP(hipEventRecord(ev.second, stream));
 }
 
 template <int KS>
-bool dispatch_kp(int KP, hipStream_t s, const float* pq, const float* pr, int nq_pad, int nr_pad, int cl, int nc,
-                 int32_t* cand, float* tau) {
+bool dispatch_kp(int KP, hipStream_t s, KnnWorkspace& ws, const TopkLaunch& L) {
     switch (KP) {
-#define BMX_KP_CASE(V)                                                  \
-    case V:                                                             \
-        launch_topk<V, KS>(s, pq, pr, nq_pad, nr_pad, cl, nc, cand, tau); \
+#define BMX_KP_CASE(V)                      \
+    case V:                                 \
+        launch_topk<V, KS>(s, ws, L);       \
         return true;
         BMX_KP_CASE(8)
         BMX_KP_CASE(16)
@@ -459,6 +692,8 @@ bool dispatch_kp(int KP, hipStream_t s, const float* pq, const float* pr, int nq
             return false;
     }
 }
+
+size_t topk_lds_for(int KP, int KS) { return (size_t)2 * RT * KP * 4 + (size_t)QB * (KS + 2 * PL) * 8 + QB * 8; }
 
 int pick_kp(int d) {
     static const int opts[] = {8, 16, 24, 32, 40, 56, 64, 80, 104, 128};
@@ -490,22 +725,56 @@ void knn_device(hipStream_t stream, KnnWorkspace& ws, const double* X, const int
     const int KS = k <= 20 ? 24 : (k <= 36 ? 40 : 0);
     const bool use_mfma = !ws.force_exact && KP != 0 && KS != 0 && nr > 2 * KS;
 
-    ws.topk_launched = false;
     int32_t* flagged = ws.flagged.reserve((size_t)nq + 1);
     BMX_HIP(hipMemsetAsync(flagged, 0, sizeof(int32_t), stream));
 
     if (use_mfma) {
         const int nq_pad = (int)round_up(nq, QB);
-        // reference chunks: enough workgroups to fill 256 CUs x 2 several times over, chunk length a tile multiple
-        int nchunks = 1;
-        const int nqb = nq_pad / QB;
-        while (nchunks < MAX_CHUNKS && (int64_t)nqb * nchunks < 1024 && (int64_t)nr / (nchunks * 2) >= 4096) nchunks *= 2;
-        const int chunk_len = (int)round_up(cdiv(nr, nchunks), RT);
-        nchunks = cdiv(nr, chunk_len);
-        const int nr_pad = chunk_len * nchunks;
+        static const int variant = [] {
+            const char* v = std::getenv("BMX_TOPK_VARIANT");
+            return v ? std::atoi(v) : 1;
+        }();
+        const int nqb = variant == 1 ? nq_pad / 32 : nq_pad / QB;
+        // Reference ranges.  A short sample range [0, S) runs first and leaves every query a valid starting
+        // threshold, so the C main ranges start selective instead of with tau = +inf.  C (and, for the
+        // wave-per-workgroup kernel, the resident workgroups per CU W, capped through the LDS request) is picked so
+        // that (query blocks x C) workgroups fill the resident slots in whole rounds; every extra range costs a
+        // little selection work, hence the small penalties.
+        const int S = nr >= 32768 ? 4096 : 0;
+        int C = 1, W = 12;
+        {
+            double best = -1.0;
+            // resident waves per CU for the wave-per-workgroup kernel: VGPRs (100 up to KP 64, 168 above) and LDS
+            const int w_cap = std::min(KP <= 64 ? 16 : 12, (160 * 1024) / (32 * (KS + 2 * PL) * 8 + 256));
+            const int w_lo = variant == 1 ? std::min(8, w_cap) : 0, w_hi = variant == 1 ? w_cap : 0;
+            for (int w = w_hi; w >= w_lo; --w)
+                for (int c = 1; c <= MAX_CHUNKS - 1; ++c) {
+                    if (c > 1 && (nr - S) / c < 2048) break;
+                    const int slots = variant == 1 ? w * 256 : (topk_lds_for(KP, KS) <= 80 * 1024 ? 512 : 256);
+                    const double rounds = (double)nqb * c / slots;
+                    const double eff = rounds >= 1.0 ? rounds / std::ceil(rounds) : rounds;
+                    const double score = eff - 0.015 * c - 0.01 * (w_hi - w);
+                    if (score > best) {
+                        best = score;
+                        C = c;
+                        W = w;
+                    }
+                }
+        }
+        const int rmul = RT;
+        const int chunk_len = (int)round_up(cdiv(nr - S, C), rmul);
+        C = std::max(1, cdiv(nr - S, chunk_len));
+        const int nr_pad = S + chunk_len * C;
+        const int nchunks = C + (S > 0 && variant != 1 ? 1 : 0);  // variant 1 folds the sample into every range
+        if (std::getenv("BMX_DEBUG")) fprintf(stderr, "[bmx] knn nq=%d nr=%d KP=%d KS=%d variant=%d S=%d C=%d W=%d chunk=%d\n", nq, nr, KP, KS, variant, S, C, W, chunk_len);
+        int lds_pad = 0;
+        if (variant == 1) {
+            const int base = 32 * (KS + 2 * PL) * 8 + 256;
+            lds_pad = std::max(0, (160 * 1024) / W - 512 - base);  // floor(160 KiB / request) == W
+        }
 
         float* pq = ws.pq.reserve((size_t)nq_pad * KP);
-        float* pr = ws.pr.reserve((size_t)(nr_pad + RT) * KP);  // + one tile: the staging loads over-read
+        float* pr = ws.pr.reserve((size_t)(nr_pad + 4 * RT) * KP);  // + tail padding: the prefetches over-read
         double* qn2 = ws.qn2.reserve(nq_pad);
         double* rn2 = ws.rn2.reserve(nr_pad);
         double* mean = ws.mean.reserve((size_t)d + 2);
@@ -524,18 +793,30 @@ void knn_device(hipStream_t stream, KnnWorkspace& ws, const double* X, const int
         BMX_HIP(hipMemsetAsync(maxbits, 0, sizeof(unsigned long long), stream));
 
         hipLaunchKernelGGL(knn_prep, dim3(cdiv(nr_pad, 256)), dim3(256), 0, stream, X, ref_rows, nr, nr_pad, d, KP, mean,
-                           0, pr, rn2, maxbits);
+                           0, variant == 1 ? 1 : 0, pr, rn2, maxbits);
         BMX_LAUNCH_CHECK();
         hipLaunchKernelGGL(knn_prep, dim3(cdiv(nq_pad, 256)), dim3(256), 0, stream, Qs, qrs, nq, nq_pad, d, KP, mean, 1,
-                           pq, qn2, maxbits);
+                           0, pq, qn2, maxbits);
         BMX_LAUNCH_CHECK();
 
-        if (ws.ev_begin) BMX_HIP(hipEventRecord(ws.ev_begin, stream));
-        bool ok = KS == 24 ? dispatch_kp<24>(KP, stream, pq, pr, nq_pad, nr_pad, chunk_len, nchunks, cand, tau)
-                           : dispatch_kp<40>(KP, stream, pq, pr, nq_pad, nr_pad, chunk_len, nchunks, cand, tau);
+        TopkLaunch L{pq, pr, nqb, 0, S, 1, S, 0, nchunks, nullptr, cand, tau, variant, lds_pad};
+        unsigned long long* seed = nullptr;
+        if (variant == 1 && S > 0) {
+            seed = reinterpret_cast<unsigned long long*>(ws.seed.reserve((size_t)nq_pad * (KS + 1)));
+            L.seed_out = seed;
+        }
+        bool ok = true;
+        if (S > 0) ok = KS == 24 ? dispatch_kp<24>(KP, stream, ws, L) : dispatch_kp<40>(KP, stream, ws, L);
+        L.first_begin = S;
+        L.range_len = chunk_len;
+        L.nranges = C;
+        L.r_limit = nr_pad;
+        L.out_chunk0 = S > 0 && variant != 1 ? 1 : 0;
+        L.tau_init = S > 0 && variant != 1 ? tau : nullptr;  // column 0 of tau[q][nchunks]: read with stride nchunks
+        L.seed_in = seed;
+        L.seed_out = nullptr;
+        ok = ok && (KS == 24 ? dispatch_kp<24>(KP, stream, ws, L) : dispatch_kp<40>(KP, stream, ws, L));
         if (!ok) throw Error(BMX_ERR_ARG, "kNN: unsupported padded dimension");
-        if (ws.ev_end) BMX_HIP(hipEventRecord(ws.ev_end, stream));
-        ws.topk_launched = true;
 
         hipLaunchKernelGGL(knn_refine, dim3(cdiv(nq, 4)), dim3(256), 0, stream, X, ref_rows, Qs, qrs, nq, d, k, KS,
                            nchunks, KP, cand, tau, qn2, maxbits, io, dout, flagged);
