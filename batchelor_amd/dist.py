@@ -52,7 +52,8 @@ class TorchExchange:
         """full: 1-D uint8 tensor of world * per bytes whose slice `rank` is valid; gathers in place."""
         mine = full[self.rank * per:(self.rank + 1) * per]
         if self.backend == "nccl":
-            self.dist.all_gather_into_tensor(full, mine, group=self.group)
+            # a private copy of the (few-MB) slice keeps send and receive buffers disjoint
+            self.dist.all_gather_into_tensor(full, mine.clone(), group=self.group)
         else:
             host = mine.cpu() if full.is_cuda else mine.clone()
             parts = [self.torch.empty_like(host) for _ in range(self.world)]

@@ -1,0 +1,68 @@
+"""Sharded engine on real hardware: two ranks (sharing the box's one GPU, gloo exchange) must both produce exactly
+the single-rank result -- pairs bit-identical, coordinates bit-identical (the exchange is the only difference)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_rank_engine_equals_single_rank(tmp_path):
+    import batchelor_amd as bx
+    from tests.conftest import synth_batches
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_gpu_shard_worker.py"), str(r), "2",
+                               str(port), str(tmp_path)], env=env) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    B = synth_batches(13, [3001, 2500, 1777], 50)
+    ref = bx.reducedMNN(*B)
+    for r in range(2):
+        got = np.load(tmp_path / f"rank{r}.npz")
+        assert np.array_equal(got["corrected"], ref.corrected)
+        for m in range(2):
+            assert np.array_equal(got[f"pl{m}"], ref.merge_info.pairs[m][0])
+            assert np.array_equal(got[f"pr{m}"], ref.merge_info.pairs[m][1])
+        assert np.array_equal(got["lost_var"], ref.merge_info.lost_var)
+        assert int(got["calls"]) == 2 * (2 + 2)   # per merge: two index gathers + tricube index and distance gathers
+
+
+def test_nccl_exchange_aliases_raw_device_pointer():
+    """World-size-1 RCCL group: the production transport (all_gather_into_tensor on a tensor aliasing a raw device
+    pointer handed over by the engine) runs and really aliases the buffer."""
+    code = r'''
+import os, sys
+sys.path.insert(0, os.environ["BMX_ROOT"])
+import torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%s" % os.environ["BMX_PORT"], rank=0, world_size=1,
+                        device_id=torch.device("cuda", 0))
+from batchelor_amd.dist import TorchExchange, _RawDeviceBuffer
+ex = TorchExchange(0)
+t = torch.arange(4096, dtype=torch.uint8, device="cuda") % 251
+ref = t.clone()
+alias = torch.as_tensor(_RawDeviceBuffer(t.data_ptr(), t.numel()), device=torch.device("cuda", 0))
+alias[7] = 200
+assert int(t[7]) == 200
+ref[7] = 200
+ex(t.data_ptr(), t.numel())
+assert torch.equal(t, ref) and ex.calls == 1
+dist.destroy_process_group()
+print("nccl-ok")
+'''
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, BMX_ROOT=ROOT, BMX_PORT=str(port))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "nccl-ok" in out.stdout, out.stderr[-2000:]
