@@ -67,6 +67,7 @@ struct KnnWorkspace {
     DevBuf<double> qn2, rn2, mean, red;
     DevBuf<int32_t> cand;          // [nq][C][KS]
     DevBuf<float> tau;             // [nq][C]
+    DevBuf<float> tau0;            // [nq] starting thresholds from the sample pass (split-bf16 kernel)
     DevBuf<uint64_t> seed;         // [nq][KS + 1] kept list of the sample range (wave-per-workgroup kernel)
     DevBuf<int32_t> flagged;       // [nq + 1] compact list of queries needing the exact path (+ counter)
     DevBuf<double> drow;           // exact-path distance rows
@@ -95,6 +96,22 @@ struct KnnWorkspace {
     }
     unsigned long long* flag_total = nullptr;  // device counter accumulating exact-path queries (optional)
 };
+
+// split-bf16 candidate pass (knn_bf16.hip)
+struct Bf16Launch {
+    const uint16_t* pq;
+    const uint16_t* pr;
+    int nqb, first_begin, range_len, nranges, r_limit, out_chunk0, out_nchunks;
+    const float* tau_init;  // full pass: starting threshold per query (from the sample pass), or null
+    int sample;             // non-zero: threshold-estimation pass, writes tau[q] only
+    int32_t* cand;
+    float* tau;
+};
+int bf16_pick_ns(int d);         // MFMA k-steps (16 bf16 each) for 3 d + 3 columns; 0 = unsupported
+int bf16_ncons(int NS, int KS);  // consumer waves (32 queries each) per workgroup
+void bf16_prep(hipStream_t stream, const double* X, const int32_t* rows, int n, int n_pad, int d, int NS,
+               const double* mean, int is_query, uint16_t* P, double* n2, unsigned long long* maxbits);
+bool bf16_launch(hipStream_t stream, KnnWorkspace& ws, int NS, int KS, const Bf16Launch& L);
 
 // For rows q in [q_begin, q_end) of the query list: the k nearest rows of the reference list (exact, FP64 Euclidean,
 // ties by lowest position).  X/Q are row-major [*, d]; ref_rows / q_rows (0-based, may be null = identity) select

@@ -19,6 +19,7 @@
 //                        entirely in FP64.
 // Result: indices are exactly those of an FP64 brute-force search with (distance, index) ordering.
 #include "bmx_common.hpp"
+#include "knn_select.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -27,22 +28,12 @@
 namespace bmx {
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+using namespace sel;
 
 constexpr int QB = 128;          // queries per workgroup: 4 waves x one 32-query MFMA column tile
 constexpr int RT = 64;           // references per staged LDS tile (two 32-row MFMA tiles)
 constexpr int THREADS = 256;
 constexpr int MAX_CHUNKS = 8;
-
-__device__ __forceinline__ uint32_t f32_orderable(float v) {
-    uint32_t u = __float_as_uint(v);
-    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
-}
-__device__ __forceinline__ float orderable_f32(uint32_t o) {
-    uint32_t u = o ^ ((o >> 31) ? 0x80000000u : 0xFFFFFFFFu);
-    return __uint_as_float(u);
-}
 
 // ---------------------------------------------------------------------------------------------------
 // column sums over a row list (two deterministic stages)
@@ -116,40 +107,6 @@ __global__ void knn_prep(const double* __restrict__ X, const int32_t* __restrict
 // ---------------------------------------------------------------------------------------------------
 // 2. MFMA distance tiles + per-query threshold / buffer selection
 // ---------------------------------------------------------------------------------------------------
-// Per query slot the LDS holds KS "kept" entries (sorted, shared by the two lanes that own the query's two K-halves)
-// followed by two lane-private pending lists of PL entries each: a lane appends with a plain ds_write (no atomics, no
-// returned value to wait for).  When a pending list fills, one wave merges kept + both pending lists by rank-counting
-// over the unique 64-bit keys (orderable value << 32 | reference index), keeps the KS smallest and tightens tau.
-constexpr int PL = 12;
-
-template <int KS>
-__device__ __forceinline__ void compact_slot(unsigned long long* buf, int* kcnt, float* tau_s, int slot, int jj,
-                                             int lane, int& mycnt) {
-    constexpr int CAP = KS + 2 * PL;
-    const int nk = kcnt[slot];
-    const int n0 = __builtin_amdgcn_readlane(mycnt, jj);
-    const int n1 = __builtin_amdgcn_readlane(mycnt, jj + 32);
-    const int n = nk + n0 + n1;
-    unsigned long long* b = buf + slot * CAP;
-    int src = lane;  // kept entries sit at [0, nk)
-    if (lane >= nk) src = lane < nk + n0 ? KS + (lane - nk) : KS + PL + (lane - nk - n0);
-    const unsigned long long key = lane < n ? b[src] : ~0ull;
-    const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
-    int rank = 0;
-    for (int f = 0; f < n; ++f) {
-        const uint32_t flo = __builtin_amdgcn_readlane(klo, f);
-        const uint32_t fhi = __builtin_amdgcn_readlane(khi, f);
-        const unsigned long long fk = ((unsigned long long)fhi << 32) | flo;
-        rank += fk < key ? 1 : 0;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // every lane holds its key before slots are rewritten
-    if (lane < n && rank < KS) b[rank] = key;
-    if (n >= KS && lane < n && rank == KS - 1) tau_s[slot] = orderable_f32(khi);
-    if (lane == 0) kcnt[slot] = n < KS ? n : KS;
-    if (lane == jj || lane == jj + 32) mycnt = 0;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-}
-
 // Staging registers as a recursive struct (an array here ends up in scratch memory).
 template <int N>
 struct StageRegs {
@@ -488,7 +445,8 @@ constexpr int REFINE_MAXM = 64 * 5;  // MAX_CHUNKS * 40
 
 __global__ __launch_bounds__(256) void knn_refine(const double* __restrict__ X, const int32_t* __restrict__ ref_rows,
                                                   const double* __restrict__ Q, const int32_t* __restrict__ q_rows,
-                                                  int nq, int d, int k, int KS, int nchunks, int KP,
+                                                  int nq, int d, int k, int KS, int nchunks, double eps_k,
+                                                  double eps_qr, double eps_split,
                                                   const int32_t* __restrict__ cand, const float* __restrict__ tau,
                                                   const double* __restrict__ qn2,
                                                   const unsigned long long* __restrict__ max_rn2_bits,
@@ -547,7 +505,9 @@ __global__ __launch_bounds__(256) void knn_refine(const double* __restrict__ X, 
         const double qn = sqrt(qn2[q]);
         const double rm = sqrt(__longlong_as_double((long long)*max_rn2_bits));
         const double u = 5.9604644775390625e-8;  // 2^-24
-        const double eps = 1.5 * u * (2.0 * (qn + rm) * (qn + rm) + (KP + 1.0) * (rm * rm + 2.0 * qn * rm));
+        // f32 rounding of the centred coordinates + accumulation over eps_k terms (+ the dropped split-bf16 terms)
+        const double eps = 1.5 * (u * (2.0 * (qn + rm) * (qn + rm) + (eps_k + 1.0) * (rm * rm + eps_qr * qn * rm)) +
+                                  eps_split * qn * rm);
         const bool proven = kth < (double)tmin + qn2[q] - eps;  // tmin = +inf when nothing was ever rejected
         if (!proven) {
             const int pos = atomicAdd(&flagged[0], 1);
@@ -557,54 +517,61 @@ __global__ __launch_bounds__(256) void knn_refine(const double* __restrict__ X, 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// 4. exact FP64 scan for flagged queries (or every query when the MFMA path does not apply)
+// 4. exact FP64 scan for flagged queries (or every query when the MFMA path does not apply), in batches:
+//    knn_exact_dist   -- grid (reference blocks, queries of the batch): all exact squared distances, spread over the
+//                        whole chip even when only a handful of queries are flagged;
+//    knn_exact_select -- one workgroup per query: k rounds of block-wide (distance, index) minimum.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void knn_exact(const double* __restrict__ X, const int32_t* __restrict__ ref_rows,
-                                                 int nr, const double* __restrict__ Q,
-                                                 const int32_t* __restrict__ q_rows, int nq, int d, int k,
-                                                 const int32_t* __restrict__ flagged, int all_queries,
-                                                 double* __restrict__ drow, int32_t* __restrict__ idx_out,
-                                                 double* __restrict__ dist_out) {
+__global__ __launch_bounds__(256) void knn_exact_dist(const double* __restrict__ X, const int32_t* __restrict__ ref_rows,
+                                                      int nr, const double* __restrict__ Q,
+                                                      const int32_t* __restrict__ q_rows, int d,
+                                                      const int32_t* __restrict__ flagged, int f0,
+                                                      double* __restrict__ drow) {
+    const int f = f0 + blockIdx.y;
+    const int q = flagged ? flagged[1 + f] : f;
+    const double* qv = Q + (int64_t)(q_rows ? q_rows[q] : q) * d;
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r < nr) drow[(int64_t)blockIdx.y * nr + r] = exact_d2(qv, X + (int64_t)(ref_rows ? ref_rows[r] : r) * d, d);
+}
+
+__global__ __launch_bounds__(256) void knn_exact_select(const double* __restrict__ drow, int nr, int k,
+                                                        const int32_t* __restrict__ flagged, int f0,
+                                                        int32_t* __restrict__ idx_out, double* __restrict__ dist_out) {
     __shared__ double rd[256];
     __shared__ int ri[256];
     const int tid = threadIdx.x;
-    const int count = all_queries ? nq : flagged[0];
-    double* row = drow + (int64_t)blockIdx.x * nr;
-    for (int f = blockIdx.x; f < count; f += gridDim.x) {
-        const int q = all_queries ? f : flagged[1 + f];
-        const double* qv = Q + (int64_t)(q_rows ? q_rows[q] : q) * d;
-        for (int r = tid; r < nr; r += 256) row[r] = exact_d2(qv, X + (int64_t)(ref_rows ? ref_rows[r] : r) * d, d);
+    const int f = f0 + blockIdx.x;
+    const int q = flagged ? flagged[1 + f] : f;
+    const double* row = drow + (int64_t)blockIdx.x * nr;
+    double last_d = -1.0;  // squared distances are >= 0
+    int last_i = -1;
+    for (int jdx = 0; jdx < k; ++jdx) {
+        double bd = __builtin_inf();
+        int bi = 0x7FFFFFFF;
+        for (int r = tid; r < nr; r += 256) {
+            const double v = row[r];
+            if (key_less(last_d, last_i, v, r) && key_less(v, r, bd, bi)) {
+                bd = v;
+                bi = r;
+            }
+        }
+        rd[tid] = bd;
+        ri[tid] = bi;
         __syncthreads();
-        double last_d = -1.0;  // squared distances are >= 0
-        int last_i = -1;
-        for (int jdx = 0; jdx < k; ++jdx) {
-            double bd = __builtin_inf();
-            int bi = 0x7FFFFFFF;
-            for (int r = tid; r < nr; r += 256) {
-                const double v = row[r];
-                if (key_less(last_d, last_i, v, r) && key_less(v, r, bd, bi)) {
-                    bd = v;
-                    bi = r;
-                }
-            }
-            rd[tid] = bd;
-            ri[tid] = bi;
-            __syncthreads();
-            for (int o = 128; o > 0; o >>= 1) {
-                if (tid < o && key_less(rd[tid + o], ri[tid + o], rd[tid], ri[tid])) {
-                    rd[tid] = rd[tid + o];
-                    ri[tid] = ri[tid + o];
-                }
-                __syncthreads();
-            }
-            last_d = rd[0];
-            last_i = ri[0];
-            if (tid == 0) {
-                idx_out[(int64_t)q * k + jdx] = last_i;
-                if (dist_out) dist_out[(int64_t)q * k + jdx] = sqrt(last_d);
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o && key_less(rd[tid + o], ri[tid + o], rd[tid], ri[tid])) {
+                rd[tid] = rd[tid + o];
+                ri[tid] = ri[tid + o];
             }
             __syncthreads();
         }
+        last_d = rd[0];
+        last_i = ri[0];
+        if (tid == 0) {
+            idx_out[(int64_t)q * k + jdx] = last_i;
+            if (dist_out) dist_out[(int64_t)q * k + jdx] = sqrt(last_d);
+        }
+        __syncthreads();
     }
 }
 
@@ -729,31 +696,49 @@ void knn_device(hipStream_t stream, KnnWorkspace& ws, const double* X, const int
     BMX_HIP(hipMemsetAsync(flagged, 0, sizeof(int32_t), stream));
 
     if (use_mfma) {
-        const int nq_pad = (int)round_up(nq, QB);
-        static const int variant = [] {
+        // candidate-pass variant: 2 = split-bf16 MFMA with an LDS ring (default), 1 = f32 MFMA, one wave per
+        // workgroup, 0 = f32 MFMA with workgroup-shared LDS staging.  BMX_TOPK_VARIANT overrides (A/B runs).
+        static const int requested = [] {
             const char* v = std::getenv("BMX_TOPK_VARIANT");
-            return v ? std::atoi(v) : 1;
+            return v ? std::atoi(v) : 2;
         }();
-        const int nqb = variant == 1 ? nq_pad / 32 : nq_pad / QB;
-        // Reference ranges.  A short sample range [0, S) runs first and leaves every query a valid starting
-        // threshold, so the C main ranges start selective instead of with tau = +inf.  C (and, for the
-        // wave-per-workgroup kernel, the resident workgroups per CU W, capped through the LDS request) is picked so
-        // that (query blocks x C) workgroups fill the resident slots in whole rounds; every extra range costs a
-        // little selection work, hence the small penalties.
-        const int S = nr >= 32768 ? 4096 : 0;
-        int C = 1, W = 12;
+        const int NS = bf16_pick_ns(d);
+        int variant = requested;
+        if (variant == 2 && (NS == 0 || (KS == 40 && NS > 16))) variant = 1;
+        const int ncons = variant == 2 ? bf16_ncons(NS, KS) : 0;
+        const int unit = variant == 2 ? 32 * ncons : (variant == 1 ? 32 : QB);  // queries per workgroup
+        const int nq_pad = (int)round_up(nq, 256);
+        const int nqb = nq_pad / unit;
+        const int rmul = variant == 2 ? 32 : RT;  // range lengths are multiples of the kernels' tile step
+
+        // Reference ranges.  A short sample range [0, S) runs first; its kept list seeds every main range (variants
+        // 1, 2) or at least hands it a valid starting threshold (variant 0), so selection is tight from the first
+        // tile.  C ranges (and for variant 1 the resident workgroups per CU, W, capped through the LDS request) are
+        // picked so that (query blocks x C) workgroups fill the resident slots in whole rounds; every extra range
+        // repeats a little selection work, hence the small penalties.
+        const int S = nr >= 32768 ? (std::getenv("BMX_SAMPLE") ? std::atoi(std::getenv("BMX_SAMPLE")) : 4096) : 0;
+        int C = 1, W = 0;
         {
+            int w_lo = 0, w_hi = 0, fixed_slots = 0;
+            if (variant == 1) {  // VGPRs (100 up to KP 64, 168 above) and LDS bound the resident waves per CU
+                w_hi = std::min(KP <= 64 ? 16 : 12, (160 * 1024) / (32 * (KS + 2 * PL) * 8 + 256));
+                w_lo = std::min(8, w_hi);
+            } else if (variant == 2) {
+                const size_t lds = (size_t)4 * NS * 1024 + (size_t)ncons * 32 * (KS + 2 * PL) * 8 + ncons * 256 + 64;
+                fixed_slots = 256 * std::max<int>(1, std::min<size_t>((160 * 1024) / lds, 32 / (ncons + 4)));
+            } else {
+                fixed_slots = topk_lds_for(KP, KS) <= 80 * 1024 ? 512 : 256;
+            }
             double best = -1.0;
-            // resident waves per CU for the wave-per-workgroup kernel: VGPRs (100 up to KP 64, 168 above) and LDS
-            const int w_cap = std::min(KP <= 64 ? 16 : 12, (160 * 1024) / (32 * (KS + 2 * PL) * 8 + 256));
-            const int w_lo = variant == 1 ? std::min(8, w_cap) : 0, w_hi = variant == 1 ? w_cap : 0;
             for (int w = w_hi; w >= w_lo; --w)
                 for (int c = 1; c <= MAX_CHUNKS - 1; ++c) {
                     if (c > 1 && (nr - S) / c < 2048) break;
-                    const int slots = variant == 1 ? w * 256 : (topk_lds_for(KP, KS) <= 80 * 1024 ? 512 : 256);
+                    const int slots = variant == 1 ? w * 256 : fixed_slots;
                     const double rounds = (double)nqb * c / slots;
                     const double eff = rounds >= 1.0 ? rounds / std::ceil(rounds) : rounds;
-                    const double score = eff - 0.015 * c - 0.01 * (w_hi - w);
+                    // measured on 100k x 100k: each extra range costs the split-bf16 kernel ~0.1 of a sweep (selection
+                    // restarts from the sample threshold, bigger refine), the f32 kernels ~0.015
+                    const double score = eff - (variant == 2 ? 0.10 : 0.015) * c - 0.01 * (w_hi - w);
                     if (score > best) {
                         best = score;
                         C = c;
@@ -761,28 +746,35 @@ void knn_device(hipStream_t stream, KnnWorkspace& ws, const double* X, const int
                     }
                 }
         }
-        const int rmul = RT;
-        const int chunk_len = (int)round_up(cdiv(nr - S, C), rmul);
-        C = std::max(1, cdiv(nr - S, chunk_len));
-        const int nr_pad = S + chunk_len * C;
-        const int nchunks = C + (S > 0 && variant != 1 ? 1 : 0);  // variant 1 folds the sample into every range
-        if (std::getenv("BMX_DEBUG")) fprintf(stderr, "[bmx] knn nq=%d nr=%d KP=%d KS=%d variant=%d S=%d C=%d W=%d chunk=%d\n", nq, nr, KP, KS, variant, S, C, W, chunk_len);
+        if (std::getenv("BMX_FORCE_C")) C = std::atoi(std::getenv("BMX_FORCE_C"));
+        const int main_rows = variant == 2 ? nr : nr - S;  // the bf16 full pass rescans the sample rows
+        const int chunk_len = (int)round_up(cdiv(main_rows, C), rmul);
+        C = std::max(1, cdiv(main_rows, chunk_len));
+        const int nr_pad = (variant == 2 ? 0 : S) + chunk_len * C;
+        const bool seeded = variant == 1 && S > 0;
+        const int nchunks = C + (S > 0 && variant == 0 ? 1 : 0);  // only variant 0 keeps the sample as its own column
+        if (std::getenv("BMX_DEBUG"))
+            fprintf(stderr, "[bmx] knn nq=%d nr=%d d=%d KS=%d variant=%d S=%d C=%d W=%d chunk=%d\n", nq, nr, d, KS,
+                    variant, S, C, W, chunk_len);
         int lds_pad = 0;
         if (variant == 1) {
             const int base = 32 * (KS + 2 * PL) * 8 + 256;
             lds_pad = std::max(0, (160 * 1024) / W - 512 - base);  // floor(160 KiB / request) == W
         }
 
-        float* pq = ws.pq.reserve((size_t)nq_pad * KP);
-        float* pr = ws.pr.reserve((size_t)(nr_pad + 4 * RT) * KP);  // + tail padding: the prefetches over-read
+        const int KPw = variant == 2 ? 8 * NS : KP;  // prepared row width in 4-byte words
+        float* pq = ws.pq.reserve((size_t)nq_pad * KPw);
+        float* pr = ws.pr.reserve((size_t)(nr_pad + 4 * RT) * KPw);  // + tail padding: the prefetches over-read
         double* qn2 = ws.qn2.reserve(nq_pad);
         double* rn2 = ws.rn2.reserve(nr_pad);
         double* mean = ws.mean.reserve((size_t)d + 2);
         unsigned long long* maxbits = reinterpret_cast<unsigned long long*>(mean + d);
         int32_t* cand = ws.cand.reserve((size_t)nq_pad * nchunks * KS);
         float* tau = ws.tau.reserve((size_t)nq_pad * nchunks);
+        unsigned long long* seed =
+            seeded ? reinterpret_cast<unsigned long long*>(ws.seed.reserve((size_t)nq_pad * (KS + 1))) : nullptr;
 
-        // reference mean (any centre is valid; the mean keeps the f32 error bound tight)
+        // reference mean (any centre is valid; the mean keeps the error bound tight)
         const int rpb = 1024;
         const int nb = cdiv(nr, rpb);
         double* red = ws.red.reserve((size_t)nb * d);
@@ -792,46 +784,83 @@ void knn_device(hipStream_t stream, KnnWorkspace& ws, const double* X, const int
         BMX_LAUNCH_CHECK();
         BMX_HIP(hipMemsetAsync(maxbits, 0, sizeof(unsigned long long), stream));
 
-        hipLaunchKernelGGL(knn_prep, dim3(cdiv(nr_pad, 256)), dim3(256), 0, stream, X, ref_rows, nr, nr_pad, d, KP, mean,
-                           0, variant == 1 ? 1 : 0, pr, rn2, maxbits);
-        BMX_LAUNCH_CHECK();
-        hipLaunchKernelGGL(knn_prep, dim3(cdiv(nq_pad, 256)), dim3(256), 0, stream, Qs, qrs, nq, nq_pad, d, KP, mean, 1,
-                           0, pq, qn2, maxbits);
-        BMX_LAUNCH_CHECK();
-
-        TopkLaunch L{pq, pr, nqb, 0, S, 1, S, 0, nchunks, nullptr, cand, tau, variant, lds_pad};
-        unsigned long long* seed = nullptr;
-        if (variant == 1 && S > 0) {
-            seed = reinterpret_cast<unsigned long long*>(ws.seed.reserve((size_t)nq_pad * (KS + 1)));
-            L.seed_out = seed;
+        double eps_k, eps_qr, eps_split;
+        if (variant == 2) {
+            bf16_prep(stream, X, ref_rows, nr, nr_pad, d, NS, mean, 0, reinterpret_cast<uint16_t*>(pr), rn2, maxbits);
+            bf16_prep(stream, Qs, qrs, nq, nq_pad, d, NS, mean, 1, reinterpret_cast<uint16_t*>(pq), qn2, maxbits);
+            // sample pass: threshold estimation over rows [0, S); full pass: every row, starting from that threshold
+            float* tau0 = S > 0 ? ws.tau0.reserve(nq_pad) : nullptr;
+            Bf16Launch L{reinterpret_cast<const uint16_t*>(pq), reinterpret_cast<const uint16_t*>(pr), nqb, 0, S, 1, S,
+                         0, nchunks, nullptr, 1, cand, tau0};
+            bool ok = true;
+            if (S > 0) ok = bf16_launch(stream, ws, NS, KS, L);
+            L.first_begin = 0;
+            L.range_len = chunk_len;
+            L.nranges = C;
+            L.r_limit = nr_pad;
+            L.tau_init = tau0;
+            L.sample = 0;
+            L.tau = tau;
+            ok = ok && bf16_launch(stream, ws, NS, KS, L);
+            if (!ok) throw Error(BMX_ERR_ARG, "kNN: unsupported padded dimension");
+            eps_k = 16.0 * NS;                                   // f32 accumulation over the concatenated K
+            eps_qr = 6.0;                                        // three product blocks, each <= 2 |q||r|
+            eps_split = 3.03 * 2.0 * 1.52587890625e-05;          // dropped ql.rl, qh.r3, q3.rh: 3.03 * 2^-16 * 2|q||r|
+        } else {
+            hipLaunchKernelGGL(knn_prep, dim3(cdiv(nr_pad, 256)), dim3(256), 0, stream, X, ref_rows, nr, nr_pad, d, KP,
+                               mean, 0, variant == 1 ? 1 : 0, pr, rn2, maxbits);
+            BMX_LAUNCH_CHECK();
+            hipLaunchKernelGGL(knn_prep, dim3(cdiv(nq_pad, 256)), dim3(256), 0, stream, Qs, qrs, nq, nq_pad, d, KP, mean,
+                               1, 0, pq, qn2, maxbits);
+            BMX_LAUNCH_CHECK();
+            TopkLaunch L{pq, pr, nqb, 0, S, 1, S, 0, nchunks, nullptr, cand, tau, variant, lds_pad};
+            if (seeded) L.seed_out = seed;
+            bool ok = true;
+            if (S > 0) ok = KS == 24 ? dispatch_kp<24>(KP, stream, ws, L) : dispatch_kp<40>(KP, stream, ws, L);
+            L.first_begin = S;
+            L.range_len = chunk_len;
+            L.nranges = C;
+            L.r_limit = nr_pad;
+            L.out_chunk0 = S > 0 && !seeded ? 1 : 0;
+            L.tau_init = S > 0 && !seeded ? tau : nullptr;  // column 0 of tau[q][nchunks]: read with stride nchunks
+            L.seed_in = seed;
+            L.seed_out = nullptr;
+            ok = ok && (KS == 24 ? dispatch_kp<24>(KP, stream, ws, L) : dispatch_kp<40>(KP, stream, ws, L));
+            if (!ok) throw Error(BMX_ERR_ARG, "kNN: unsupported padded dimension");
+            eps_k = KP;
+            eps_qr = 2.0;
+            eps_split = 0.0;
         }
-        bool ok = true;
-        if (S > 0) ok = KS == 24 ? dispatch_kp<24>(KP, stream, ws, L) : dispatch_kp<40>(KP, stream, ws, L);
-        L.first_begin = S;
-        L.range_len = chunk_len;
-        L.nranges = C;
-        L.r_limit = nr_pad;
-        L.out_chunk0 = S > 0 && variant != 1 ? 1 : 0;
-        L.tau_init = S > 0 && variant != 1 ? tau : nullptr;  // column 0 of tau[q][nchunks]: read with stride nchunks
-        L.seed_in = seed;
-        L.seed_out = nullptr;
-        ok = ok && (KS == 24 ? dispatch_kp<24>(KP, stream, ws, L) : dispatch_kp<40>(KP, stream, ws, L));
-        if (!ok) throw Error(BMX_ERR_ARG, "kNN: unsupported padded dimension");
 
         hipLaunchKernelGGL(knn_refine, dim3(cdiv(nq, 4)), dim3(256), 0, stream, X, ref_rows, Qs, qrs, nq, d, k, KS,
-                           nchunks, KP, cand, tau, qn2, maxbits, io, dout, flagged);
+                           nchunks, eps_k, eps_qr, eps_split, cand, tau, qn2, maxbits, io, dout, flagged);
         BMX_LAUNCH_CHECK();
     }
 
-    // exact path: flagged queries, or everything when the MFMA path does not apply
+    // exact path: flagged queries, or everything when the MFMA path does not apply.  The number of flagged queries
+    // decides the launch shape, so it is read back here (one small synchronisation per search).
     {
-        size_t budget = (size_t)512 << 20;
-        int blocks = (int)std::min<size_t>(256, std::max<size_t>(8, budget / ((size_t)nr * 8)));
-        blocks = std::min(blocks, std::max(1, nq));
-        double* drow = ws.drow.reserve((size_t)blocks * nr);
-        hipLaunchKernelGGL(knn_exact, dim3(blocks), dim3(256), 0, stream, X, ref_rows, nr, Qs, qrs, nq, d, k, flagged,
-                           use_mfma ? 0 : 1, drow, io, dout);
-        BMX_LAUNCH_CHECK();
+        int count = nq;
+        if (use_mfma) {
+            int32_t h = 0;
+            BMX_HIP(hipMemcpyAsync(&h, flagged, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+            BMX_HIP(hipStreamSynchronize(stream));
+            count = h;
+        }
+        if (count > 0) {
+            const size_t budget = (size_t)512 << 20;
+            const int batch = (int)std::min<size_t>(std::max<size_t>(1, budget / ((size_t)nr * 8)), (size_t)count);
+            double* drow = ws.drow.reserve((size_t)batch * nr);
+            for (int f0 = 0; f0 < count; f0 += batch) {
+                const int nb = std::min(batch, count - f0);
+                hipLaunchKernelGGL(knn_exact_dist, dim3(cdiv(nr, 256), nb), dim3(256), 0, stream, X, ref_rows, nr, Qs, qrs,
+                                   d, use_mfma ? flagged : nullptr, f0, drow);
+                BMX_LAUNCH_CHECK();
+                hipLaunchKernelGGL(knn_exact_select, dim3(nb), dim3(256), 0, stream, drow, nr, k,
+                                   use_mfma ? flagged : nullptr, f0, io, dout);
+                BMX_LAUNCH_CHECK();
+            }
+        }
     }
     if (ws.flag_total && use_mfma) {
         hipLaunchKernelGGL(accumulate_flagged, dim3(1), dim3(64), 0, stream, flagged, ws.flag_total);

@@ -1,0 +1,379 @@
+// Split-bf16 candidate pass for the exact kNN (MI355X / gfx950).
+//
+// The f32-input MFMA runs at 1/16 of the bf16 rate, and the candidate pass only has to be accurate enough for the
+// FP64 certificate of knn_refine to hold.  So the f32 operands are split into bf16 pieces,
+//     r = rh + rl (+ 2^-16),   q' = -2q = qh + ql (+ 2^-16),
+// and ONE v_mfma_f32_32x32x16_bf16 chain over the concatenated K = [qh|qh|ql|1 1 1] . [rh|rl|rh|n1 n2 n3] yields
+//     v = |r|^2 + qh.rh + qh.rl + ql.rh        (|r|^2 as three bf16 pieces: exact to 2^-24)
+// with |v - (|r|^2 - 2 q.r)| <= 3.03 * 2^-16 * 2 |q||r| + f32 accumulation error -- the bound knn_refine certifies
+// against.  10 MFMAs of 32 cycles per 32x32 tile at 50 PCs instead of 28 of 64 cycles.
+//
+// At that rate the matrix pipe is no longer the limit; staging and selection are.  Structure of a workgroup:
+//   * NCONS consumer waves, 32 queries each: query fragments resident in VGPRs, selection state in LDS
+//     (knn_select.hpp), exactly as in the f32 kernel;
+//   * 4 producer waves stream the reference tiles (fragment-major, 1 KiB coalesced reads, two tiles in flight per
+//     producer) into a 4-slot LDS ring shared by all consumers -- one read of the reference set per 32*NCONS queries;
+//   * no s_barrier in the main loop: slots are handed over through LDS words (ready[slot] = tile number + 1,
+//     done[slot] += 1 per consumer), which the in-order LDS queue of each wave makes safe without extra waits.
+//     A consumer that is busy compacting a candidate buffer therefore delays nobody until the ring runs dry.
+#include "bmx_common.hpp"
+#include "knn_select.hpp"
+
+#include <cmath>
+
+namespace bmx {
+namespace {
+
+using namespace sel;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int NPROD = 4;  // producer waves == ring slots: producer p owns slot p and stages tiles p, p+4, ...
+
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7F800000u) == 0x7F800000u) return (uint16_t)(u >> 16);  // inf / nan pass through
+    u += 0x7FFFu + ((u >> 16) & 1u);                                   // round to nearest even
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
+
+// logical element L of a prepared row -> position inside the fragment-major reference tile
+__device__ __forceinline__ int64_t frag_pos(int r, int L, int NS) {
+    const int hk = 8 * NS;  // elements per lane half
+    const int h = L / hk, s = (L % hk) >> 3, j = L & 7;
+    return ((((int64_t)(r >> 5) * NS + s) * 64 + h * 32 + (r & 31)) << 3) + j;
+}
+
+__global__ void knn_prep_bf16(const double* __restrict__ X, const int32_t* __restrict__ rows, int n, int n_pad, int d,
+                              int NS, const double* __restrict__ mean, int is_query, uint16_t* __restrict__ P,
+                              double* __restrict__ n2, unsigned long long* __restrict__ max_n2_bits) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_pad) return;
+    const int K = 16 * NS;
+    auto put = [&](int L, uint16_t v) {
+        if (is_query)
+            P[(int64_t)r * K + L] = v;
+        else
+            P[frag_pos(r, L, NS)] = v;
+    };
+    for (int L = 0; L < K; ++L) put(L, 0);
+    if (r >= n) {
+        if (!is_query) put(3 * d, 0x7F80);  // +inf in the norm column: a padded reference never passes a threshold
+        return;
+    }
+    const int64_t row = rows ? rows[r] : r;
+    const double* x = X + row * d;
+    double s = 0.0;
+    for (int c = 0; c < d; ++c) {
+        const float f = (float)(x[c] - mean[c]);
+        s += (double)f * (double)f;
+        const float g = is_query ? -2.f * f : f;
+        const uint16_t hi = f32_to_bf16(g);
+        const uint16_t lo = f32_to_bf16(g - bf16_to_f32(hi));
+        if (is_query) {
+            put(c, hi);
+            put(d + c, hi);
+            put(2 * d + c, lo);
+        } else {
+            put(c, hi);
+            put(d + c, lo);
+            put(2 * d + c, hi);
+        }
+    }
+    if (is_query) {
+        put(3 * d, 0x3F80);  // 1.0
+        put(3 * d + 1, 0x3F80);
+        put(3 * d + 2, 0x3F80);
+    } else {
+        const float nf = (float)s;  // what the f32 kernel would add; its three bf16 pieces reproduce it exactly
+        const uint16_t a = f32_to_bf16(nf);
+        const float r1 = nf - bf16_to_f32(a);
+        const uint16_t b = f32_to_bf16(r1);
+        const uint16_t c3 = f32_to_bf16(r1 - bf16_to_f32(b));
+        put(3 * d, a);
+        put(3 * d + 1, b);
+        put(3 * d + 2, c3);
+    }
+    n2[r] = s;
+    if (!is_query) atomicMax(max_n2_bits, (unsigned long long)__double_as_longlong(s));
+}
+
+__device__ __forceinline__ int lds_load_volatile(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// SAMPLE = true: threshold estimation only.  Each (tile, lane-half) contributes the minimum of its 16 values as ONE
+// candidate; the KS-th smallest of these group minima bounds the KS-th nearest reference from above (they are KS
+// distinct references), so it is a valid starting threshold for the full pass.  Nothing else is kept: the full pass
+// rescans the sample rows.  Output: tau_out[q].  SAMPLE = false: the full pass, starting from tau_init[q].
+template <int NS, int KS, int NCONS, bool SAMPLE>
+__global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
+    const uint16_t* __restrict__ Pq, const uint16_t* __restrict__ PrF, int first_begin, int range_len, int r_limit,
+    int out_chunk0, int out_nchunks, const float* __restrict__ tau_init, int32_t* __restrict__ cand,
+    float* __restrict__ tau_out) {
+    constexpr int CAP = KS + 2 * PL;
+    constexpr int NQ = NCONS * 32;
+    constexpr int TILE_BYTES = NS * 1024;
+    static_assert(CAP <= 64, "one candidate per lane during compaction");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring = smem;                                                                        // [NPROD][TILE_BYTES]
+    unsigned long long* buf = reinterpret_cast<unsigned long long*>(smem + NPROD * TILE_BYTES);  // [NQ][CAP]
+    int* kcnt = reinterpret_cast<int*>(buf + NQ * CAP);                                       // [NQ]
+    float* tau_s = reinterpret_cast<float*>(kcnt + NQ);                                       // [NQ]
+    int* ready = reinterpret_cast<int*>(tau_s + NQ);                                          // [NPROD]
+    int* done = ready + NPROD;                                                                // [NPROD]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r_begin = first_begin + blockIdx.y * range_len;
+    const int r_end = min(r_limit, r_begin + range_len);
+    const int ntiles = (r_end - r_begin) >> 5;
+    const int out_chunk = out_chunk0 + blockIdx.y;
+    if (tid < 2 * NPROD) ready[tid] = 0;  // ready[] and done[] are contiguous
+    __syncthreads();
+
+    if (wave >= NCONS) {
+        // ------------------------------------------------------------------ producer
+        const int p = wave - NCONS;
+        f32x4 ra[NS], rb[NS];
+        const f32x4* src = reinterpret_cast<const f32x4*>(PrF) + ((int64_t)(r_begin >> 5) * NS) * 64 + lane;
+        f32x4* dst = reinterpret_cast<f32x4*>(ring + p * TILE_BYTES) + lane;
+        auto load = [&](f32x4 (&r)[NS], int t) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) r[s] = src[((int64_t)t * NS + s) * 64];
+        };
+        auto publish = [&](const f32x4 (&r)[NS], int t) {
+            const int uses = t / NPROD;  // earlier tiles staged in this slot
+            while (lds_load_volatile(&done[p]) < NCONS * uses) __builtin_amdgcn_s_sleep(1);
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) dst[s * 64] = r[s];
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            // same wave, in-order LDS queue: the flag lands after the tile
+            if (lane == 0) __hip_atomic_store(&ready[p], t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        // three register sets: the loads of tiles t + 4 and t + 8 are in flight while tile t is handed over
+        f32x4 rc[NS];
+        int t = p;
+        if (t < ntiles) load(ra, t);
+        if (t + NPROD < ntiles) load(rb, t + NPROD);
+        for (; t < ntiles; t += 3 * NPROD) {
+            if (t + 2 * NPROD < ntiles) load(rc, t + 2 * NPROD);
+            publish(ra, t);
+            if (t + NPROD < ntiles) {
+                if (t + 3 * NPROD < ntiles) load(ra, t + 3 * NPROD);
+                publish(rb, t + NPROD);
+            }
+            if (t + 2 * NPROD < ntiles) {
+                if (t + 4 * NPROD < ntiles) load(rb, t + 4 * NPROD);
+                publish(rc, t + 2 * NPROD);
+            }
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumer
+    const int j = lane & 31, h = lane >> 5;
+    const int qs = wave * 32 + j;
+    const int q = blockIdx.x * NQ + qs;
+
+    float tau = (!SAMPLE && tau_init) ? tau_init[q] : __builtin_inff();
+    if (h == 0) {
+        kcnt[qs] = 0;
+        tau_s[qs] = tau;
+    }
+
+    bf16x8 bq[NS];
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(Pq + (int64_t)q * (16 * NS) + h * (8 * NS));
+#pragma unroll
+        for (int s = 0; s < NS; ++s) bq[s] = __builtin_bit_cast(bf16x8, src[s]);
+    }
+
+    unsigned long long* pend = buf + qs * CAP + KS + h * PL;
+    int mycnt = 0;
+
+    // fetch(t): wait until tile t sits in its slot, issue its fragment reads, hand the slot back.  The hand-back is
+    // queued behind the reads in this wave's in-order LDS queue, so the producer cannot overwrite them early.
+    auto fetch = [&](f32x4 (&a)[NS], int t) {
+        const int slot = t & (NPROD - 1);
+        while (lds_load_volatile(&ready[slot]) < t + 1) __builtin_amdgcn_s_sleep(1);
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        const f32x4* tp = reinterpret_cast<const f32x4*>(ring + slot * TILE_BYTES) + lane;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) a[s] = tp[s * 64];
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        if (lane == 0) __hip_atomic_fetch_add(&done[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+
+    f32x4 a0[NS], a1[NS];
+    if (ntiles > 0) fetch(a0, 0);
+    for (int t2 = 0; t2 < ntiles; t2 += 2) {
+      // two tiles per iteration so that the fragment registers ping-pong statically; tile t + 1 is fetched before
+      // tile t computes
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int t = t2 + half;
+        if (t >= ntiles) break;
+        if (t + 1 < ntiles) {
+            if (half == 0)
+                fetch(a1, t + 1);
+            else
+                fetch(a0, t + 1);
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, half == 0 ? a0[s] : a1[s]), bq[s],
+                                                          acc, 0, 0, 0);
+
+        const int r0 = r_begin + (t << 5);
+#ifdef BMX_ABLATE_SELECT
+#pragma unroll
+        for (int e = 0; e < 16; ++e) asm volatile("" ::"v"(acc[e]));
+#else
+        // group minima (4 registers each), then the lane minimum: the common case leaves after ~12 VALU instructions
+        float g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            g[u] = fminf(fminf(acc[4 * u], acc[4 * u + 1]), fminf(acc[4 * u + 2], acc[4 * u + 3]));
+        const float mn = fminf(fminf(g[0], g[1]), fminf(g[2], g[3]));
+        if (__builtin_amdgcn_ballot_w64(mn < tau) == 0) continue;
+        auto flush_full = [&]() {
+            unsigned long long fm = __builtin_amdgcn_ballot_w64(mycnt >= PL);
+            if (fm) {
+                fm = (fm | (fm >> 32)) & 0xFFFFFFFFull;
+                while (fm) {
+                    const int jj = __builtin_ctzll(fm);
+                    fm &= fm - 1;
+                    compact_slot<KS>(buf, kcnt, tau_s, wave * 32 + jj, jj, lane, mycnt);
+                }
+                tau = tau_s[qs];
+            }
+        };
+        if constexpr (SAMPLE) {
+            if (mn < tau) {
+                pend[mycnt] = ((unsigned long long)f32_orderable(mn) << 32) | (uint32_t)(r0 + 4 * h);
+                ++mycnt;
+            }
+            flush_full();
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (__builtin_amdgcn_ballot_w64(g[u] < tau) == 0) continue;
+#pragma unroll
+                for (int e = 4 * u; e < 4 * u + 4; ++e) {
+                    const float v = acc[e];
+                    const bool pass = v < tau;
+                    if (__builtin_amdgcn_ballot_w64(pass) == 0) continue;
+                    if (pass) {
+                        const int ridx = r0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        pend[mycnt] = ((unsigned long long)f32_orderable(v) << 32) | (uint32_t)ridx;
+                        ++mycnt;
+                    }
+                    flush_full();
+                }
+            }
+        }
+#endif
+      }
+    }
+
+    for (int jj = 0; jj < 32; ++jj) compact_slot<KS>(buf, kcnt, tau_s, wave * 32 + jj, jj, lane, mycnt);
+    if constexpr (SAMPLE) {
+        if (h == 0) tau_out[q] = tau_s[qs];
+        return;
+    }
+    for (int jj = 0; jj < 32; ++jj) {
+        const int s = wave * 32 + jj;
+        const int qq = blockIdx.x * NQ + s;
+        const int n = kcnt[s];
+        if (lane < KS) {
+            const unsigned long long key = buf[s * CAP + lane];
+            cand[((int64_t)qq * out_nchunks + out_chunk) * KS + lane] = lane < n ? (int32_t)(uint32_t)key : -1;
+        }
+        if (lane == 0) tau_out[(int64_t)qq * out_nchunks + out_chunk] = tau_s[s];
+    }
+}
+
+template <int NS, int KS, int NCONS>
+void launch(hipStream_t stream, KnnWorkspace& ws, const Bf16Launch& L) {
+    constexpr size_t lds = (size_t)NPROD * NS * 1024 + (size_t)NCONS * 32 * (KS + 2 * PL) * 8 + NCONS * 32 * 8 + 64;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static bool attr_set = false;
+    if (!attr_set) {
+        BMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_topk_bf16<NS, KS, NCONS, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        BMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_topk_bf16<NS, KS, NCONS, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    if (ws.profile) {
+        ev = ws.next_events();
+        BMX_HIP(hipEventRecord(ev.first, stream));
+    }
+    if (L.sample)
+        hipLaunchKernelGGL((knn_topk_bf16<NS, KS, NCONS, true>), dim3(L.nqb, L.nranges), dim3((NCONS + NPROD) * 64),
+                           lds, stream, L.pq, L.pr, L.first_begin, L.range_len, L.r_limit, L.out_chunk0, L.out_nchunks,
+                           L.tau_init, L.cand, L.tau);
+    else
+        hipLaunchKernelGGL((knn_topk_bf16<NS, KS, NCONS, false>), dim3(L.nqb, L.nranges), dim3((NCONS + NPROD) * 64),
+                           lds, stream, L.pq, L.pr, L.first_begin, L.range_len, L.r_limit, L.out_chunk0, L.out_nchunks,
+                           L.tau_init, L.cand, L.tau);
+    BMX_LAUNCH_CHECK();
+    if (ws.profile) BMX_HIP(hipEventRecord(ev.second, stream));
+}
+
+}  // namespace
+
+int bf16_pick_ns(int d) {
+    static const int opts[] = {1, 2, 3, 4, 6, 8, 10, 13, 16, 19, 24};
+    for (int o : opts)
+        if (3 * d + 3 <= 16 * o) return o;
+    return 0;
+}
+
+int bf16_ncons(int NS, int KS) { return (NS <= 10 && KS == 24) ? 8 : 4; }
+
+void bf16_prep(hipStream_t stream, const double* X, const int32_t* rows, int n, int n_pad, int d, int NS,
+               const double* mean, int is_query, uint16_t* P, double* n2, unsigned long long* maxbits) {
+    hipLaunchKernelGGL(knn_prep_bf16, dim3(cdiv(n_pad, 256)), dim3(256), 0, stream, X, rows, n, n_pad, d, NS, mean,
+                       is_query, P, n2, maxbits);
+    BMX_LAUNCH_CHECK();
+}
+
+bool bf16_launch(hipStream_t stream, KnnWorkspace& ws, int NS, int KS, const Bf16Launch& L) {
+#define BMX_CASE(N)                                                \
+    case N:                                                        \
+        if (KS == 24) {                                            \
+            if constexpr (N <= 10)                                 \
+                launch<N, 24, 8>(stream, ws, L);                   \
+            else                                                   \
+                launch<N, 24, 4>(stream, ws, L);                   \
+        } else {                                                   \
+            if constexpr (N <= 16)                                 \
+                launch<N, 40, 4>(stream, ws, L);                   \
+            else                                                   \
+                return false;                                      \
+        }                                                          \
+        return true;
+    switch (NS) {
+        BMX_CASE(1)
+        BMX_CASE(2)
+        BMX_CASE(3)
+        BMX_CASE(4)
+        BMX_CASE(6)
+        BMX_CASE(8)
+        BMX_CASE(10)
+        BMX_CASE(13)
+        BMX_CASE(16)
+        BMX_CASE(19)
+        BMX_CASE(24)
+        default:
+            return false;
+    }
+#undef BMX_CASE
+}
+
+}  // namespace bmx

@@ -1,0 +1,57 @@
+// Selection machinery shared by the MFMA top-k kernels (f32 and split-bf16 candidate passes).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace bmx {
+namespace sel {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t f32_orderable(float v) {
+    uint32_t u = __float_as_uint(v);
+    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float orderable_f32(uint32_t o) {
+    uint32_t u = o ^ ((o >> 31) ? 0x80000000u : 0xFFFFFFFFu);
+    return __uint_as_float(u);
+}
+
+// Per query slot the LDS holds KS "kept" entries (sorted, shared by the two lanes that own the query's two K-halves)
+// followed by two lane-private pending lists of PL entries each: a lane appends with a plain ds_write (no atomics, no
+// returned value to wait for).  When a pending list fills, one wave merges kept + both pending lists by rank-counting
+// over the unique 64-bit keys (orderable value << 32 | reference index), keeps the KS smallest and tightens tau.
+constexpr int PL = 12;
+
+template <int KS>
+__device__ __forceinline__ void compact_slot(unsigned long long* buf, int* kcnt, float* tau_s, int slot, int jj,
+                                             int lane, int& mycnt) {
+    constexpr int CAP = KS + 2 * PL;
+    const int nk = kcnt[slot];
+    const int n0 = __builtin_amdgcn_readlane(mycnt, jj);
+    const int n1 = __builtin_amdgcn_readlane(mycnt, jj + 32);
+    const int n = nk + n0 + n1;
+    unsigned long long* b = buf + slot * CAP;
+    int src = lane;  // kept entries sit at [0, nk)
+    if (lane >= nk) src = lane < nk + n0 ? KS + (lane - nk) : KS + PL + (lane - nk - n0);
+    const unsigned long long key = lane < n ? b[src] : ~0ull;
+    const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
+    int rank = 0;
+    for (int f = 0; f < n; ++f) {
+        const uint32_t flo = __builtin_amdgcn_readlane(klo, f);
+        const uint32_t fhi = __builtin_amdgcn_readlane(khi, f);
+        const unsigned long long fk = ((unsigned long long)fhi << 32) | flo;
+        rank += fk < key ? 1 : 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // every lane holds its key before slots are rewritten
+    if (lane < n && rank < KS) b[rank] = key;
+    if (n >= KS && lane < n && rank == KS - 1) tau_s[slot] = orderable_f32(khi);
+    if (lane == 0) kcnt[slot] = n < KS ? n : KS;
+    if (lane == jj || lane == jj + 32) mycnt = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+}  // namespace sel
+}  // namespace bmx

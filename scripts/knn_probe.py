@@ -6,6 +6,7 @@ from tests.conftest import synth_batches
 from batchelor_amd import neighbors as nb
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 d = int(sys.argv[2]) if len(sys.argv) > 2 else 50
-X, Q = synth_batches(2, [n, n], d)
+nref = int(sys.argv[3]) if len(sys.argv) > 3 else n
+X, Q = synth_batches(2, [nref, n], d)
 for it in range(3):
     t = time.time(); idx, dist = nb.query_knn(X, Q, 20); print("wall", time.time() - t, "fallbacks", nb.last_knn_exact_fallbacks(), flush=True)
