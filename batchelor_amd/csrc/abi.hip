@@ -446,6 +446,8 @@ int32_t bmx_engine_profile(bmx_engine_t* e, double* topk_ms, int64_t* topk_launc
     return guarded([&] { e->impl->profile(topk_ms, topk_launches, exact_fallbacks); });
 }
 
+int32_t bmx_engine_knn_variant(bmx_engine_t* e) { return e && e->impl ? e->impl->knn_ws_.last_variant : -1; }
+
 int32_t bmx_fast_mnn(int32_t nbatches, int32_t d, const double* const* data, const int32_t* nrows,
                      const int32_t* const* restrict_idx, const int32_t* n_restrict, const bmx_params_t* params,
                      const int32_t* tree, int32_t tree_len, double* corrected, int32_t* batch, int32_t* merge_left,

@@ -71,11 +71,14 @@ struct KnnWorkspace {
     DevBuf<uint64_t> seed;         // [nq][KS + 1] kept list of the sample range (wave-per-workgroup kernel)
     DevBuf<int32_t> flagged;       // [nq + 1] compact list of queries needing the exact path (+ counter)
     DevBuf<double> drow;           // exact-path distance rows
+    DevBuf<double> flag_bound, xd; // k-th candidate distance of flagged queries; short exact lists
+    DevBuf<int32_t> xcnt, xi, slow;
     DevBuf<int32_t> idx_tmp;
     DevBuf<double> dist_tmp;
     int64_t last_flagged = 0;      // diagnostics: queries that took the exact path in the last call
     int force_exact = 0;           // testing hook: route every query through the exact path
     // profiling: when on, every launch of the MFMA top-k kernel is bracketed by an event pair from this pool
+    int last_variant = -1;  // candidate-pass variant used by the last MFMA-path search (2 bf16 ring, 1 f32 wave, 0 f32 LDS)
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;

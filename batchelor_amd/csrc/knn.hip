@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256) void knn_refine(const double* __restrict__ X, 
                                                   const double* __restrict__ qn2,
                                                   const unsigned long long* __restrict__ max_rn2_bits,
                                                   int32_t* __restrict__ idx_out, double* __restrict__ dist_out,
-                                                  int32_t* __restrict__ flagged) {
+                                                  int32_t* __restrict__ flagged, double* __restrict__ flag_bound) {
     __shared__ double sd[4][REFINE_MAXM];
     __shared__ int si[4][REFINE_MAXM];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -512,6 +512,7 @@ __global__ __launch_bounds__(256) void knn_refine(const double* __restrict__ X, 
         if (!proven) {
             const int pos = atomicAdd(&flagged[0], 1);
             flagged[1 + pos] = q;
+            flag_bound[pos] = kth;  // the true k-th neighbour is no farther than the k-th candidate
         }
     }
 }
@@ -572,6 +573,87 @@ __global__ __launch_bounds__(256) void knn_exact_select(const double* __restrict
             if (dist_out) dist_out[(int64_t)q * k + jdx] = sqrt(last_d);
         }
         __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 4b. fast exact path for a FEW flagged queries: the k-th candidate distance bounds the true k-th neighbour from
+//     above, so one pass that stages each reference tile once in LDS, evaluates it against every flagged query in
+//     FP64 and keeps the references within that bound (a handful per query) replaces the full per-query rescan.
+//     A query whose list overflows (massive exact ties) is handed to the full scan.
+// ---------------------------------------------------------------------------------------------------
+constexpr int XF_TILE = 64;    // reference rows per staged tile
+constexpr int XF_CAP = 256;    // kept references per flagged query
+
+__global__ __launch_bounds__(256) void knn_exact_filter(const double* __restrict__ X,
+                                                        const int32_t* __restrict__ ref_rows, int nr,
+                                                        const double* __restrict__ Q,
+                                                        const int32_t* __restrict__ q_rows, int d,
+                                                        const int32_t* __restrict__ flagged,
+                                                        const double* __restrict__ flag_bound, int nflag,
+                                                        int32_t* __restrict__ xcnt, double* __restrict__ xd,
+                                                        int32_t* __restrict__ xi) {
+    extern __shared__ __attribute__((aligned(16))) char smem_x[];
+    double* xs = reinterpret_cast<double*>(smem_x);  // [XF_TILE][d + 1]  (+1: breaks the bank stride)
+    const int ld = d + 1;
+    const int tid = threadIdx.x;
+    const int r0 = blockIdx.x * XF_TILE;
+    const int rows_here = min(XF_TILE, nr - r0);
+    for (int e = tid; e < rows_here * d; e += 256) {
+        const int rr = e / d, c = e - rr * d;
+        const int64_t row = ref_rows ? ref_rows[r0 + rr] : r0 + rr;
+        xs[rr * ld + c] = X[row * d + c];
+    }
+    __syncthreads();
+    const int rr = tid & (XF_TILE - 1);
+    if (rr >= rows_here) return;
+    const double* xr = xs + rr * ld;
+    for (int f = tid / XF_TILE; f < nflag; f += 256 / XF_TILE) {
+        const int q = flagged[1 + f];
+        const double* qv = Q + (int64_t)(q_rows ? q_rows[q] : q) * d;
+        double s = 0.0;
+        for (int c = 0; c < d; ++c) {
+            const double t = qv[c] - xr[c];
+            s += t * t;
+        }
+        if (s <= flag_bound[f]) {
+            const int pos = atomicAdd(&xcnt[f], 1);
+            if (pos < XF_CAP) {
+                xd[(int64_t)f * XF_CAP + pos] = s;
+                xi[(int64_t)f * XF_CAP + pos] = r0 + rr;
+            }
+        }
+    }
+}
+
+// one wave per flagged query: exact (distance, index) ranking of its short list; overflowed lists go to `slow`
+__global__ __launch_bounds__(256) void knn_exact_pick(const int32_t* __restrict__ flagged, int nflag, int k,
+                                                      const int32_t* __restrict__ xcnt, const double* __restrict__ xd,
+                                                      const int32_t* __restrict__ xi, int32_t* __restrict__ idx_out,
+                                                      double* __restrict__ dist_out, int32_t* __restrict__ slow) {
+    const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (f >= nflag) return;
+    const int q = flagged[1 + f];
+    const int n = xcnt[f];
+    if (n > XF_CAP || n < k) {  // n < k cannot happen (the k candidates themselves qualify); belt and braces
+        if (lane == 0) {
+            const int pos = atomicAdd(&slow[0], 1);
+            slow[1 + pos] = q;
+        }
+        return;
+    }
+    const double* dd = xd + (int64_t)f * XF_CAP;
+    const int32_t* ii = xi + (int64_t)f * XF_CAP;
+    for (int m = lane; m < n; m += 64) {
+        const double dm = dd[m];
+        const int im = ii[m];
+        int rank = 0;
+        for (int t = 0; t < n; ++t) rank += key_less(dd[t], ii[t], dm, im) ? 1 : 0;
+        if (rank < k) {
+            idx_out[(int64_t)q * k + rank] = im;
+            if (dist_out) dist_out[(int64_t)q * k + rank] = sqrt(dm);
+        }
     }
 }
 
@@ -705,6 +787,7 @@ void knn_device(hipStream_t stream, KnnWorkspace& ws, const double* X, const int
         const int NS = bf16_pick_ns(d);
         int variant = requested;
         if (variant == 2 && (NS == 0 || (KS == 40 && NS > 16))) variant = 1;
+        ws.last_variant = variant;
         const int ncons = variant == 2 ? bf16_ncons(NS, KS) : 0;
         const int unit = variant == 2 ? 32 * ncons : (variant == 1 ? 32 : QB);  // queries per workgroup
         const int nq_pad = (int)round_up(nq, 256);
@@ -833,7 +916,8 @@ void knn_device(hipStream_t stream, KnnWorkspace& ws, const double* X, const int
         }
 
         hipLaunchKernelGGL(knn_refine, dim3(cdiv(nq, 4)), dim3(256), 0, stream, X, ref_rows, Qs, qrs, nq, d, k, KS,
-                           nchunks, eps_k, eps_qr, eps_split, cand, tau, qn2, maxbits, io, dout, flagged);
+                           nchunks, eps_k, eps_qr, eps_split, cand, tau, qn2, maxbits, io, dout, flagged,
+                           ws.flag_bound.reserve((size_t)nq + 1));
         BMX_LAUNCH_CHECK();
     }
 
@@ -847,6 +931,28 @@ void knn_device(hipStream_t stream, KnnWorkspace& ws, const double* X, const int
             BMX_HIP(hipStreamSynchronize(stream));
             count = h;
         }
+        const int32_t* scan_list = use_mfma ? flagged : nullptr;
+        if (count > 0 && use_mfma) {
+            // few flagged queries: bounded filter pass, then rank the short lists; overflows fall through
+            int32_t* xcnt = ws.xcnt.reserve((size_t)count);
+            double* xd = ws.xd.reserve((size_t)count * XF_CAP);
+            int32_t* xi = ws.xi.reserve((size_t)count * XF_CAP);
+            int32_t* slow = ws.slow.reserve((size_t)count + 1);
+            BMX_HIP(hipMemsetAsync(xcnt, 0, (size_t)count * sizeof(int32_t), stream));
+            BMX_HIP(hipMemsetAsync(slow, 0, sizeof(int32_t), stream));
+            const size_t lds = (size_t)XF_TILE * (d + 1) * sizeof(double);
+            hipLaunchKernelGGL(knn_exact_filter, dim3(cdiv(nr, XF_TILE)), dim3(256), lds, stream, X, ref_rows, nr, Qs, qrs,
+                               d, flagged, ws.flag_bound.p, count, xcnt, xd, xi);
+            BMX_LAUNCH_CHECK();
+            hipLaunchKernelGGL(knn_exact_pick, dim3(cdiv(count, 4)), dim3(256), 0, stream, flagged, count, k, xcnt, xd, xi,
+                               io, dout, slow);
+            BMX_LAUNCH_CHECK();
+            int32_t h = 0;
+            BMX_HIP(hipMemcpyAsync(&h, slow, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+            BMX_HIP(hipStreamSynchronize(stream));
+            count = h;
+            scan_list = slow;
+        }
         if (count > 0) {
             const size_t budget = (size_t)512 << 20;
             const int batch = (int)std::min<size_t>(std::max<size_t>(1, budget / ((size_t)nr * 8)), (size_t)count);
@@ -854,10 +960,10 @@ void knn_device(hipStream_t stream, KnnWorkspace& ws, const double* X, const int
             for (int f0 = 0; f0 < count; f0 += batch) {
                 const int nb = std::min(batch, count - f0);
                 hipLaunchKernelGGL(knn_exact_dist, dim3(cdiv(nr, 256), nb), dim3(256), 0, stream, X, ref_rows, nr, Qs, qrs,
-                                   d, use_mfma ? flagged : nullptr, f0, drow);
+                                   d, scan_list, f0, drow);
                 BMX_LAUNCH_CHECK();
-                hipLaunchKernelGGL(knn_exact_select, dim3(nb), dim3(256), 0, stream, drow, nr, k,
-                                   use_mfma ? flagged : nullptr, f0, io, dout);
+                hipLaunchKernelGGL(knn_exact_select, dim3(nb), dim3(256), 0, stream, drow, nr, k, scan_list, f0, io,
+                                   dout);
                 BMX_LAUNCH_CHECK();
             }
         }

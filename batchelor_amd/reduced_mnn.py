@@ -131,7 +131,8 @@ class MnnEngine:
     def profile(self):
         ms, n, fb = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_int64(0)
         _lib.check(_lib.lib().bmx_engine_profile(self._h, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fb)))
-        return {"topk_ms": ms.value, "topk_launches": n.value, "exact_fallbacks": fb.value}
+        return {"topk_ms": ms.value, "topk_launches": n.value, "exact_fallbacks": fb.value,
+                "variant": int(_lib.lib().bmx_engine_knn_variant(self._h))}
 
     def merge_stats(self):
         out = []

@@ -26,14 +26,37 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)" (spec; 155 measured)
+# Dense MFMA peaks from /opt/skills/guides/MI355X_MICROARCH.md ("Chip-level parameters" / "Matrix cores")
+KERNELS = {
+    2: {"kernel": "knn_topk_bf16", "dtype": "bf16 MFMA (f32 operands split into 3 bf16 products) + FP64 exact re-rank",
+        "peak": 2500.0},
+    1: {"kernel": "knn_topk_w1", "dtype": "f32 MFMA + FP64 exact re-rank", "peak": 157.3},
+    0: {"kernel": "knn_topk_mfma", "dtype": "f32 MFMA + FP64 exact re-rank", "peak": 157.3},
+}
+
+def _config5_sizes():
+    """16 batch sizes, log-uniform in [5 000, 500 000], fixed by the seed."""
+    rng = np.random.Generator(np.random.PCG64(20250314 + 5000))
+    return [int(x) for x in np.exp(rng.uniform(np.log(5e3), np.log(5e5), 16))]
+
+
+def _balanced_tree(ids):
+    """Balanced nested merge.order over the given (1-based) batch ids."""
+    if len(ids) == 1:
+        return ids[0]
+    h = len(ids) // 2
+    return [_balanced_tree(ids[:h]), _balanced_tree(ids[h:])]
+
 
 WORKLOADS = {
-    # name: (config id for the seeds, batch sizes, d, k)
-    "config2": (2, [100000, 100000], 50, 20),
-    "config3": (3, [100000] * 8, 50, 20),
-    "config1": (1, [2000, 2000], 50, 20),
+    # name: (config id for the seeds, batch sizes, d, k, merge tree or None for 1..B)
+    "config2": (2, [100000, 100000], 50, 20, None),
+    "config3": (3, [100000] * 8, 50, 20, None),
+    "config1": (1, [2000, 2000], 50, 20, None),
 }
+_s5 = _config5_sizes()
+# config 5: balanced tree over the size-sorted batches (largest first so the biggest batch is a reference leaf)
+WORKLOADS["config5"] = (5, _s5, 100, 20, _balanced_tree([i + 1 for i in np.argsort(_s5)[::-1]]))
 
 
 def synth_batches(config, sizes, d, shift=1.0):
@@ -119,7 +142,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    cfg, sizes, d, k = WORKLOADS[args.workload]
+    cfg, sizes, d, k, tree = WORKLOADS[args.workload]
     batches = synth_batches(cfg, sizes, d)
     n_cells = int(sum(sizes))
 
@@ -133,14 +156,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if tree is not None:
+        from batchelor_amd.merge_tree import resolve_merge_order
+        tree = resolve_merge_order(len(sizes), tree)
     for _ in range(args.warmup):
-        eng.run(k=k)
+        eng.run(k=k, merge_tree=tree)
     eng.set_profiling(True)
     barrier()
     t0 = time.perf_counter()
     topk_ms, topk_launches = 0.0, 0
     for _ in range(args.steps):
-        eng.run(k=k)  # returns after the engine's stream has drained
+        eng.run(k=k, merge_tree=tree)  # returns after the engine's stream has drained
         p = eng.profile()
         topk_ms += p["topk_ms"]
         topk_launches += p["topk_launches"]
@@ -152,7 +178,9 @@ def main():
         elapsed = float(t.item())
 
     stats = eng.merge_stats()
-    fallbacks = eng.profile()["exact_fallbacks"]
+    prof = eng.profile()
+    fallbacks = prof["exact_fallbacks"]
+    kern = KERNELS.get(prof["variant"], KERNELS[2])
     if rank == 0:
         flops = algorithmic_flops(stats, d) / world  # this rank's share of the query rows
         achieved = flops * args.steps / (topk_ms * 1e-3) / 1e12 if topk_ms > 0 else 0.0
@@ -167,16 +195,19 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f64 (f32 MFMA candidate pass, FP64 exact re-rank)",
+            "dtype": kern["dtype"],
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {len(sizes)} synthetic Gaussian batches x {sizes[0]} cells x "
-                                   f"{d} PCs, k={k}, merge.order=1..{len(sizes)}, inputs resident in HBM",
+            "config": {"workload": f"{args.workload}: {len(sizes)} synthetic Gaussian batches x "
+                                   f"{sizes[0] if len(set(sizes)) == 1 else str(min(sizes)) + '..' + str(max(sizes))} "
+                                   f"cells x {d} PCs, k={k}, "
+                                   f"merge.order={'1..' + str(len(sizes)) if tree is None else 'balanced tree'}, "
+                                   "inputs resident in HBM",
                        "parallelism": "kNN query rows sharded over ranks, RCCL all-gather of neighbour lists"
                                       if world > 1 else "single GPU",
                        "mnn_pairs": [m["P"] for m in stats], "exact_fallback_queries": fallbacks},
             "roofline": {
-                "bound": "mfma", "kernel": "knn_topk_mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                "bound": "mfma", "kernel": kern["kernel"], "achieved": achieved, "peak": kern["peak"],
+                "unit": "TFLOP/s", "frac": achieved / kern["peak"], "traffic": None,
                 "launches_per_step": topk_launches / max(1, args.steps),
                 "avg_launch_ms": topk_ms / max(1, topk_launches),
                 "algorithmic_flops_per_step": flops,

@@ -125,6 +125,10 @@ int32_t bmx_engine_merge_stats(bmx_engine_t* e, int32_t merge, int64_t* out6);
  * stream; after a run: total milliseconds, number of launches, and queries that needed the exact re-scan. */
 int32_t bmx_engine_set_profiling(bmx_engine_t* e, int32_t on);
 int32_t bmx_engine_profile(bmx_engine_t* e, double* topk_ms, int64_t* topk_launches, int64_t* exact_fallbacks);
+/* Candidate-pass kernel used by the engine's last MFMA-path search: 2 = knn_topk_bf16 (split-bf16 MFMA, LDS ring),
+ * 1 = knn_topk_w1 (f32 MFMA, wave per workgroup), 0 = knn_topk_mfma (f32 MFMA, LDS staging), -1 = none yet.
+ * The environment variable BMX_TOPK_VARIANT selects it for A/B runs. */
+int32_t bmx_engine_knn_variant(bmx_engine_t* e);
 
 /* One-shot convenience (what the R shim calls): create + upload + run + download + pairs stay queryable on *out_engine
  * until bmx_engine_destroy. */

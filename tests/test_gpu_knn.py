@@ -59,3 +59,16 @@ def test_query_knn_large_k_uses_exact_scan(oracle, nb):
     idx, dist = nb.query_knn(X, Q, 80)
     oi, od = oracle.query_knn(X, Q, 80)
     assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+
+
+def test_query_knn_near_ties_take_the_bounded_exact_path(oracle, nb):
+    # clusters of 30 near-duplicates (1e-9 apart): the f32 / bf16 candidate pass cannot certify any of these queries,
+    # so all of them go through knn_exact_filter / knn_exact_pick and must still match the oracle bit for bit
+    rng = np.random.default_rng(5)
+    base = rng.standard_normal((150, 20))
+    X = np.repeat(base, 30, axis=0) + 1e-9 * rng.standard_normal((4500, 20))
+    Q = base[:64] + 1e-9 * rng.standard_normal((64, 20))
+    idx, dist = nb.query_knn(X, Q, 20)
+    oi, od = oracle.query_knn(X, Q, 20)
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+    assert nb.last_knn_exact_fallbacks() >= 32
