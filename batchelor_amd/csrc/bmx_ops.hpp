@@ -35,6 +35,10 @@ struct ReduceWorkspace {
 // out[c] = scale * sum.  Deterministic two-stage reduction.
 void col_reduce(hipStream_t stream, ReduceWorkspace& ws, const double* X, const int32_t* rows, int r0, int r1, int d,
                 int mode, const double* centre, double scale, double* out);
+// .compute_perbatch_var for all segments (row ranges [starts[i], starts[i] + ns[i])) of one node: the sum over dims of
+// the sample variance of segment i lands in out[i * out_stride].  Two-pass (mean, then squared deviations).
+void segment_variances(hipStream_t stream, ReduceWorkspace& ws, const double* X, int d, const int* starts,
+                       const int* ns, int nseg, double* out, int out_stride);
 // out[0] = scale * sum_c in[c]   (single thread; d is tiny)
 void sum_vector(hipStream_t stream, const double* in, int d, double scale, double* out);
 

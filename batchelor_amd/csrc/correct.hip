@@ -39,13 +39,83 @@ __global__ __launch_bounds__(256) void col_reduce_partial(const double* __restri
     }
 }
 
-__global__ void col_reduce_final(const double* __restrict__ partial, int nblocks, int d, double scale,
-                                 double* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= d) return;
+__global__ __launch_bounds__(256) void col_reduce_final(const double* __restrict__ partial, int nblocks, int d,
+                                                        double scale, double* __restrict__ out) {
+    // one workgroup; four thread groups share each column's partials, combined in a fixed order (deterministic)
+    __shared__ double sm[4][64];
+    const int c0 = threadIdx.x & 63, g = threadIdx.x >> 6;
+    for (int cb = 0; cb < d; cb += 64) {
+        const int c = cb + c0;
+        double s = 0.0;
+        if (c < d)
+            for (int b = g; b < nblocks; b += 4) s += partial[(int64_t)b * d + c];
+        sm[g][c0] = s;
+        __syncthreads();
+        if (g == 0 && c < d) out[c] = ((sm[0][c0] + sm[1][c0]) + (sm[2][c0] + sm[3][c0])) * scale;
+        __syncthreads();
+    }
+}
+
+// ---- per-segment variants: all original batches of a node in one launch (.compute_perbatch_var) -----------------
+struct SegDesc {
+    int start[16];
+    int n[16];
+    int nseg;
+};
+
+__global__ __launch_bounds__(256) void seg_reduce_partial(const double* __restrict__ X, int d, SegDesc sd, int mode,
+                                                          const double* __restrict__ centres, int maxnb,
+                                                          double* __restrict__ partial) {
+    __shared__ double sm[4][64];
+    const int seg = blockIdx.y;
+    const int c0 = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int b0 = sd.start[seg] + blockIdx.x * RED_ROWS;
+    const int b1 = min(sd.start[seg] + sd.n[seg], b0 + RED_ROWS);
+    if (blockIdx.x * RED_ROWS >= sd.n[seg]) return;
+    for (int cb = 0; cb < d; cb += 64) {
+        const int c = cb + c0;
+        double s = 0.0;
+        if (c < d) {
+            const double m = mode == 2 ? centres[(int64_t)seg * d + c] : 0.0;
+            for (int r = b0 + rl; r < b1; r += 4) {
+                const double x = X[(int64_t)r * d + c];
+                s += mode == 0 ? x : (x - m) * (x - m);
+            }
+        }
+        sm[rl][c0] = s;
+        __syncthreads();
+        if (rl == 0 && c < d)
+            partial[((int64_t)seg * maxnb + blockIdx.x) * d + c] = (sm[0][c0] + sm[1][c0]) + (sm[2][c0] + sm[3][c0]);
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void seg_reduce_final(const double* __restrict__ partial, int maxnb, int d, SegDesc sd,
+                                                        int mode, double* __restrict__ out) {
+    __shared__ double sm[4][64];
+    const int seg = blockIdx.x;
+    const int nb = (sd.n[seg] + RED_ROWS - 1) / RED_ROWS;
+    const double scale = mode == 0 ? 1.0 / (double)sd.n[seg] : 1.0 / (double)(sd.n[seg] - 1);
+    const int c0 = threadIdx.x & 63, g = threadIdx.x >> 6;
+    for (int cb = 0; cb < d; cb += 64) {
+        const int c = cb + c0;
+        double s = 0.0;
+        if (c < d)
+            for (int b = g; b < nb; b += 4) s += partial[((int64_t)seg * maxnb + b) * d + c];
+        sm[g][c0] = s;
+        __syncthreads();
+        if (g == 0 && c < d) out[(int64_t)seg * d + c] = ((sm[0][c0] + sm[1][c0]) + (sm[2][c0] + sm[3][c0])) * scale;
+        __syncthreads();
+    }
+}
+
+__global__ void seg_sum_kernel(const double* __restrict__ vars, int d, int nseg, double* __restrict__ out,
+                               int out_stride) {
+    const int seg = blockIdx.x * blockDim.x + threadIdx.x;
+    if (seg >= nseg) return;
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += partial[(int64_t)b * d + c];
-    out[c] = s * scale;
+    for (int c = 0; c < d; ++c) s += vars[(int64_t)seg * d + c];
+    out[(int64_t)seg * out_stride] = s;
 }
 
 __global__ void sum_vector_kernel(const double* __restrict__ in, int d, double scale, double* __restrict__ out) {
@@ -201,8 +271,35 @@ void col_reduce(hipStream_t stream, ReduceWorkspace& ws, const double* X, const 
     double* partial = ws.partial.reserve((size_t)nb * d);
     hipLaunchKernelGGL(col_reduce_partial, dim3(nb), dim3(256), 0, stream, X, rows, r0, r1, d, mode, centre, partial);
     BMX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(col_reduce_final, dim3(cdiv(d, 64)), dim3(64), 0, stream, partial, nb, d, scale, out);
+    hipLaunchKernelGGL(col_reduce_final, dim3(1), dim3(256), 0, stream, partial, nb, d, scale, out);
     BMX_LAUNCH_CHECK();
+}
+
+void segment_variances(hipStream_t stream, ReduceWorkspace& ws, const double* X, int d, const int* starts,
+                       const int* ns, int nseg, double* out, int out_stride) {
+    for (int s0 = 0; s0 < nseg; s0 += 16) {
+        SegDesc sd;
+        sd.nseg = std::min(16, nseg - s0);
+        int maxn = 1;
+        for (int i = 0; i < sd.nseg; ++i) {
+            sd.start[i] = starts[s0 + i];
+            sd.n[i] = ns[s0 + i];
+            maxn = std::max(maxn, ns[s0 + i]);
+        }
+        const int maxnb = cdiv(maxn, RED_ROWS);
+        double* partial = ws.partial.reserve((size_t)sd.nseg * maxnb * d + (size_t)2 * 16 * d);
+        double* means = partial + (size_t)sd.nseg * maxnb * d;
+        double* vars = means + (size_t)16 * d;
+        hipLaunchKernelGGL(seg_reduce_partial, dim3(maxnb, sd.nseg), dim3(256), 0, stream, X, d, sd, 0, nullptr, maxnb,
+                           partial);
+        hipLaunchKernelGGL(seg_reduce_final, dim3(sd.nseg), dim3(256), 0, stream, partial, maxnb, d, sd, 0, means);
+        hipLaunchKernelGGL(seg_reduce_partial, dim3(maxnb, sd.nseg), dim3(256), 0, stream, X, d, sd, 2, means, maxnb,
+                           partial);
+        hipLaunchKernelGGL(seg_reduce_final, dim3(sd.nseg), dim3(256), 0, stream, partial, maxnb, d, sd, 2, vars);
+        hipLaunchKernelGGL(seg_sum_kernel, dim3(1), dim3(64), 0, stream, vars, d, sd.nseg, out + (size_t)s0 * out_stride,
+                           out_stride);
+        BMX_LAUNCH_CHECK();
+    }
 }
 
 void sum_vector(hipStream_t stream, const double* in, int d, double scale, double* out) {

@@ -161,17 +161,14 @@ Engine::MnnOut Engine::find_mnn(const Node& left, const Node& right, int k, doub
 
 void Engine::perbatch_var(const Node& node, int scal_off) {
     // .compute_perbatch_var (R/fastMNN.R:651-658): per original batch, sum over dims of the sample variance
-    double* tmp = vecs_.p + (size_t)(2 * B_ + 4) * d_;  // two scratch vectors behind the extras pool
+    std::vector<int> starts, ns;
     int r0 = 0;
-    int slot = scal_off;
     for (const Segment& s : node.origin) {
-        col_reduce(stream_, red_ws_, node.data.p, nullptr, r0, r0 + s.n, d_, 0, nullptr, 1.0 / (double)s.n, tmp);
-        col_reduce(stream_, red_ws_, node.data.p, nullptr, r0, r0 + s.n, d_, 2, tmp, 1.0 / (double)(s.n - 1),
-                   tmp + d_);
-        sum_vector(stream_, tmp + d_, d_, 1.0, scal_.p + slot);
+        starts.push_back(r0);
+        ns.push_back(s.n);
         r0 += s.n;
-        slot += 2;
     }
+    segment_variances(stream_, red_ws_, node.data.p, d_, starts.data(), ns.data(), (int)ns.size(), scal_.p + scal_off, 2);
 }
 
 void Engine::orthogonalize(Node& node, const std::vector<int>& extras) {

@@ -819,9 +819,11 @@ void knn_device(hipStream_t stream, KnnWorkspace& ws, const double* X, const int
                     const int slots = variant == 1 ? w * 256 : fixed_slots;
                     const double rounds = (double)nqb * c / slots;
                     const double eff = rounds >= 1.0 ? rounds / std::ceil(rounds) : rounds;
-                    // measured on 100k x 100k: each extra range costs the split-bf16 kernel ~0.1 of a sweep (selection
-                    // restarts from the sample threshold, bigger refine), the f32 kernels ~0.015
-                    const double score = eff - (variant == 2 ? 0.10 : 0.015) * c - 0.01 * (w_hi - w);
+                    // measured on 100k x 100k: each extra range costs the split-bf16 kernel ~0.1 of a 100k-row sweep
+                    // (selection restarts from the sample threshold, bigger refine) -- a fixed cost, so relatively
+                    // less for longer reference sets; the f32 kernels ~0.015 of a sweep
+                    const double per_range = variant == 2 ? 0.10 * std::min(1.0, 1.0e5 / (double)nr) : 0.015;
+                    const double score = eff - per_range * c - 0.01 * (w_hi - w);
                     if (score > best) {
                         best = score;
                         C = c;

@@ -7,7 +7,10 @@
 A "step" is one complete engine run -- every merge of the workload: exact kNN both ways, mutual pairs, averaged
 correction vectors, centring, variance bookkeeping, tricube-smoothed correction -- on inputs already resident in
 HBM (bmx_engine_upload happens before the timed region; the PCIe-inclusive rate is quoted in DESIGN.md).
-Workload (all N): BASELINE.json configs[1] = 2 synthetic Gaussian batches x 100 000 cells x 50 PCs, k = 20.
+Workload (all N): the configuration BASELINE.json's metric and target are quoted on and that fits one GPU --
+configs[2] = 8 synthetic Gaussian batches x 100 000 cells x 50 PCs, k = 20, progressive merge 1..8 (7 merges; the
+m-th new batch is orthogonalised against m-1 earlier batch vectors).  `--workload config2` (2 x 100k) and `config5`
+(16 unequal batches, 100 PCs, balanced tree) are available for comparison runs.
 With N > 1 the same job is split by kNN query rows over the ranks (strong scaling) and the per-rank neighbour lists
 are all-gathered with RCCL; every rank ends with the full result.
 
@@ -132,7 +135,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

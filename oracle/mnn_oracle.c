@@ -91,54 +91,67 @@ int orc_knn(const double* X, int32_t nr, const double* Q, int32_t nq, int32_t d,
                 Xt[((size_t)b * d + c) * RB + j] = r < nr ? X[(size_t)r * d + c] : 0.0;
             }
     int fail = 0;
+    /* A chunk of QC queries shares every transposed reference block while it sits in cache (the blocked brute force of
+     * BASELINE.md's "variant B"); per (query, reference) pair the arithmetic is unchanged. */
+    enum { QC = 32 };
 #pragma omp parallel
     {
-        cand_t* heap = (cand_t*)malloc((size_t)k * sizeof(cand_t));
+        cand_t* heaps = (cand_t*)malloc((size_t)QC * k * sizeof(cand_t));
+        int hn[QC];
         double acc[RB];
-        if (!heap) {
+        if (!heaps) {
 #pragma omp atomic write
             fail = 1;
         }
-#pragma omp for schedule(dynamic, 16)
-        for (int q = 0; q < nq; ++q) {
-            if (!heap) continue;
-            const double* qv = Q + (size_t)q * d;
-            int hn = 0;
+#pragma omp for schedule(dynamic, 1)
+        for (int q0 = 0; q0 < nq; q0 += QC) {
+            if (!heaps) continue;
+            const int qn = nq - q0 < QC ? nq - q0 : QC;
+            for (int qq = 0; qq < qn; ++qq) hn[qq] = 0;
             for (int b = 0; b < nblk; ++b) {
                 const double* blk = Xt + (size_t)b * d * RB;
-                for (int j = 0; j < RB; ++j) acc[j] = 0.0;
-                for (int c = 0; c < d; ++c) {
-                    const double qc = qv[c];
-                    const double* row = blk + (size_t)c * RB;
-                    for (int j = 0; j < RB; ++j) {
-                        double t = qc - row[j];
-                        acc[j] += t * t;
-                    }
-                }
                 int lim = nr - b * RB;
                 if (lim > RB) lim = RB;
-                for (int j = 0; j < lim; ++j) {
-                    int32_t r = b * RB + j;
-                    if (hn < k) {
-                        heap[hn].d2 = acc[j];
-                        heap[hn].idx = r;
-                        ++hn;
-                        if (hn == k)
-                            for (int i = k / 2 - 1; i >= 0; --i) heap_sift_down(heap, k, i);
-                    } else if (cand_less(acc[j], r, heap[0].d2, heap[0].idx)) {
-                        heap[0].d2 = acc[j];
-                        heap[0].idx = r;
-                        heap_sift_down(heap, k, 0);
+                for (int qq = 0; qq < qn; ++qq) {
+                    const double* qv = Q + (size_t)(q0 + qq) * d;
+                    cand_t* heap = heaps + (size_t)qq * k;
+                    for (int j = 0; j < RB; ++j) acc[j] = 0.0;
+                    for (int c = 0; c < d; ++c) {
+                        const double qc = qv[c];
+                        const double* row = blk + (size_t)c * RB;
+                        for (int j = 0; j < RB; ++j) {
+                            double t = qc - row[j];
+                            acc[j] += t * t;
+                        }
                     }
+                    int n = hn[qq];
+                    for (int j = 0; j < lim; ++j) {
+                        int32_t r = b * RB + j;
+                        if (n < k) {
+                            heap[n].d2 = acc[j];
+                            heap[n].idx = r;
+                            ++n;
+                            if (n == k)
+                                for (int i = k / 2 - 1; i >= 0; --i) heap_sift_down(heap, k, i);
+                        } else if (cand_less(acc[j], r, heap[0].d2, heap[0].idx)) {
+                            heap[0].d2 = acc[j];
+                            heap[0].idx = r;
+                            heap_sift_down(heap, k, 0);
+                        }
+                    }
+                    hn[qq] = n;
                 }
             }
-            qsort(heap, (size_t)hn, sizeof(cand_t), cand_cmp);
-            for (int j = 0; j < k; ++j) {
-                idx[(size_t)q * k + j] = heap[j].idx;
-                if (dist) dist[(size_t)q * k + j] = sqrt(heap[j].d2);
+            for (int qq = 0; qq < qn; ++qq) {
+                cand_t* heap = heaps + (size_t)qq * k;
+                qsort(heap, (size_t)hn[qq], sizeof(cand_t), cand_cmp);
+                for (int j = 0; j < k; ++j) {
+                    idx[(size_t)(q0 + qq) * k + j] = heap[j].idx;
+                    if (dist) dist[(size_t)(q0 + qq) * k + j] = sqrt(heap[j].d2);
+                }
             }
         }
-        free(heap);
+        free(heaps);
     }
     free(Xt);
     return fail ? ORC_ERR_NOMEM : ORC_OK;
