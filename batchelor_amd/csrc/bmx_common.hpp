@@ -67,7 +67,8 @@ struct KnnWorkspace {
     DevBuf<double> qn2, rn2, mean, red;
     DevBuf<int32_t> cand;          // [nq][C][KS]
     DevBuf<float> tau;             // [nq][C]
-    DevBuf<float> tau0;            // [nq] starting thresholds from the sample pass (split-bf16 kernel)
+    DevBuf<float> cand_v;          // [nq][C][KS] approximate values (multi-range runs: refine pre-ranks by them)
+    DevBuf<uint32_t> tau_g;        // [nq] per-query thresholds shared across reference ranges (split-bf16 kernel)
     DevBuf<uint64_t> seed;         // [nq][KS + 1] kept list of the sample range (wave-per-workgroup kernel)
     DevBuf<int32_t> flagged;       // [nq + 1] compact list of queries needing the exact path (+ counter)
     DevBuf<double> drow;           // exact-path distance rows
@@ -105,9 +106,10 @@ struct Bf16Launch {
     const uint16_t* pq;
     const uint16_t* pr;
     int nqb, first_begin, range_len, nranges, r_limit, out_chunk0, out_nchunks;
-    const float* tau_init;  // full pass: starting threshold per query (from the sample pass), or null
-    int sample;             // non-zero: threshold-estimation pass, writes tau[q] only
+    uint32_t* tau_g;        // per-query threshold shared by all ranges (orderable image); sample pass writes it
+    int sample;             // non-zero: threshold-estimation pass, writes tau_g[q] only
     int32_t* cand;
+    float* cand_v;          // approximate values of the candidates (null: not needed, single range)
     float* tau;
 };
 int bf16_pick_ns(int d);         // MFMA k-steps (16 bf16 each) for 3 d + 3 columns; 0 = unsupported

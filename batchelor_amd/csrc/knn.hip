@@ -445,10 +445,10 @@ constexpr int REFINE_MAXM = 64 * 5;  // MAX_CHUNKS * 40
 
 __global__ __launch_bounds__(256) void knn_refine(const double* __restrict__ X, const int32_t* __restrict__ ref_rows,
                                                   const double* __restrict__ Q, const int32_t* __restrict__ q_rows,
-                                                  int nq, int d, int k, int KS, int nchunks, double eps_k,
-                                                  double eps_qr, double eps_split,
-                                                  const int32_t* __restrict__ cand, const float* __restrict__ tau,
-                                                  const double* __restrict__ qn2,
+                                                  int nq, int d, int k, int KS, int nchunks, int dedupe,
+                                                  double eps_k, double eps_qr, double eps_split,
+                                                  const int32_t* __restrict__ cand, const float* __restrict__ cand_v,
+                                                  const float* __restrict__ tau, const double* __restrict__ qn2,
                                                   const unsigned long long* __restrict__ max_rn2_bits,
                                                   int32_t* __restrict__ idx_out, double* __restrict__ dist_out,
                                                   int32_t* __restrict__ flagged, double* __restrict__ flag_bound) {
@@ -457,31 +457,74 @@ __global__ __launch_bounds__(256) void knn_refine(const double* __restrict__ X, 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int q = blockIdx.x * 4 + w;
     if (q >= nq) return;
-    const int M = nchunks * KS;
+    const int Mall = nchunks * KS;
     const double* qv = Q + (int64_t)(q_rows ? q_rows[q] : q) * d;
-    for (int m = lane; m < M; m += 64) {
-        const int id = cand[(int64_t)q * M + m];
-        double d2 = __builtin_inf();
-        if (id >= 0) d2 = exact_d2(qv, X + (int64_t)(ref_rows ? ref_rows[id] : id) * d, d);
-        sd[w][m] = d2;
-        si[w][m] = id >= 0 ? id : 0x7FFFFFFF;
+    // gather the valid candidates of all ranges into a dense list (ballot prefix), then work on that list only
+    int M = 0;
+    float* sv = reinterpret_cast<float*>(&sd[w][0]) + REFINE_MAXM;  // upper half of this wave's sd row: approx values
+    for (int m0 = 0; m0 < Mall; m0 += 64) {
+        const int m = m0 + lane;
+        const int id = m < Mall ? cand[(int64_t)q * Mall + m] : -1;
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(id >= 0);
+        const int pos = M + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+        if (id >= 0) {
+            si[w][pos] = id;
+            if (cand_v) sv[pos] = cand_v[(int64_t)q * Mall + m];
+        }
+        M += __builtin_popcountll(mask);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if (nchunks > 1) {
+    // several ranges: only the KS best by approximate value can matter; the rest count as rejected with the
+    // (KS+1)-th smallest approximate value as their bound, which enters the certificate below
+    float tmerge = __builtin_inff();
+    if (cand_v && M > KS) {
+        constexpr int NU = (REFINE_MAXM + 63) / 64;
+        int keep_pos[NU], ids[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int m = lane + 64 * u;
+            keep_pos[u] = -1;
+            ids[u] = 0;
+            if (m < M) {
+                const float vm = sv[m];
+                const int im = si[w][m];
+                int rank = 0;
+                for (int f = 0; f < M; ++f) {
+                    const float vf = sv[f];
+                    rank += (vf < vm || (vf == vm && si[w][f] < im)) ? 1 : 0;
+                }
+                keep_pos[u] = rank < KS ? rank : -1;
+                ids[u] = im;
+                if (rank == KS) tmerge = vm;  // the first rejected one bounds all rejected ones from below
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+            if (keep_pos[u] >= 0) si[w][keep_pos[u]] = ids[u];
+        for (int o = 32; o > 0; o >>= 1) tmerge = fminf(tmerge, __shfl_xor(tmerge, o));
+        M = KS;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    for (int m = lane; m < M; m += 64) {
+        const int id = si[w][m];
+        sd[w][m] = exact_d2(qv, X + (int64_t)(ref_rows ? ref_rows[id] : id) * d, d);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (dedupe && nchunks > 1) {
         // seeded ranges can carry the same sample reference in several lists: keep the first copy only
         for (int m = lane; m < M; m += 64) {
             const int im = si[w][m];
             bool dup = false;
-            if (im != 0x7FFFFFFF)
-                for (int f = 0; f < m; ++f) dup |= si[w][f] == im;
+            for (int f = 0; f < m; ++f) dup |= si[w][f] == im;
             if (dup) sd[w][m] = __builtin_inf();
-            // the index is voided after every lane has finished comparing against it
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            if (dup) si[w][m] = 0x7FFFFFFF;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (int m = lane; m < M; m += 64)
+            if (sd[w][m] == __builtin_inf()) si[w][m] = 0x7FFFFFFF;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
-    double kth = 0.0;
+    double kth = M >= k ? 0.0 : __builtin_inf();  // fewer than k candidates: never certified
     for (int m = lane; m < M; m += 64) {
         const double dm = sd[w][m];
         const int im = si[w][m];
@@ -495,7 +538,7 @@ __global__ __launch_bounds__(256) void knn_refine(const double* __restrict__ X, 
     }
     // certification: every rejected reference has  v >= tau_c, i.e. approx d2 >= tau_c + |q~|^2, and the f32 path
     // is within eps of the exact value, so the top k is proven when  kth < min_c tau_c + |q~|^2 - eps.
-    float tmin = __builtin_inff();
+    float tmin = tmerge;
     for (int c = lane; c < nchunks; c += 64) tmin = fminf(tmin, tau[(int64_t)q * nchunks + c]);
     for (int o = 32; o > 0; o >>= 1) {
         tmin = fminf(tmin, __shfl_xor(tmin, o));
@@ -655,6 +698,11 @@ __global__ __launch_bounds__(256) void knn_exact_pick(const int32_t* __restrict_
             if (dist_out) dist_out[(int64_t)q * k + rank] = sqrt(dm);
         }
     }
+}
+
+__global__ void fill_u32(uint32_t* __restrict__ p, int n, uint32_t v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
 }
 
 __global__ void accumulate_flagged(const int32_t* __restrict__ flagged, unsigned long long* __restrict__ total) {
@@ -822,8 +870,10 @@ void knn_device(hipStream_t stream, KnnWorkspace& ws, const double* X, const int
                     // measured on 100k x 100k: each extra range costs the split-bf16 kernel ~0.1 of a 100k-row sweep
                     // (selection restarts from the sample threshold, bigger refine) -- a fixed cost, so relatively
                     // less for longer reference sets; the f32 kernels ~0.015 of a sweep
-                    const double per_range = variant == 2 ? 0.10 * std::min(1.0, 1.0e5 / (double)nr) : 0.015;
-                    const double score = eff - per_range * c - 0.01 * (w_hi - w);
+                    const double per_range = variant == 2 ? 0.03 * std::min(1.0, 1.0e5 / (double)nr) : 0.015;
+                    // a lone range that needs a second, partly filled round measured ~12 % slower than its round count says
+                    const double lone = (variant == 2 && c == 1 && rounds > 1.0 && rounds < 2.0) ? 0.12 : 0.0;
+                    const double score = eff - per_range * c - lone - 0.01 * (w_hi - w);
                     if (score > best) {
                         best = score;
                         C = c;
@@ -870,22 +920,27 @@ void knn_device(hipStream_t stream, KnnWorkspace& ws, const double* X, const int
         BMX_HIP(hipMemsetAsync(maxbits, 0, sizeof(unsigned long long), stream));
 
         double eps_k, eps_qr, eps_split;
+        const float* cand_v = nullptr;
         if (variant == 2) {
             bf16_prep(stream, X, ref_rows, nr, nr_pad, d, NS, mean, 0, reinterpret_cast<uint16_t*>(pr), rn2, maxbits);
             bf16_prep(stream, Qs, qrs, nq, nq_pad, d, NS, mean, 1, reinterpret_cast<uint16_t*>(pq), qn2, maxbits);
             // sample pass: threshold estimation over rows [0, S); full pass: every row, starting from that threshold
-            float* tau0 = S > 0 ? ws.tau0.reserve(nq_pad) : nullptr;
+            uint32_t* tau_g = ws.tau_g.reserve(nq_pad);
+            if (S == 0) {  // no sample: +inf everywhere (0xFF800000 is the orderable image of +inf)
+                hipLaunchKernelGGL(fill_u32, dim3(cdiv(nq_pad, 256)), dim3(256), 0, stream, tau_g, nq_pad, 0xFF800000u);
+                BMX_LAUNCH_CHECK();
+            }
             Bf16Launch L{reinterpret_cast<const uint16_t*>(pq), reinterpret_cast<const uint16_t*>(pr), nqb, 0, S, 1, S,
-                         0, nchunks, nullptr, 1, cand, tau0};
+                         0, nchunks, tau_g, 1, cand, nchunks > 1 ? ws.cand_v.reserve((size_t)nq_pad * nchunks * KS) : nullptr,
+                         tau};
+            cand_v = L.cand_v;
             bool ok = true;
             if (S > 0) ok = bf16_launch(stream, ws, NS, KS, L);
             L.first_begin = 0;
             L.range_len = chunk_len;
             L.nranges = C;
             L.r_limit = nr_pad;
-            L.tau_init = tau0;
             L.sample = 0;
-            L.tau = tau;
             ok = ok && bf16_launch(stream, ws, NS, KS, L);
             if (!ok) throw Error(BMX_ERR_ARG, "kNN: unsupported padded dimension");
             eps_k = 16.0 * NS;                                   // f32 accumulation over the concatenated K
@@ -918,9 +973,19 @@ void knn_device(hipStream_t stream, KnnWorkspace& ws, const double* X, const int
         }
 
         hipLaunchKernelGGL(knn_refine, dim3(cdiv(nq, 4)), dim3(256), 0, stream, X, ref_rows, Qs, qrs, nq, d, k, KS,
-                           nchunks, eps_k, eps_qr, eps_split, cand, tau, qn2, maxbits, io, dout, flagged,
+                           nchunks, seeded ? 1 : 0, eps_k, eps_qr, eps_split, cand, cand_v, tau, qn2, maxbits, io, dout,
+                           flagged,
                            ws.flag_bound.reserve((size_t)nq + 1));
         BMX_LAUNCH_CHECK();
+        if (std::getenv("BMX_DEBUG")) {
+            std::vector<int32_t> hc((size_t)nq * nchunks * KS);
+            BMX_HIP(hipMemcpyAsync(hc.data(), cand, hc.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+            BMX_HIP(hipStreamSynchronize(stream));
+            size_t valid = 0;
+            for (int32_t v : hc) valid += v >= 0;
+            fprintf(stderr, "[bmx] candidates per query after the top-k pass: %.1f (of %d slots)\n", (double)valid / nq,
+                    nchunks * KS);
+        }
     }
 
     // exact path: flagged queries, or everything when the MFMA path does not apply.  The number of flagged queries

@@ -103,12 +103,17 @@ __device__ __forceinline__ int lds_load_volatile(const int* p) { return __hip_at
 // SAMPLE = true: threshold estimation only.  Each (tile, lane-half) contributes the minimum of its 16 values as ONE
 // candidate; the KS-th smallest of these group minima bounds the KS-th nearest reference from above (they are KS
 // distinct references), so it is a valid starting threshold for the full pass.  Nothing else is kept: the full pass
-// rescans the sample rows.  Output: tau_out[q].  SAMPLE = false: the full pass, starting from tau_init[q].
+// rescans the sample rows.  Output: tau_g[q] (order-preserving integer image of the threshold).
+// SAMPLE = false: the full pass.  tau_g[q] is SHARED by all reference ranges of query q: every workgroup folds its
+// own list's threshold into it (atomicMin) whenever it compacts, and refreshes its working threshold from it, so a
+// range benefits from what the others have already found and extra ranges cost no extra selection work.  Each
+// range's threshold is an upper bound of the KS-th nearest reference overall, hence so is their minimum; a stale
+// read only leaves the filter looser, never wrong.
 template <int NS, int KS, int NCONS, bool SAMPLE>
 __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
     const uint16_t* __restrict__ Pq, const uint16_t* __restrict__ PrF, int first_begin, int range_len, int r_limit,
-    int out_chunk0, int out_nchunks, const float* __restrict__ tau_init, int32_t* __restrict__ cand,
-    float* __restrict__ tau_out) {
+    int out_chunk0, int out_nchunks, uint32_t* __restrict__ tau_g, int32_t* __restrict__ cand,
+    float* __restrict__ cand_v, float* __restrict__ tau_out) {
     constexpr int CAP = KS + 2 * PL;
     constexpr int NQ = NCONS * 32;
     constexpr int TILE_BYTES = NS * 1024;
@@ -175,7 +180,7 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
     const int qs = wave * 32 + j;
     const int q = blockIdx.x * NQ + qs;
 
-    float tau = (!SAMPLE && tau_init) ? tau_init[q] : __builtin_inff();
+    float tau = (!SAMPLE && tau_g) ? orderable_f32(tau_g[q]) : __builtin_inff();
     if (h == 0) {
         kcnt[qs] = 0;
         tau_s[qs] = tau;
@@ -207,6 +212,10 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
     f32x4 a0[NS], a1[NS];
     if (ntiles > 0) fetch(a0, 0);
     for (int t2 = 0; t2 < ntiles; t2 += 2) {
+      if constexpr (!SAMPLE) {
+          if (tau_g && (t2 & 31) == 0 && t2 > 0)  // cheap periodic refresh of the shared threshold (L1-bypassing load)
+              tau = fminf(tau, orderable_f32(__hip_atomic_load(&tau_g[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+      }
       // two tiles per iteration so that the fragment registers ping-pong statically; tile t + 1 is fetched before
       // tile t computes
 #pragma unroll
@@ -249,6 +258,14 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
                     compact_slot<KS>(buf, kcnt, tau_s, wave * 32 + jj, jj, lane, mycnt);
                 }
                 tau = tau_s[qs];
+                if constexpr (!SAMPLE) {
+                    if (tau_g) {  // publish this list's threshold, adopt the best one known for the query
+                        const uint32_t mine = f32_orderable(tau);
+                        const uint32_t seen = h == 0 ? atomicMin(&tau_g[q], mine) : mine;
+                        const uint32_t other = __shfl_xor(seen, 32);
+                        tau = orderable_f32(min(min(seen, other), mine));
+                    }
+                }
             }
         };
         if constexpr (SAMPLE) {
@@ -281,18 +298,25 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
 
     for (int jj = 0; jj < 32; ++jj) compact_slot<KS>(buf, kcnt, tau_s, wave * 32 + jj, jj, lane, mycnt);
     if constexpr (SAMPLE) {
-        if (h == 0) tau_out[q] = tau_s[qs];
+        if (h == 0) tau_g[q] = f32_orderable(tau_s[qs]);
         return;
     }
     for (int jj = 0; jj < 32; ++jj) {
         const int s = wave * 32 + jj;
         const int qq = blockIdx.x * NQ + s;
         const int n = kcnt[s];
+        // what this range rejected was rejected against thresholds >= the final working threshold of its lane pair;
+        // kept entries at or above that threshold are as good as rejected (another range holds KS better ones), so
+        // they are dropped here and the refine kernel only sees the few that matter
+        const float wt = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tau), jj));
+        const float eff = wt < tau_s[s] ? wt : tau_s[s];
         if (lane < KS) {
             const unsigned long long key = buf[s * CAP + lane];
-            cand[((int64_t)qq * out_nchunks + out_chunk) * KS + lane] = lane < n ? (int32_t)(uint32_t)key : -1;
+            const bool keep = lane < n && ((uint32_t)(key >> 32) < f32_orderable(eff) || out_nchunks == 1);
+            cand[((int64_t)qq * out_nchunks + out_chunk) * KS + lane] = keep ? (int32_t)(uint32_t)key : -1;
+            if (cand_v) cand_v[((int64_t)qq * out_nchunks + out_chunk) * KS + lane] = orderable_f32((uint32_t)(key >> 32));
         }
-        if (lane == 0) tau_out[(int64_t)qq * out_nchunks + out_chunk] = tau_s[s];
+        if (lane == 0) tau_out[(int64_t)qq * out_nchunks + out_chunk] = eff;
     }
 }
 
@@ -316,11 +340,11 @@ void launch(hipStream_t stream, KnnWorkspace& ws, const Bf16Launch& L) {
     if (L.sample)
         hipLaunchKernelGGL((knn_topk_bf16<NS, KS, NCONS, true>), dim3(L.nqb, L.nranges), dim3((NCONS + NPROD) * 64),
                            lds, stream, L.pq, L.pr, L.first_begin, L.range_len, L.r_limit, L.out_chunk0, L.out_nchunks,
-                           L.tau_init, L.cand, L.tau);
+                           L.tau_g, L.cand, L.cand_v, L.tau);
     else
         hipLaunchKernelGGL((knn_topk_bf16<NS, KS, NCONS, false>), dim3(L.nqb, L.nranges), dim3((NCONS + NPROD) * 64),
                            lds, stream, L.pq, L.pr, L.first_begin, L.range_len, L.r_limit, L.out_chunk0, L.out_nchunks,
-                           L.tau_init, L.cand, L.tau);
+                           L.tau_g, L.cand, L.cand_v, L.tau);
     BMX_LAUNCH_CHECK();
     if (ws.profile) BMX_HIP(hipEventRecord(ev.second, stream));
 }
