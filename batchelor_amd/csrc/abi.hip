@@ -395,6 +395,44 @@ int32_t bmx_adjust_shift_variance(const double* data1, int32_t g1, int32_t n1, c
     });
 }
 
+int32_t bmx_cosine_norm(const double* x, int32_t G, int32_t n, double* l2, double* normalized) {
+    return guarded([&] {
+        if (G < 0 || n < 0) throw bmx::Error(BMX_ERR_ARG, "negative dimension");
+        if (n == 0) return;
+        bmx::Engine& e = prim(1);
+        hipStream_t s = e.stream();
+        bmx::DevBuf<double> dx, dl, dn;
+        const double* px = upload(dx, x, (size_t)G * n, s);
+        double* pl = dl.reserve(n);
+        bmx::cosine_l2_device(s, px, G, n, pl);
+        if (l2) BMX_HIP(hipMemcpyAsync(l2, pl, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
+        if (normalized && G > 0) {
+            double* pn = dn.reserve((size_t)G * n);
+            bmx::apply_cosine_norm_device(s, px, G, n, pl, pn);
+            BMX_HIP(hipMemcpyAsync(normalized, pn, (size_t)G * n * sizeof(double), hipMemcpyDeviceToHost, s));
+        }
+        BMX_HIP(hipStreamSynchronize(s));
+    });
+}
+
+int32_t bmx_cosnorm_project(const double* x, int32_t G, int32_t n, const double* rotation, int32_t d,
+                            const double* centers, int32_t cos_norm, double* out) {
+    return guarded([&] {
+        if (G < 1 || n < 0 || d < 1) throw bmx::Error(BMX_ERR_ARG, "invalid dimension");
+        if (n == 0) return;
+        bmx::Engine& e = prim(1);
+        hipStream_t s = e.stream();
+        bmx::DevBuf<double> dx, du, dc, dout, dcu;
+        const double* px = upload(dx, x, (size_t)G * n, s);
+        const double* pu = upload(du, rotation, (size_t)G * d, s);
+        const double* pc = upload(dc, centers, (size_t)G, s);
+        double* po = dout.reserve((size_t)n * d);
+        bmx::cosnorm_project_device(s, px, G, n, pu, d, pc, cos_norm, po, nullptr, dcu.reserve(d));
+        BMX_HIP(hipMemcpyAsync(out, po, (size_t)n * d * sizeof(double), hipMemcpyDeviceToHost, s));
+        BMX_HIP(hipStreamSynchronize(s));
+    });
+}
+
 /* ---------------------------------------------------------------- engine ---------------------------------------- */
 
 int32_t bmx_engine_create(int32_t device, bmx_engine_t** out) {

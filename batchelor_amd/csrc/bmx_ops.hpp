@@ -62,6 +62,14 @@ void tricube_apply(hipStream_t stream, double* X, int n, int d, const double* av
 void transpose_cm_to_rm(hipStream_t stream, const double* cm, int n, int d, double* rm);  // [n x d] col-major -> row-major
 void transpose_rm_to_cm(hipStream_t stream, const double* rm, int n, int d, double* cm, int ld_cm, int row_off);
 
+// ---- upstream of the engine (prepca.hip): cosineNorm + PCA projection, x is genes x cells column-major ----------
+void cosine_l2_device(hipStream_t stream, const double* x, int G, int n, double* l2);
+void apply_cosine_norm_device(hipStream_t stream, const double* x, int G, int n, const double* l2, double* out);
+// out [n x d] column-major = crossprod(x / pmax(1e-8, l2) - centers, u)   (u [G x d] column-major); cos_norm = 0 skips
+// the division.  One pass over x.  l2_out (nullable) receives the column norms; cu_scratch: d doubles.
+void cosnorm_project_device(hipStream_t stream, const double* x, int G, int n, const double* u, int d,
+                            const double* centers, int cos_norm, double* out, double* l2_out, double* cu_scratch);
+
 // ---- legacy natives (legacy.hip) -------------------------------------------------------------------
 void smooth_gaussian_kernel_device(hipStream_t stream, const double* averaged, int g, int U, const int32_t* index,
                                    const double* mat, int gd, int n, double sigma2, double* out, double* ws_density);

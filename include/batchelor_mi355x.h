@@ -159,6 +159,16 @@ int32_t bmx_mnn_average_correction(const double* refdata, int32_t n1, const doub
 /* .compute_perbatch_var (R/fastMNN.R:651-658) for one batch: sum over dims of the sample variance of data [n x d]. */
 int32_t bmx_total_variance(const double* data, int32_t n, int32_t d, double* out);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Directly upstream of the engine in fastMNN() (R/fastMNN.R:348-354).  x is genes x cells, column-major.
+ * ---------------------------------------------------------------------------------------------------------------- */
+/* cosineNorm(x, mode=) (R/cosineNorm.R:53-82): l2 [n] and / or the normalised matrix [G x n]; either may be NULL. */
+int32_t bmx_cosine_norm(const double* x, int32_t G, int32_t n, double* l2, double* normalized);
+/* One pass over x: cosine normalisation (if cos_norm != 0) fused with the PCA projection of R/multiBatchPCA.R:236-239,
+ * out [n x d] = crossprod(cosineNorm(x) - centers, rotation); rotation [G x d] column-major, centers [G]. */
+int32_t bmx_cosnorm_project(const double* x, int32_t G, int32_t n, const double* rotation, int32_t d,
+                            const double* centers, int32_t cos_norm, double* out);
+
 #ifdef __cplusplus
 }
 #endif
