@@ -44,58 +44,83 @@ __device__ __forceinline__ int64_t frag_pos(int r, int L, int NS) {
     return ((((int64_t)(r >> 5) * NS + s) * 64 + h * 32 + (r & 31)) << 3) + j;
 }
 
-__global__ void knn_prep_bf16(const double* __restrict__ X, const int32_t* __restrict__ rows, int n, int n_pad, int d,
-                              int NS, const double* __restrict__ mean, int is_query, uint16_t* __restrict__ P,
-                              double* __restrict__ n2, unsigned long long* __restrict__ max_n2_bits) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_pad) return;
+// One workgroup prepares one 32-row tile: rows are staged in LDS with coalesced reads, every output element is
+// computed from there, the tile image (fragment-major for references, row-major for queries -- both contiguous per
+// tile) is assembled in LDS and written out linearly.
+__global__ __launch_bounds__(256) void knn_prep_bf16(const double* __restrict__ X, const int32_t* __restrict__ rows,
+                                                     int n, int n_pad, int d, int NS, const double* __restrict__ mean,
+                                                     int is_query, uint16_t* __restrict__ P, double* __restrict__ n2,
+                                                     unsigned long long* __restrict__ max_n2_bits) {
+    extern __shared__ __attribute__((aligned(16))) char smem_pp[];
     const int K = 16 * NS;
-    auto put = [&](int L, uint16_t v) {
-        if (is_query)
-            P[(int64_t)r * K + L] = v;
-        else
-            P[frag_pos(r, L, NS)] = v;
-    };
-    for (int L = 0; L < K; ++L) put(L, 0);
-    if (r >= n) {
-        if (!is_query) put(3 * d, 0x7F80);  // +inf in the norm column: a padded reference never passes a threshold
-        return;
+    float* xs = reinterpret_cast<float*>(smem_pp);                       // [32][d] centred, rounded to f32
+    float* nrm = xs + 32 * d;                                            // [32] f32(|x~|^2)
+    uint16_t* img = reinterpret_cast<uint16_t*>(nrm + 32);               // [32 * K] tile image
+    const int tid = threadIdx.x;
+    const int r0 = blockIdx.x * 32;
+    (void)n_pad;
+    for (int e = tid; e < 32 * d; e += 256) {
+        const int rr = e / d, c = e - rr * d;
+        const int r = r0 + rr;
+        float f = 0.f;
+        if (r < n) {
+            const int64_t row = rows ? rows[r] : r;
+            f = (float)(X[row * d + c] - mean[c]);
+        }
+        xs[e] = f;
     }
-    const int64_t row = rows ? rows[r] : r;
-    const double* x = X + row * d;
-    double s = 0.0;
-    for (int c = 0; c < d; ++c) {
-        const float f = (float)(x[c] - mean[c]);
-        s += (double)f * (double)f;
-        const float g = is_query ? -2.f * f : f;
-        const uint16_t hi = f32_to_bf16(g);
-        const uint16_t lo = f32_to_bf16(g - bf16_to_f32(hi));
-        if (is_query) {
-            put(c, hi);
-            put(d + c, hi);
-            put(2 * d + c, lo);
-        } else {
-            put(c, hi);
-            put(d + c, lo);
-            put(2 * d + c, hi);
+    __syncthreads();
+    if (tid < 32) {
+        const int r = r0 + tid;
+        double s = 0.0;
+        for (int c = 0; c < d; ++c) {
+            const double f = (double)xs[tid * d + c];
+            s += f * f;
+        }
+        nrm[tid] = (float)s;
+        if (r < n) {
+            n2[r] = s;
+            if (!is_query) atomicMax(max_n2_bits, (unsigned long long)__double_as_longlong(s));
         }
     }
-    if (is_query) {
-        put(3 * d, 0x3F80);  // 1.0
-        put(3 * d + 1, 0x3F80);
-        put(3 * d + 2, 0x3F80);
-    } else {
-        const float nf = (float)s;  // what the f32 kernel would add; its three bf16 pieces reproduce it exactly
-        const uint16_t a = f32_to_bf16(nf);
-        const float r1 = nf - bf16_to_f32(a);
-        const uint16_t b = f32_to_bf16(r1);
-        const uint16_t c3 = f32_to_bf16(r1 - bf16_to_f32(b));
-        put(3 * d, a);
-        put(3 * d + 1, b);
-        put(3 * d + 2, c3);
+    __syncthreads();
+    const int hk = 8 * NS;
+    for (int e = tid; e < 32 * K; e += 256) {
+        const int rr = e / K, L = e - rr * K;
+        const bool live = r0 + rr < n;
+        uint16_t v = 0;
+        if (L < 3 * d) {
+            const int blk = L / d, c = L - blk * d;
+            const float f = xs[rr * d + c];
+            const float g = is_query ? -2.f * f : f;
+            const uint16_t hi = f32_to_bf16(g);
+            const bool want_lo = is_query ? blk == 2 : blk == 1;
+            v = want_lo ? f32_to_bf16(g - bf16_to_f32(hi)) : hi;
+        } else if (L < 3 * d + 3) {
+            const int piece = L - 3 * d;
+            if (is_query) {
+                v = live ? 0x3F80 : 0;  // 1.0 (padded queries stay all-zero)
+            } else if (!live) {
+                v = piece == 0 ? 0x7F80 : 0;  // +inf: a padded reference never passes a threshold
+            } else {
+                const float nf = nrm[rr];  // its three bf16 pieces reproduce the f32 value exactly
+                const uint16_t a = f32_to_bf16(nf);
+                const float r1 = nf - bf16_to_f32(a);
+                const uint16_t b2 = f32_to_bf16(r1);
+                v = piece == 0 ? a : (piece == 1 ? b2 : f32_to_bf16(r1 - bf16_to_f32(b2)));
+            }
+        }
+        int pos = e;  // queries: row-major inside the tile
+        if (!is_query) {
+            const int h = L / hk, s = (L - h * hk) >> 3, j = L & 7;
+            pos = ((s * 64 + h * 32 + rr) << 3) + j;
+        }
+        img[pos] = v;
     }
-    n2[r] = s;
-    if (!is_query) atomicMax(max_n2_bits, (unsigned long long)__double_as_longlong(s));
+    __syncthreads();
+    const uint4* src = reinterpret_cast<const uint4*>(img);
+    uint4* dst = reinterpret_cast<uint4*>(P + (int64_t)r0 * K);
+    for (int e = tid; e < 32 * K / 8; e += 256) dst[e] = src[e];
 }
 
 __device__ __forceinline__ int lds_load_volatile(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -362,8 +387,9 @@ int bf16_ncons(int NS, int KS) { return (NS <= 10 && KS == 24) ? 8 : 4; }
 
 void bf16_prep(hipStream_t stream, const double* X, const int32_t* rows, int n, int n_pad, int d, int NS,
                const double* mean, int is_query, uint16_t* P, double* n2, unsigned long long* maxbits) {
-    hipLaunchKernelGGL(knn_prep_bf16, dim3(cdiv(n_pad, 256)), dim3(256), 0, stream, X, rows, n, n_pad, d, NS, mean,
-                       is_query, P, n2, maxbits);
+    const size_t lds = (size_t)32 * d * 4 + 128 + (size_t)32 * 16 * NS * 2 + 16;
+    hipLaunchKernelGGL(knn_prep_bf16, dim3(n_pad / 32), dim3(256), lds, stream, X, rows, n, n_pad, d, NS, mean, is_query,
+                       P, n2, maxbits);
     BMX_LAUNCH_CHECK();
 }
 
