@@ -27,7 +27,7 @@ namespace {
 using namespace sel;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int NPROD = 4;  // producer waves == ring slots: producer p owns slot p and stages tiles p, p+4, ...
+constexpr int NPROD = 4;  // producer waves; producer p stages tiles p, p + 4, ... into ring slot (tile % NSLOT)
 
 __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
     uint32_t u = __float_as_uint(f);
@@ -123,6 +123,40 @@ __global__ __launch_bounds__(256) void knn_prep_bf16(const double* __restrict__ 
     for (int e = tid; e < 32 * K / 8; e += 256) dst[e] = src[e];
 }
 
+// Fragment reads of one staged tile (see the consumer's fetch()).  issue(): NS ds_read_b128, 1 KB apart.
+// landed(): s_waitcnt lgkmcnt(0) that names every fragment register as read-write, so each later use depends on it.
+template <int NS, int S>
+struct FragReads {
+    static __device__ __forceinline__ void issue(f32x4 (&a)[NS], uint32_t addr) {
+        if constexpr (S < NS) {
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[S]) : "v"(addr), "n"(S * 1024) : "memory");
+            FragReads<NS, S + 1>::issue(a, addr);
+        }
+    }
+};
+template <int NS>
+__device__ __forceinline__ void frags_landed(f32x4 (&a)[NS]) {
+    if constexpr (NS == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0])::"memory");
+    else if constexpr (NS == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1])::"memory");
+    else if constexpr (NS == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2])::"memory");
+    else if constexpr (NS == 4)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])::"memory");
+    else {
+        // more than 4 fragments: tie them in groups (one wait instruction per group; only the first one can stall)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])::"memory");
+        frags_landed(reinterpret_cast<f32x4(&)[NS - 4]>(a[4]));
+    }
+}
+
+// Ring depth: as many staged tiles as the LDS left over by the candidate lists holds (at most 8).  The consumers of a
+// workgroup stall at different times (a compaction costs a couple of tile times); the deeper the ring, the less one
+// consumer's stall holds up the others.
+__host__ __device__ constexpr int ring_slots(int NS, int KS, int NCONS) {
+    const int rest = 160 * 1024 - NCONS * 32 * (KS + 2 * PL) * 8 - NCONS * 32 * 8 - 64;
+    const int n = rest / (NS * 1024);
+    return n > 8 ? 8 : n;
+}
+
 __device__ __forceinline__ int lds_load_volatile(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // SAMPLE = true: threshold estimation only.  Each (tile, lane-half) contributes the minimum of its 16 values as ONE
@@ -142,22 +176,23 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
     constexpr int CAP = KS + 2 * PL;
     constexpr int NQ = NCONS * 32;
     constexpr int TILE_BYTES = NS * 1024;
+    constexpr int NSLOT = ring_slots(NS, KS, NCONS);
     static_assert(CAP <= 64, "one candidate per lane during compaction");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* ring = smem;                                                                        // [NPROD][TILE_BYTES]
-    unsigned long long* buf = reinterpret_cast<unsigned long long*>(smem + NPROD * TILE_BYTES);  // [NQ][CAP]
+    char* ring = smem;                                                                        // [NSLOT][TILE_BYTES]
+    unsigned long long* buf = reinterpret_cast<unsigned long long*>(smem + NSLOT * TILE_BYTES);  // [NQ][CAP]
     int* kcnt = reinterpret_cast<int*>(buf + NQ * CAP);                                       // [NQ]
     float* tau_s = reinterpret_cast<float*>(kcnt + NQ);                                       // [NQ]
-    int* ready = reinterpret_cast<int*>(tau_s + NQ);                                          // [NPROD]
-    int* done = ready + NPROD;                                                                // [NPROD]
+    int* ready = reinterpret_cast<int*>(tau_s + NQ);                                          // [NSLOT]
+    int* done = ready + NSLOT;                                                                // [NSLOT]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r_begin = first_begin + blockIdx.y * range_len;
     const int r_end = min(r_limit, r_begin + range_len);
     const int ntiles = (r_end - r_begin) >> 5;
     const int out_chunk = out_chunk0 + blockIdx.y;
-    if (tid < 2 * NPROD) ready[tid] = 0;  // ready[] and done[] are contiguous
+    if (tid < 2 * NSLOT) ready[tid] = 0;  // ready[] and done[] are contiguous
     __syncthreads();
 
     if (wave >= NCONS) {
@@ -165,20 +200,23 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
         const int p = wave - NCONS;
         f32x4 ra[NS], rb[NS];
         const f32x4* src = reinterpret_cast<const f32x4*>(PrF) + ((int64_t)(r_begin >> 5) * NS) * 64 + lane;
-        f32x4* dst = reinterpret_cast<f32x4*>(ring + p * TILE_BYTES) + lane;
+        f32x4* ring_l = reinterpret_cast<f32x4*>(ring) + lane;
         auto load = [&](f32x4 (&r)[NS], int t) {
 #pragma unroll
             for (int s = 0; s < NS; ++s) r[s] = src[((int64_t)t * NS + s) * 64];
         };
         auto publish = [&](const f32x4 (&r)[NS], int t) {
-            const int uses = t / NPROD;  // earlier tiles staged in this slot
-            while (lds_load_volatile(&done[p]) < NCONS * uses) __builtin_amdgcn_s_sleep(1);
+            // tile t goes to slot t % NSLOT once every consumer has read the tile staged there NSLOT tiles earlier
+            // (the slot's previous tile may have come from another producer: the done count orders the two)
+            const int uses = t / NSLOT, slot = t - uses * NSLOT;
+            while (lds_load_volatile(&done[slot]) < NCONS * uses) __builtin_amdgcn_s_sleep(1);
             __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            f32x4* dst = ring_l + slot * (TILE_BYTES / 16);
 #pragma unroll
             for (int s = 0; s < NS; ++s) dst[s * 64] = r[s];
             __atomic_signal_fence(__ATOMIC_SEQ_CST);
             // same wave, in-order LDS queue: the flag lands after the tile
-            if (lane == 0) __hip_atomic_store(&ready[p], t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lane == 0) __hip_atomic_store(&ready[slot], t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         };
         // three register sets: the loads of tiles t + 4 and t + 8 are in flight while tile t is handed over
         f32x4 rc[NS];
@@ -221,37 +259,59 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
     unsigned long long* pend = buf + qs * CAP + KS + h * PL;
     int mycnt = 0;
 
-    // fetch(t): wait until tile t sits in its slot, issue its fragment reads, hand the slot back.  The hand-back is
-    // queued behind the reads in this wave's in-order LDS queue, so the producer cannot overwrite them early.
-    auto fetch = [&](f32x4 (&a)[NS], int t) {
-        const int slot = t & (NPROD - 1);
-        while (lds_load_volatile(&ready[slot]) < t + 1) __builtin_amdgcn_s_sleep(1);
+    // fetch(t): tile t must sit in its slot (`seen` is the value of its ready word polled one iteration earlier, so
+    // in steady state no LDS round trip is waited for here); issue its fragment reads and hand the slot back.  The
+    // hand-back is queued behind the reads in this wave's in-order LDS queue: the producer cannot overwrite them early.
+    // The reads are issued from inline assembly so that the compiler's wait-count pass does not see them: it would
+    // otherwise make the MFMAs of tile t wait for the reads of tile t + 1 issued just before them.  landed() is the
+    // matching wait, placed a whole tile later where it costs nothing.
+    const uint32_t ring_lane = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring + lane * 16;
+    auto fetch = [&](f32x4 (&a)[NS], int t, int seen) {
+        const int slot = t % NSLOT;
+        while (seen < t + 1) {
+            __builtin_amdgcn_s_sleep(1);
+            seen = lds_load_volatile(&ready[slot]);
+        }
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
-        const f32x4* tp = reinterpret_cast<const f32x4*>(ring + slot * TILE_BYTES) + lane;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) a[s] = tp[s * 64];
+        FragReads<NS, 0>::issue(a, ring_lane + slot * TILE_BYTES);
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         if (lane == 0) __hip_atomic_fetch_add(&done[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
+    auto peek = [&](int t) { return t < ntiles ? lds_load_volatile(&ready[t % NSLOT]) : 0; };
 
+    const bool shared_tau = !SAMPLE && tau_g != nullptr && gridDim.y > 1;
+    uint32_t tau_fetch = 0xFFFFFFFFu;
     f32x4 a0[NS], a1[NS];
-    if (ntiles > 0) fetch(a0, 0);
+    if (ntiles > 0) fetch(a0, 0, 0);
+    int seen_next = peek(1);
     for (int t2 = 0; t2 < ntiles; t2 += 2) {
       if constexpr (!SAMPLE) {
-          if (tau_g && (t2 & 31) == 0 && t2 > 0)  // cheap periodic refresh of the shared threshold (L1-bypassing load)
-              tau = fminf(tau, orderable_f32(__hip_atomic_load(&tau_g[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+          // periodic refresh of the shared threshold: the (L1-bypassing) load is issued here and looked at one
+          // iteration later, so nobody waits for the round trip
+          if (shared_tau) {
+              if ((t2 & 15) == 2) tau = fminf(tau, orderable_f32(tau_fetch));
+              if ((t2 & 15) == 0) tau_fetch = __hip_atomic_load(&tau_g[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
       }
       // two tiles per iteration so that the fragment registers ping-pong statically; tile t + 1 is fetched before
-      // tile t computes
+      // tile t computes, and the ready word of tile t + 2 is polled now to be looked at in the next iteration
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         const int t = t2 + half;
         if (t >= ntiles) break;
+        // everything this wave has queued on the LDS so far is a tile old: waiting for it is free, tells the compiler
+        // that nothing is pending (so it adds no wait of its own in front of the MFMAs) and covers the assembly reads
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+        if (half == 0)
+            frags_landed(a0);
+        else
+            frags_landed(a1);
         if (t + 1 < ntiles) {
             if (half == 0)
-                fetch(a1, t + 1);
+                fetch(a1, t + 1, seen_next);
             else
-                fetch(a0, t + 1);
+                fetch(a0, t + 1, seen_next);
+            seen_next = peek(t + 2);
         }
         f32x16 acc;
 #pragma unroll
@@ -274,7 +334,7 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
         const float mn = fminf(fminf(g[0], g[1]), fminf(g[2], g[3]));
         if (__builtin_amdgcn_ballot_w64(mn < tau) == 0) continue;
         auto flush_full = [&]() {
-            unsigned long long fm = __builtin_amdgcn_ballot_w64(mycnt >= PL);
+            unsigned long long fm = __builtin_amdgcn_ballot_w64(mycnt > PL - 4);  // keep 4 slots free
             if (fm) {
                 fm = (fm | (fm >> 32)) & 0xFFFFFFFFull;
                 while (fm) {
@@ -282,14 +342,11 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
                     fm &= fm - 1;
                     compact_slot<KS>(buf, kcnt, tau_s, wave * 32 + jj, jj, lane, mycnt);
                 }
-                tau = tau_s[qs];
+                tau = fminf(tau, tau_s[qs]);
                 if constexpr (!SAMPLE) {
-                    if (tau_g) {  // publish this list's threshold, adopt the best one known for the query
-                        const uint32_t mine = f32_orderable(tau);
-                        const uint32_t seen = h == 0 ? atomicMin(&tau_g[q], mine) : mine;
-                        const uint32_t other = __shfl_xor(seen, 32);
-                        tau = orderable_f32(min(min(seen, other), mine));
-                    }
+                    // publish this list's threshold (fire and forget; what the other ranges publish is picked up by
+                    // the periodic refresh above)
+                    if (shared_tau && h == 0) atomicMin(&tau_g[q], f32_orderable(tau));
                 }
             }
         };
@@ -303,18 +360,18 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (__builtin_amdgcn_ballot_w64(g[u] < tau) == 0) continue;
+                // a pending list keeps 4 free slots at this point, so the group's (at most 4) survivors of a lane are
+                // appended under the exec mask alone -- no wave-level branch per register
 #pragma unroll
                 for (int e = 4 * u; e < 4 * u + 4; ++e) {
                     const float v = acc[e];
-                    const bool pass = v < tau;
-                    if (__builtin_amdgcn_ballot_w64(pass) == 0) continue;
-                    if (pass) {
+                    if (v < tau) {
                         const int ridx = r0 + (e & 3) + 8 * (e >> 2) + 4 * h;
                         pend[mycnt] = ((unsigned long long)f32_orderable(v) << 32) | (uint32_t)ridx;
                         ++mycnt;
                     }
-                    flush_full();
                 }
+                flush_full();
             }
         }
 #endif
@@ -333,7 +390,9 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
         // what this range rejected was rejected against thresholds >= the final working threshold of its lane pair;
         // kept entries at or above that threshold are as good as rejected (another range holds KS better ones), so
         // they are dropped here and the refine kernel only sees the few that matter
-        const float wt = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tau), jj));
+        const float w0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tau), jj));
+        const float w1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tau), jj + 32));
+        const float wt = w0 < w1 ? w0 : w1;
         const float eff = wt < tau_s[s] ? wt : tau_s[s];
         if (lane < KS) {
             const unsigned long long key = buf[s * CAP + lane];
@@ -347,7 +406,7 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
 
 template <int NS, int KS, int NCONS>
 void launch(hipStream_t stream, KnnWorkspace& ws, const Bf16Launch& L) {
-    constexpr size_t lds = (size_t)NPROD * NS * 1024 + (size_t)NCONS * 32 * (KS + 2 * PL) * 8 + NCONS * 32 * 8 + 64;
+    constexpr size_t lds = (size_t)ring_slots(NS, KS, NCONS) * NS * 1024 + (size_t)NCONS * 32 * (KS + 2 * PL) * 8 + NCONS * 32 * 8 + 64;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set) {

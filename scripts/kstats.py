@@ -1,6 +1,6 @@
 """Pretty-print a rocprofv3 kernel_stats.csv (developer helper)."""
 import csv, glob, sys
-f = glob.glob(sys.argv[1] + "/*/*kernel_stats.csv")[0]
+f = (glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True))[0]
 rows = list(csv.DictReader(open(f)))
 tot = sum(int(r["TotalDurationNs"]) for r in rows)
 for r in rows[: int(sys.argv[2]) if len(sys.argv) > 2 else 16]:
