@@ -123,40 +123,19 @@ __global__ __launch_bounds__(256) void knn_prep_bf16(const double* __restrict__ 
     for (int e = tid; e < 32 * K / 8; e += 256) dst[e] = src[e];
 }
 
-// Fragment reads of one staged tile (see the consumer's fetch()).  issue(): NS ds_read_b128, 1 KB apart.
-// landed(): s_waitcnt lgkmcnt(0) that names every fragment register as read-write, so each later use depends on it.
-template <int NS, int S>
-struct FragReads {
-    static __device__ __forceinline__ void issue(f32x4 (&a)[NS], uint32_t addr) {
-        if constexpr (S < NS) {
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[S]) : "v"(addr), "n"(S * 1024) : "memory");
-            FragReads<NS, S + 1>::issue(a, addr);
-        }
-    }
-};
-template <int NS>
-__device__ __forceinline__ void frags_landed(f32x4 (&a)[NS]) {
-    if constexpr (NS == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0])::"memory");
-    else if constexpr (NS == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1])::"memory");
-    else if constexpr (NS == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2])::"memory");
-    else if constexpr (NS == 4)
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])::"memory");
-    else {
-        // more than 4 fragments: tie them in groups (one wait instruction per group; only the first one can stall)
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])::"memory");
-        frags_landed(reinterpret_cast<f32x4(&)[NS - 4]>(a[4]));
-    }
-}
-
 // Ring depth: as many staged tiles as the LDS left over by the candidate lists holds (at most 8).  The consumers of a
 // workgroup stall at different times (a compaction costs a couple of tile times); the deeper the ring, the less one
 // consumer's stall holds up the others.
 __host__ __device__ constexpr int ring_slots(int NS, int KS, int NCONS) {
-    const int rest = 160 * 1024 - NCONS * 32 * (KS + 2 * PL) * 8 - NCONS * 32 * 8 - 64;
+    const int rest = 160 * 1024 - NCONS * 32 * (KS + 2 * PL) * 8 - 64;
     const int n = rest / (NS * 1024);
     return n > 8 ? 8 : n;
 }
 
+#ifdef BMX_STAMPS
+__device__ unsigned long long bmx_dbg[16];
+#define STAMP() __builtin_readcyclecounter()
+#endif
 __device__ __forceinline__ int lds_load_volatile(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // SAMPLE = true: threshold estimation only.  Each (tile, lane-half) contributes the minimum of its 16 values as ONE
@@ -182,9 +161,7 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem;                                                                        // [NSLOT][TILE_BYTES]
     unsigned long long* buf = reinterpret_cast<unsigned long long*>(smem + NSLOT * TILE_BYTES);  // [NQ][CAP]
-    int* kcnt = reinterpret_cast<int*>(buf + NQ * CAP);                                       // [NQ]
-    float* tau_s = reinterpret_cast<float*>(kcnt + NQ);                                       // [NQ]
-    int* ready = reinterpret_cast<int*>(tau_s + NQ);                                          // [NSLOT]
+    int* ready = reinterpret_cast<int*>(buf + NQ * CAP);                                      // [NSLOT]
     int* done = ready + NSLOT;                                                                // [NSLOT]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -244,10 +221,7 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
     const int q = blockIdx.x * NQ + qs;
 
     float tau = (!SAMPLE && tau_g) ? orderable_f32(tau_g[q]) : __builtin_inff();
-    if (h == 0) {
-        kcnt[qs] = 0;
-        tau_s[qs] = tau;
-    }
+    int nk = 0;  // entries in this query's kept list (the same in both of its lanes, like tau)
 
     bf16x8 bq[NS];
     {
@@ -258,22 +232,38 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
 
     unsigned long long* pend = buf + qs * CAP + KS + h * PL;
     int mycnt = 0;
+#ifdef BMX_STAMPS
+    unsigned long long dbg_spin = 0, dbg_flush = 0, dbg_nspin = 0, dbg_nflush = 0, dbg_ncomp = 0, dbg_evt = 0, dbg_grp = 0;
+    const unsigned long long dbg_t0 = STAMP();
+#endif
 
     // fetch(t): tile t must sit in its slot (`seen` is the value of its ready word polled one iteration earlier, so
     // in steady state no LDS round trip is waited for here); issue its fragment reads and hand the slot back.  The
     // hand-back is queued behind the reads in this wave's in-order LDS queue: the producer cannot overwrite them early.
-    // The reads are issued from inline assembly so that the compiler's wait-count pass does not see them: it would
-    // otherwise make the MFMAs of tile t wait for the reads of tile t + 1 issued just before them.  landed() is the
-    // matching wait, placed a whole tile later where it costs nothing.
-    const uint32_t ring_lane = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring + lane * 16;
+    // The explicit wait at the top of every tile (see the loop) tells the compiler's wait-count pass that nothing is
+    // pending when the reads of tile t + 1 are issued; without it the pass makes the MFMAs of tile t wait for them.
     auto fetch = [&](f32x4 (&a)[NS], int t, int seen) {
         const int slot = t % NSLOT;
+#ifdef BMX_STAMPS
+        if (seen < t + 1) {
+            const unsigned long long s0 = STAMP();
+            while (seen < t + 1) {
+                __builtin_amdgcn_s_sleep(1);
+                seen = lds_load_volatile(&ready[slot]);
+            }
+            dbg_spin += STAMP() - s0;
+            ++dbg_nspin;
+        }
+#else
         while (seen < t + 1) {
             __builtin_amdgcn_s_sleep(1);
             seen = lds_load_volatile(&ready[slot]);
         }
+#endif
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
-        FragReads<NS, 0>::issue(a, ring_lane + slot * TILE_BYTES);
+        const f32x4* tp = reinterpret_cast<const f32x4*>(ring + slot * TILE_BYTES) + lane;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) a[s] = tp[s * 64];
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         if (lane == 0) __hip_atomic_fetch_add(&done[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
@@ -299,13 +289,9 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
       for (int half = 0; half < 2; ++half) {
         const int t = t2 + half;
         if (t >= ntiles) break;
-        // everything this wave has queued on the LDS so far is a tile old: waiting for it is free, tells the compiler
-        // that nothing is pending (so it adds no wait of its own in front of the MFMAs) and covers the assembly reads
+        // everything this wave has queued on the LDS so far is a tile old (the fragments of tile t included): waiting
+        // for it here is free and leaves the compiler with no pending LDS operation to protect the MFMAs from
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-        if (half == 0)
-            frags_landed(a0);
-        else
-            frags_landed(a1);
         if (t + 1 < ntiles) {
             if (half == 0)
                 fetch(a1, t + 1, seen_next);
@@ -332,22 +318,35 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
         for (int u = 0; u < 4; ++u)
             g[u] = fminf(fminf(acc[4 * u], acc[4 * u + 1]), fminf(acc[4 * u + 2], acc[4 * u + 3]));
         const float mn = fminf(fminf(g[0], g[1]), fminf(g[2], g[3]));
+#ifdef BMX_ABLATE_EVENTS
+        if (!SAMPLE) { asm volatile("" ::"v"(mn)); continue; }
+#endif
         if (__builtin_amdgcn_ballot_w64(mn < tau) == 0) continue;
+#ifdef BMX_STAMPS
+        ++dbg_evt;
+#endif
         auto flush_full = [&]() {
             unsigned long long fm = __builtin_amdgcn_ballot_w64(mycnt > PL - 4);  // keep 4 slots free
             if (fm) {
+#ifdef BMX_STAMPS
+                const unsigned long long s0 = STAMP();
+                ++dbg_nflush;
+                dbg_ncomp += __builtin_popcountll((fm | (fm >> 32)) & 0xFFFFFFFFull);
+#endif
                 fm = (fm | (fm >> 32)) & 0xFFFFFFFFull;
                 while (fm) {
                     const int jj = __builtin_ctzll(fm);
                     fm &= fm - 1;
-                    compact_slot<KS>(buf, kcnt, tau_s, wave * 32 + jj, jj, lane, mycnt);
+                    compact_regs<KS>(buf, wave * 32 + jj, jj, lane, mycnt, nk, tau);
                 }
-                tau = fminf(tau, tau_s[qs]);
                 if constexpr (!SAMPLE) {
                     // publish this list's threshold (fire and forget; what the other ranges publish is picked up by
                     // the periodic refresh above)
                     if (shared_tau && h == 0) atomicMin(&tau_g[q], f32_orderable(tau));
                 }
+#ifdef BMX_STAMPS
+                dbg_flush += STAMP() - s0;
+#endif
             }
         };
         if constexpr (SAMPLE) {
@@ -360,6 +359,9 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (__builtin_amdgcn_ballot_w64(g[u] < tau) == 0) continue;
+#ifdef BMX_STAMPS
+                ++dbg_grp;
+#endif
                 // a pending list keeps 4 free slots at this point, so the group's (at most 4) survivors of a lane are
                 // appended under the exec mask alone -- no wave-level branch per register
 #pragma unroll
@@ -378,22 +380,35 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
       }
     }
 
-    for (int jj = 0; jj < 32; ++jj) compact_slot<KS>(buf, kcnt, tau_s, wave * 32 + jj, jj, lane, mycnt);
+#ifdef BMX_STAMPS
+    if (!SAMPLE && lane == 0) {
+        atomicAdd(&bmx_dbg[0], STAMP() - dbg_t0);
+        atomicAdd(&bmx_dbg[1], dbg_spin);
+        atomicAdd(&bmx_dbg[2], dbg_flush);
+        atomicAdd(&bmx_dbg[3], dbg_nspin);
+        atomicAdd(&bmx_dbg[4], dbg_nflush);
+        atomicAdd(&bmx_dbg[5], dbg_ncomp);
+        atomicAdd(&bmx_dbg[6], dbg_evt);
+        atomicAdd(&bmx_dbg[7], dbg_grp);
+        atomicAdd(&bmx_dbg[8], (unsigned long long)ntiles);
+        atomicAdd(&bmx_dbg[9], 1ull);
+    }
+#endif
+    for (int jj = 0; jj < 32; ++jj) compact_regs<KS>(buf, wave * 32 + jj, jj, lane, mycnt, nk, tau);
     if constexpr (SAMPLE) {
-        if (h == 0) tau_g[q] = f32_orderable(tau_s[qs]);
+        if (h == 0) tau_g[q] = f32_orderable(tau);
         return;
     }
     for (int jj = 0; jj < 32; ++jj) {
         const int s = wave * 32 + jj;
         const int qq = blockIdx.x * NQ + s;
-        const int n = kcnt[s];
+        const int n = __builtin_amdgcn_readlane(nk, jj);
         // what this range rejected was rejected against thresholds >= the final working threshold of its lane pair;
         // kept entries at or above that threshold are as good as rejected (another range holds KS better ones), so
         // they are dropped here and the refine kernel only sees the few that matter
         const float w0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tau), jj));
         const float w1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tau), jj + 32));
-        const float wt = w0 < w1 ? w0 : w1;
-        const float eff = wt < tau_s[s] ? wt : tau_s[s];
+        const float eff = w0 < w1 ? w0 : w1;
         if (lane < KS) {
             const unsigned long long key = buf[s * CAP + lane];
             const bool keep = lane < n && ((uint32_t)(key >> 32) < f32_orderable(eff) || out_nchunks == 1);
@@ -406,7 +421,7 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
 
 template <int NS, int KS, int NCONS>
 void launch(hipStream_t stream, KnnWorkspace& ws, const Bf16Launch& L) {
-    constexpr size_t lds = (size_t)ring_slots(NS, KS, NCONS) * NS * 1024 + (size_t)NCONS * 32 * (KS + 2 * PL) * 8 + NCONS * 32 * 8 + 64;
+    constexpr size_t lds = (size_t)ring_slots(NS, KS, NCONS) * NS * 1024 + (size_t)NCONS * 32 * (KS + 2 * PL) * 8 + 64;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set) {
@@ -431,6 +446,18 @@ void launch(hipStream_t stream, KnnWorkspace& ws, const Bf16Launch& L) {
                            L.tau_g, L.cand, L.cand_v, L.tau);
     BMX_LAUNCH_CHECK();
     if (ws.profile) BMX_HIP(hipEventRecord(ev.second, stream));
+#ifdef BMX_STAMPS
+    if (!L.sample) {
+        unsigned long long h[16];
+        BMX_HIP(hipStreamSynchronize(stream));
+        BMX_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(bmx_dbg), sizeof(h)));
+        const double w = (double)h[9], nt = (double)h[8];
+        fprintf(stderr, "[stamps] waves=%.0f tiles/wave=%.0f cyc/tile=%.0f spin/tile=%.0f flush/tile=%.0f nspin/tile=%.3f nflush/tile=%.3f ncomp/tile=%.3f evt/tile=%.3f grp/tile=%.3f cyc/flush=%.0f\n",
+                w, nt / w, h[0] / nt, h[1] / nt, h[2] / nt, h[3] / nt, h[4] / nt, h[5] / nt, h[6] / nt, h[7] / nt, h[4] ? (double)h[2] / h[4] : 0.0);
+        unsigned long long z[16] = {0};
+        BMX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(bmx_dbg), z, sizeof(z)));
+    }
+#endif
 }
 
 }  // namespace

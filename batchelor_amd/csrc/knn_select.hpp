@@ -53,5 +53,53 @@ __device__ __forceinline__ void compact_slot(unsigned long long* buf, int* kcnt,
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
+// Register-state variant used by the split-bf16 ring kernel: the number of kept entries (nk) and the working
+// threshold (tau) of a query live in the registers of the two lanes that own it, so a compaction makes ONE LDS round
+// trip (the keys).  The rank count runs over 8-entry chunks with constant lane numbers (no per-iteration readlane
+// hazard, no loop-carried scalar work); lanes past n hold the maximal key and add nothing to anybody's rank.
+template <int KS>
+__device__ __forceinline__ void compact_regs(unsigned long long* buf, int slot, int jj, int lane, int& mycnt, int& nk_reg,
+                                             float& tau) {
+    constexpr int CAP = KS + 2 * PL;
+    const int nk = __builtin_amdgcn_readlane(nk_reg, jj);
+    const int n0 = __builtin_amdgcn_readlane(mycnt, jj);
+    const int n1 = __builtin_amdgcn_readlane(mycnt, jj + 32);
+    const int n = nk + n0 + n1;
+    unsigned long long* b = buf + slot * CAP;
+    int src = lane;  // kept entries sit at [0, nk)
+    if (lane >= nk) src = lane < nk + n0 ? KS + (lane - nk) : KS + PL + (lane - nk - n0);
+    const unsigned long long key = lane < n ? b[src] : ~0ull;
+    const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
+    int rank = 0;
+#pragma unroll
+    for (int c = 0; c < (CAP + 7) / 8; ++c) {
+        if (c * 8 < n) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int f = c * 8 + e;
+                if (f < CAP) {
+                    const uint32_t flo = __builtin_amdgcn_readlane(klo, f);
+                    const uint32_t fhi = __builtin_amdgcn_readlane(khi, f);
+                    const unsigned long long fk = ((unsigned long long)fhi << 32) | flo;
+                    rank += fk < key ? 1 : 0;
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // every lane holds its key before slots are rewritten
+    if (lane < n && rank < KS) b[rank] = key;
+    const bool mine = lane == jj || lane == jj + 32;
+    if (n >= KS) {
+        const unsigned long long at = __builtin_amdgcn_ballot_w64(lane < n && rank == KS - 1);
+        const float kth = orderable_f32(__builtin_amdgcn_readlane(khi, __builtin_ctzll(at)));
+        if (mine) tau = kth < tau ? kth : tau;
+    }
+    if (mine) {
+        mycnt = 0;
+        nk_reg = n < KS ? n : KS;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
 }  // namespace sel
 }  // namespace bmx

@@ -14,7 +14,11 @@ def nb():
 
 
 @pytest.mark.parametrize("nx,nq,d,k", [(2000, 2000, 50, 20), (5000, 3000, 50, 20), (700, 1300, 10, 5),
-                                       (4000, 1000, 100, 20), (3000, 500, 20, 30), (300, 300, 2, 1)])
+                                       (4000, 1000, 100, 20), (3000, 500, 20, 30), (300, 300, 2, 1),
+                                       # one case per fragment-count class of the split-bf16 kernel (NS = 1 ... 24)
+                                       (1500, 900, 4, 10), (1500, 900, 9, 10), (1500, 900, 15, 10),
+                                       (1500, 900, 31, 20), (2500, 1200, 41, 20), (2500, 1200, 60, 20),
+                                       (2500, 1200, 70, 20), (2500, 1200, 84, 20), (2500, 1200, 120, 20)])
 def test_query_knn_matches_oracle(oracle, nb, nx, nq, d, k):
     X, Q = synth_batches(1, [nx, nq], d)
     idx, dist = nb.query_knn(X, Q, k)
