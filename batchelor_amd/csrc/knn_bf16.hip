@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void knn_prep_bf16(const double* __restrict__ 
 // workgroup stall at different times (a compaction costs a couple of tile times); the deeper the ring, the less one
 // consumer's stall holds up the others.
 __host__ __device__ constexpr int ring_slots(int NS, int KS, int NCONS) {
-    const int rest = 160 * 1024 - NCONS * 32 * (KS + 2 * PL) * 8 - 64;
+    const int rest = 160 * 1024 - NCONS * 32 * list_pitch(KS) * 8 - 320;
     const int n = rest / (NS * 1024);
     return n > 8 ? 8 : n;
 }
@@ -153,6 +153,7 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
     int out_chunk0, int out_nchunks, uint32_t* __restrict__ tau_g, int32_t* __restrict__ cand,
     float* __restrict__ cand_v, float* __restrict__ tau_out) {
     constexpr int CAP = KS + 2 * PL;
+    constexpr int PITCH = list_pitch(KS);
     constexpr int NQ = NCONS * 32;
     constexpr int TILE_BYTES = NS * 1024;
     constexpr int NSLOT = ring_slots(NS, KS, NCONS);
@@ -161,15 +162,15 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem;                                                                        // [NSLOT][TILE_BYTES]
     unsigned long long* buf = reinterpret_cast<unsigned long long*>(smem + NSLOT * TILE_BYTES);  // [NQ][CAP]
-    int* ready = reinterpret_cast<int*>(buf + NQ * CAP);                                      // [NSLOT]
-    int* done = ready + NSLOT;                                                                // [NSLOT]
+    int* ready = reinterpret_cast<int*>(buf + NQ * PITCH);                                     // [NSLOT]
+    int* done = ready + NSLOT;                                                                // [NSLOT][NCONS]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r_begin = first_begin + blockIdx.y * range_len;
     const int r_end = min(r_limit, r_begin + range_len);
     const int ntiles = (r_end - r_begin) >> 5;
     const int out_chunk = out_chunk0 + blockIdx.y;
-    if (tid < 2 * NSLOT) ready[tid] = 0;  // ready[] and done[] are contiguous
+    if (tid < NSLOT * (1 + NCONS)) ready[tid] = 0;  // ready[] and done[] are contiguous
     __syncthreads();
 
     if (wave >= NCONS) {
@@ -182,11 +183,21 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
 #pragma unroll
             for (int s = 0; s < NS; ++s) r[s] = src[((int64_t)t * NS + s) * 64];
         };
+        // tile t goes to slot t % NSLOT once every consumer has read the tile staged there NSLOT tiles earlier (that
+        // tile may have come from another producer: the consumers' done words order the two).  done[slot][c] is the
+        // number of the last tile consumer c has read from the slot, plus one.
+        auto wait_free = [&](int t, int slot) {
+            if (t < NSLOT) return;
+            const int need = t - NSLOT + 1;
+            for (;;) {
+                const int v = lane < NCONS ? lds_load_volatile(&done[slot * NCONS + lane]) : need;
+                if (__builtin_amdgcn_ballot_w64(v < need) == 0) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+        };
         auto publish = [&](const f32x4 (&r)[NS], int t) {
-            // tile t goes to slot t % NSLOT once every consumer has read the tile staged there NSLOT tiles earlier
-            // (the slot's previous tile may have come from another producer: the done count orders the two)
-            const int uses = t / NSLOT, slot = t - uses * NSLOT;
-            while (lds_load_volatile(&done[slot]) < NCONS * uses) __builtin_amdgcn_s_sleep(1);
+            const int slot = t % NSLOT;
+            wait_free(t, slot);
             __atomic_signal_fence(__ATOMIC_SEQ_CST);
             f32x4* dst = ring_l + slot * (TILE_BYTES / 16);
 #pragma unroll
@@ -212,6 +223,12 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
                 publish(rc, t + 2 * NPROD);
             }
         }
+        // one empty tile past the end, so that the consumers' prefetch of "tile t + 1" needs no last-tile case
+        if (ntiles > 0 && ntiles % NPROD == p) {
+            const int slot = ntiles % NSLOT;
+            wait_free(ntiles, slot);
+            if (lane == 0) __hip_atomic_store(&ready[slot], ntiles + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
         return;
     }
 
@@ -230,82 +247,65 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
         for (int s = 0; s < NS; ++s) bq[s] = __builtin_bit_cast(bf16x8, src[s]);
     }
 
-    unsigned long long* pend = buf + qs * CAP + KS + h * PL;
+    unsigned long long* pend = buf + qs * PITCH + KS + h * PL;
     int mycnt = 0;
 #ifdef BMX_STAMPS
-    unsigned long long dbg_spin = 0, dbg_flush = 0, dbg_nspin = 0, dbg_nflush = 0, dbg_ncomp = 0, dbg_evt = 0, dbg_grp = 0;
+    unsigned long long dbg_spin = 0, dbg_flush = 0, dbg_nspin = 0, dbg_nflush = 0, dbg_ncomp = 0, dbg_evt = 0, dbg_grp = 0, dbg_evc = 0;
     const unsigned long long dbg_t0 = STAMP();
 #endif
 
-    // fetch(t): tile t must sit in its slot (`seen` is the value of its ready word polled one iteration earlier, so
-    // in steady state no LDS round trip is waited for here); issue its fragment reads and hand the slot back.  The
-    // hand-back is queued behind the reads in this wave's in-order LDS queue: the producer cannot overwrite them early.
-    // The explicit wait at the top of every tile (see the loop) tells the compiler's wait-count pass that nothing is
-    // pending when the reads of tile t + 1 are issued; without it the pass makes the MFMAs of tile t wait for them.
-    auto fetch = [&](f32x4 (&a)[NS], int t, int seen) {
-        const int slot = t % NSLOT;
+    // Tile hand-over.  Tile t + 1 (the producers stage one empty tile past the end, so there always is one) is read
+    // into the other fragment set before tile t computes.  Its ready word was polled one tile earlier (`seen`), so in
+    // steady state no LDS round trip is waited for.  After its fragment reads the wave stores "read up to t + 1" in
+    // its done word of the slot -- queued behind the reads in the wave's in-order LDS queue, so the producer cannot
+    // overwrite them early -- and polls the ready word of tile t + 2.
+    // The explicit lgkmcnt(0) at the top of every tile is free (everything queued is a tile old, the fragments of
+    // tile t included) and leaves the compiler's wait-count pass with nothing pending: without it the pass makes the
+    // MFMAs of tile t wait for the reads of tile t + 1 issued just before them.
+    const bool shared_tau = !SAMPLE && tau_g != nullptr && gridDim.y > 1;
+    uint32_t tau_fetch = 0xFFFFFFFFu;
+    int seen = 0;
+    int slot_n = 0;  // slot of the tile to read next
+    auto spin_until_staged = [&](int tile) {
 #ifdef BMX_STAMPS
-        if (seen < t + 1) {
+        if (seen < tile + 1) {
             const unsigned long long s0 = STAMP();
-            while (seen < t + 1) {
+            ++dbg_nspin;
+            while (seen < tile + 1) {
                 __builtin_amdgcn_s_sleep(1);
-                seen = lds_load_volatile(&ready[slot]);
+                seen = lds_load_volatile(&ready[slot_n]);
             }
             dbg_spin += STAMP() - s0;
-            ++dbg_nspin;
         }
 #else
-        while (seen < t + 1) {
+        while (seen < tile + 1) {
             __builtin_amdgcn_s_sleep(1);
-            seen = lds_load_volatile(&ready[slot]);
+            seen = lds_load_volatile(&ready[slot_n]);
         }
 #endif
-        __atomic_signal_fence(__ATOMIC_SEQ_CST);
-        const f32x4* tp = reinterpret_cast<const f32x4*>(ring + slot * TILE_BYTES) + lane;
+    };
+    auto read_tile = [&](f32x4 (&a)[NS], int tile) {
+        const f32x4* tp = reinterpret_cast<const f32x4*>(ring + slot_n * TILE_BYTES) + lane;
 #pragma unroll
         for (int s = 0; s < NS; ++s) a[s] = tp[s * 64];
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
-        if (lane == 0) __hip_atomic_fetch_add(&done[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0)
+            __hip_atomic_store(&done[slot_n * NCONS + wave], tile + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        slot_n = slot_n + 1 == NSLOT ? 0 : slot_n + 1;
+        seen = lds_load_volatile(&ready[slot_n]);
     };
-    auto peek = [&](int t) { return t < ntiles ? lds_load_volatile(&ready[t % NSLOT]) : 0; };
 
-    const bool shared_tau = !SAMPLE && tau_g != nullptr && gridDim.y > 1;
-    uint32_t tau_fetch = 0xFFFFFFFFu;
-    f32x4 a0[NS], a1[NS];
-    if (ntiles > 0) fetch(a0, 0, 0);
-    int seen_next = peek(1);
-    for (int t2 = 0; t2 < ntiles; t2 += 2) {
-      if constexpr (!SAMPLE) {
-          // periodic refresh of the shared threshold: the (L1-bypassing) load is issued here and looked at one
-          // iteration later, so nobody waits for the round trip
-          if (shared_tau) {
-              if ((t2 & 15) == 2) tau = fminf(tau, orderable_f32(tau_fetch));
-              if ((t2 & 15) == 0) tau_fetch = __hip_atomic_load(&tau_g[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-      }
-      // two tiles per iteration so that the fragment registers ping-pong statically; tile t + 1 is fetched before
-      // tile t computes, and the ready word of tile t + 2 is polled now to be looked at in the next iteration
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const int t = t2 + half;
-        if (t >= ntiles) break;
-        // everything this wave has queued on the LDS so far is a tile old (the fragments of tile t included): waiting
-        // for it here is free and leaves the compiler with no pending LDS operation to protect the MFMAs from
+    auto step = [&](const f32x4 (&cur)[NS], f32x4 (&nxt)[NS], const int t) {
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-        if (t + 1 < ntiles) {
-            if (half == 0)
-                fetch(a1, t + 1, seen_next);
-            else
-                fetch(a0, t + 1, seen_next);
-            seen_next = peek(t + 2);
-        }
+        spin_until_staged(t + 1);
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        read_tile(nxt, t + 1);
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
         for (int s = 0; s < NS; ++s)
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, half == 0 ? a0[s] : a1[s]), bq[s],
-                                                          acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur[s]), bq[s], acc, 0, 0, 0);
 
         const int r0 = r_begin + (t << 5);
 #ifdef BMX_ABLATE_SELECT
@@ -319,11 +319,12 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
             g[u] = fminf(fminf(acc[4 * u], acc[4 * u + 1]), fminf(acc[4 * u + 2], acc[4 * u + 3]));
         const float mn = fminf(fminf(g[0], g[1]), fminf(g[2], g[3]));
 #ifdef BMX_ABLATE_EVENTS
-        if (!SAMPLE) { asm volatile("" ::"v"(mn)); continue; }
+        if (!SAMPLE) { asm volatile("" ::"v"(mn)); return; }
 #endif
-        if (__builtin_amdgcn_ballot_w64(mn < tau) == 0) continue;
+        if (__builtin_amdgcn_ballot_w64(mn < tau) == 0) return;
 #ifdef BMX_STAMPS
         ++dbg_evt;
+        const unsigned long long dbg_e0 = STAMP();
 #endif
         auto flush_full = [&]() {
             unsigned long long fm = __builtin_amdgcn_ballot_w64(mycnt > PL - 4);  // keep 4 slots free
@@ -351,7 +352,7 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
         };
         if constexpr (SAMPLE) {
             if (mn < tau) {
-                pend[mycnt] = ((unsigned long long)f32_orderable(mn) << 32) | (uint32_t)(r0 + 4 * h);
+                pend[mycnt] = ((unsigned long long)__float_as_uint(mn) << 32) | (uint32_t)(r0 + 4 * h);
                 ++mycnt;
             }
             flush_full();
@@ -362,22 +363,46 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
 #ifdef BMX_STAMPS
                 ++dbg_grp;
 #endif
-                // a pending list keeps 4 free slots at this point, so the group's (at most 4) survivors of a lane are
-                // appended under the exec mask alone -- no wave-level branch per register
+                // a pending list keeps 4 free slots at this point, so the group's four values are appended in straight
+                // line code: a lane whose value does not pass writes it to the list's last slot instead, which stays
+                // unused as long as anything fails (at most 3 real entries land in the 4 free slots then)
+                const int rbase = r0 + 8 * u + 4 * h;
 #pragma unroll
-                for (int e = 4 * u; e < 4 * u + 4; ++e) {
-                    const float v = acc[e];
-                    if (v < tau) {
-                        const int ridx = r0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                        pend[mycnt] = ((unsigned long long)f32_orderable(v) << 32) | (uint32_t)ridx;
-                        ++mycnt;
-                    }
+                for (int e = 0; e < 4; ++e) {
+                    const float v = acc[4 * u + e];
+                    const bool pass = v < tau;
+                    uint32_t* dst = reinterpret_cast<uint32_t*>(pend + (pass ? mycnt : PL - 1));
+                    dst[0] = (uint32_t)(rbase + e);
+                    dst[1] = __float_as_uint(v);
+                    mycnt += pass ? 1 : 0;
                 }
                 flush_full();
             }
         }
+#ifdef BMX_STAMPS
+        dbg_evc += STAMP() - dbg_e0;
 #endif
-      }
+#endif
+    };
+
+    f32x4 a0[NS], a1[NS];
+    if (ntiles > 0) {
+        spin_until_staged(0);
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        read_tile(a0, 0);
+    }
+    // two tiles per iteration so that the fragment registers ping-pong statically
+    for (int t2 = 0; t2 < ntiles; t2 += 2) {
+        if constexpr (!SAMPLE) {
+            // periodic refresh of the shared threshold: the (L1-bypassing) load is issued here and looked at one
+            // iteration later, so nobody waits for the round trip
+            if (shared_tau) {
+                if ((t2 & 15) == 2) tau = fminf(tau, orderable_f32(tau_fetch));
+                if ((t2 & 15) == 0) tau_fetch = __hip_atomic_load(&tau_g[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        step(a0, a1, t2);
+        if (t2 + 1 < ntiles) step(a1, a0, t2 + 1);
     }
 
 #ifdef BMX_STAMPS
@@ -392,6 +417,7 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
         atomicAdd(&bmx_dbg[7], dbg_grp);
         atomicAdd(&bmx_dbg[8], (unsigned long long)ntiles);
         atomicAdd(&bmx_dbg[9], 1ull);
+        atomicAdd(&bmx_dbg[10], dbg_evc);
     }
 #endif
     for (int jj = 0; jj < 32; ++jj) compact_regs<KS>(buf, wave * 32 + jj, jj, lane, mycnt, nk, tau);
@@ -410,10 +436,11 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
         const float w1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tau), jj + 32));
         const float eff = w0 < w1 ? w0 : w1;
         if (lane < KS) {
-            const unsigned long long key = buf[s * CAP + lane];
-            const bool keep = lane < n && ((uint32_t)(key >> 32) < f32_orderable(eff) || out_nchunks == 1);
+            const unsigned long long key = buf[s * PITCH + lane];
+            const float val = __uint_as_float((uint32_t)(key >> 32));
+            const bool keep = lane < n && (val < eff || out_nchunks == 1);
             cand[((int64_t)qq * out_nchunks + out_chunk) * KS + lane] = keep ? (int32_t)(uint32_t)key : -1;
-            if (cand_v) cand_v[((int64_t)qq * out_nchunks + out_chunk) * KS + lane] = orderable_f32((uint32_t)(key >> 32));
+            if (cand_v) cand_v[((int64_t)qq * out_nchunks + out_chunk) * KS + lane] = val;
         }
         if (lane == 0) tau_out[(int64_t)qq * out_nchunks + out_chunk] = eff;
     }
@@ -421,7 +448,7 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
 
 template <int NS, int KS, int NCONS>
 void launch(hipStream_t stream, KnnWorkspace& ws, const Bf16Launch& L) {
-    constexpr size_t lds = (size_t)ring_slots(NS, KS, NCONS) * NS * 1024 + (size_t)NCONS * 32 * (KS + 2 * PL) * 8 + 64;
+    constexpr size_t lds = (size_t)ring_slots(NS, KS, NCONS) * NS * 1024 + (size_t)NCONS * 32 * list_pitch(KS) * 8 + 320;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set) {
@@ -452,8 +479,8 @@ void launch(hipStream_t stream, KnnWorkspace& ws, const Bf16Launch& L) {
         BMX_HIP(hipStreamSynchronize(stream));
         BMX_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(bmx_dbg), sizeof(h)));
         const double w = (double)h[9], nt = (double)h[8];
-        fprintf(stderr, "[stamps] waves=%.0f tiles/wave=%.0f cyc/tile=%.0f spin/tile=%.0f flush/tile=%.0f nspin/tile=%.3f nflush/tile=%.3f ncomp/tile=%.3f evt/tile=%.3f grp/tile=%.3f cyc/flush=%.0f\n",
-                w, nt / w, h[0] / nt, h[1] / nt, h[2] / nt, h[3] / nt, h[4] / nt, h[5] / nt, h[6] / nt, h[7] / nt, h[4] ? (double)h[2] / h[4] : 0.0);
+        fprintf(stderr, "[stamps] waves=%.0f tiles/wave=%.0f cyc/tile=%.0f spin/tile=%.0f flush/tile=%.0f nspin/tile=%.3f nflush/tile=%.3f ncomp/tile=%.3f evt/tile=%.3f grp/tile=%.3f cyc/flush=%.0f evpath/tile=%.0f\n",
+                w, nt / w, h[0] / nt, h[1] / nt, h[2] / nt, h[3] / nt, h[4] / nt, h[5] / nt, h[6] / nt, h[7] / nt, h[4] ? (double)h[2] / h[4] : 0.0, h[10] / nt);
         unsigned long long z[16] = {0};
         BMX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(bmx_dbg), z, sizeof(z)));
     }

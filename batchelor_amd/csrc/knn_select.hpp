@@ -24,6 +24,9 @@ __device__ __forceinline__ float orderable_f32(uint32_t o) {
 // returned value to wait for).  When a pending list fills, one wave merges kept + both pending lists by rank-counting
 // over the unique 64-bit keys (orderable value << 32 | reference index), keeps the KS smallest and tightens tau.
 constexpr int PL = 12;
+// Row pitch of a query's list in 8-byte entries (register-state variant): one more than the capacity, so that the
+// lists of neighbouring queries start 2 banks apart and the appends of a wave's lanes do not pile up on one bank pair.
+__host__ __device__ constexpr int list_pitch(int KS) { return KS + 2 * PL + 1; }
 
 template <int KS>
 __device__ __forceinline__ void compact_slot(unsigned long long* buf, int* kcnt, float* tau_s, int slot, int jj,
@@ -57,6 +60,8 @@ __device__ __forceinline__ void compact_slot(unsigned long long* buf, int* kcnt,
 // threshold (tau) of a query live in the registers of the two lanes that own it, so a compaction makes ONE LDS round
 // trip (the keys).  The rank count runs over 8-entry chunks with constant lane numbers (no per-iteration readlane
 // hazard, no loop-carried scalar work); lanes past n hold the maximal key and add nothing to anybody's rank.
+// Entries sit in the LDS as (raw f32 bits << 32 | reference index): the order-preserving integer image of the value
+// is formed here, once per compaction, instead of at every append.
 template <int KS>
 __device__ __forceinline__ void compact_regs(unsigned long long* buf, int slot, int jj, int lane, int& mycnt, int& nk_reg,
                                              float& tau) {
@@ -65,11 +70,13 @@ __device__ __forceinline__ void compact_regs(unsigned long long* buf, int slot, 
     const int n0 = __builtin_amdgcn_readlane(mycnt, jj);
     const int n1 = __builtin_amdgcn_readlane(mycnt, jj + 32);
     const int n = nk + n0 + n1;
-    unsigned long long* b = buf + slot * CAP;
+    unsigned long long* b = buf + slot * list_pitch(KS);
     int src = lane;  // kept entries sit at [0, nk)
     if (lane >= nk) src = lane < nk + n0 ? KS + (lane - nk) : KS + PL + (lane - nk - n0);
-    const unsigned long long key = lane < n ? b[src] : ~0ull;
-    const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
+    const unsigned long long raw = lane < n ? b[src] : 0ull;
+    const uint32_t klo = lane < n ? (uint32_t)raw : 0xFFFFFFFFu;
+    const uint32_t khi = lane < n ? f32_orderable(__uint_as_float((uint32_t)(raw >> 32))) : 0xFFFFFFFFu;
+    const unsigned long long key = ((unsigned long long)khi << 32) | klo;
     int rank = 0;
 #pragma unroll
     for (int c = 0; c < (CAP + 7) / 8; ++c) {
@@ -87,7 +94,7 @@ __device__ __forceinline__ void compact_regs(unsigned long long* buf, int slot, 
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // every lane holds its key before slots are rewritten
-    if (lane < n && rank < KS) b[rank] = key;
+    if (lane < n && rank < KS) b[rank] = raw;
     const bool mine = lane == jj || lane == jj + 32;
     if (n >= KS) {
         const unsigned long long at = __builtin_amdgcn_ballot_w64(lane < n && rank == KS - 1);
