@@ -284,10 +284,12 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
         }
 #endif
     };
-    auto read_tile = [&](f32x4 (&a)[NS], int tile) {
+    auto read_tile = [&](f32x4 (&a)[NS]) {
         const f32x4* tp = reinterpret_cast<const f32x4*>(ring + slot_n * TILE_BYTES) + lane;
 #pragma unroll
         for (int s = 0; s < NS; ++s) a[s] = tp[s * 64];
+    };
+    auto hand_back = [&](int tile) {
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         if (lane == 0)
             __hip_atomic_store(&done[slot_n * NCONS + wave], tile + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -299,13 +301,21 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
         spin_until_staged(t + 1);
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
-        read_tile(nxt, t + 1);
+        read_tile(nxt);
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
         for (int s = 0; s < NS; ++s)
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur[s]), bq[s], acc, 0, 0, 0);
+        // the wave cannot issue the next (dependent) MFMA before the previous one is through the pipe: the fragment
+        // reads of the next tile go into those gaps instead of in front of the chain
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one LDS read
+        }
+        hand_back(t + 1);
 
         const int r0 = r_begin + (t << 5);
 #ifdef BMX_ABLATE_SELECT
@@ -389,7 +399,8 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
     if (ntiles > 0) {
         spin_until_staged(0);
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
-        read_tile(a0, 0);
+        read_tile(a0);
+        hand_back(0);
     }
     // two tiles per iteration so that the fragment registers ping-pong statically
     for (int t2 = 0; t2 < ntiles; t2 += 2) {
