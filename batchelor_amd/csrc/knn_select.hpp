@@ -58,10 +58,12 @@ __device__ __forceinline__ void compact_slot(unsigned long long* buf, int* kcnt,
 
 // Register-state variant used by the split-bf16 ring kernel: the number of kept entries (nk) and the working
 // threshold (tau) of a query live in the registers of the two lanes that own it, so a compaction makes ONE LDS round
-// trip (the keys).  The rank count runs over 8-entry chunks with constant lane numbers (no per-iteration readlane
-// hazard, no loop-carried scalar work); lanes past n hold the maximal key and add nothing to anybody's rank.
-// Entries sit in the LDS as (raw f32 bits << 32 | reference index): the order-preserving integer image of the value
-// is formed here, once per compaction, instead of at every append.
+// trip (the entries).  Entries sit in the LDS as (raw f32 bits << 32 | reference index).
+// Ranking uses a 31-bit key per lane: the order-preserving integer image of the value, shifted right by one, with
+// its low 6 bits replaced by the lane number -- unique, and a comparison is the sign of a difference; entries are
+// broadcast by readlane in 8-entry chunks with constant lane numbers.
+// Values closer than 2^-16 relative may therefore swap places at the cut; the new threshold is the cut key with the
+// lane bits cleared, which is <= the value of everything dropped, so "rejected => value >= tau" still holds exactly.
 template <int KS>
 __device__ __forceinline__ void compact_regs(unsigned long long* buf, int slot, int jj, int lane, int& mycnt, int& nk_reg,
                                              float& tau) {
@@ -74,31 +76,27 @@ __device__ __forceinline__ void compact_regs(unsigned long long* buf, int slot, 
     int src = lane;  // kept entries sit at [0, nk)
     if (lane >= nk) src = lane < nk + n0 ? KS + (lane - nk) : KS + PL + (lane - nk - n0);
     const unsigned long long raw = lane < n ? b[src] : 0ull;
-    const uint32_t klo = lane < n ? (uint32_t)raw : 0xFFFFFFFFu;
-    const uint32_t khi = lane < n ? f32_orderable(__uint_as_float((uint32_t)(raw >> 32))) : 0xFFFFFFFFu;
-    const unsigned long long key = ((unsigned long long)khi << 32) | klo;
+    const uint32_t key =
+        lane < n ? (((f32_orderable(__uint_as_float((uint32_t)(raw >> 32))) >> 1) & ~63u) | (uint32_t)lane) : 0x7FFFFFFFu;
     int rank = 0;
 #pragma unroll
     for (int c = 0; c < (CAP + 7) / 8; ++c) {
         if (c * 8 < n) {
+            // 31-bit keys: the sign of the difference is the comparison, so no lane mask (and no scalar-register
+            // round trip per entry) is involved
+            uint32_t fk[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int f = c * 8 + e;
-                if (f < CAP) {
-                    const uint32_t flo = __builtin_amdgcn_readlane(klo, f);
-                    const uint32_t fhi = __builtin_amdgcn_readlane(khi, f);
-                    const unsigned long long fk = ((unsigned long long)fhi << 32) | flo;
-                    rank += fk < key ? 1 : 0;
-                }
-            }
+            for (int e = 0; e < 8; ++e) fk[e] = c * 8 + e < CAP ? (uint32_t)__builtin_amdgcn_readlane(key, c * 8 + e) : 0x7FFFFFFFu;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) rank += (fk[e] - key) >> 31;
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // every lane holds its key before slots are rewritten
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // every lane holds its entry before slots are rewritten
     if (lane < n && rank < KS) b[rank] = raw;
     const bool mine = lane == jj || lane == jj + 32;
     if (n >= KS) {
         const unsigned long long at = __builtin_amdgcn_ballot_w64(lane < n && rank == KS - 1);
-        const float kth = orderable_f32(__builtin_amdgcn_readlane(khi, __builtin_ctzll(at)));
+        const float kth = orderable_f32(((uint32_t)__builtin_amdgcn_readlane(key, __builtin_ctzll(at)) & ~63u) << 1);
         if (mine) tau = kth < tau ? kth : tau;
     }
     if (mine) {
