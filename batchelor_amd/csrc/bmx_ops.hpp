@@ -17,12 +17,22 @@ void exclusive_scan_i32(hipStream_t stream, ScanWorkspace& ws, const int32_t* in
 // idxRL [nR][k1]: for each right cell the positions of its nearest left cells.
 // cntL[l]  = number of mutual partners of left cell l;   flags via the emit kernel.
 // partR [nR][k1]: mutual left partners of each right cell, ascending; cntR[r] their number.
+// idxLR may cover a SUBSET of the left cells: row c belongs to left cell lsel[c] (ascending) and lpos2c[l] is the row
+// of a selected left cell l (both nullptr: one row per left cell).  nL = number of rows of idxLR.
 void mutual_counts(hipStream_t stream, const int32_t* idxLR, int nL, int k2, const int32_t* idxRL, int nR, int k1,
-                   int32_t* cntL, int32_t* partR, int32_t* cntR);
+                   int32_t* cntL, int32_t* partR, int32_t* cntR, const int32_t* lsel = nullptr,
+                   const int32_t* lpos2c = nullptr);
 // Pairs in the reference order (src/find_mutual_nns.cpp:23-36): left ascending, then the left cell's neighbour rank.
 // offL = exclusive scan of cntL.  Ids written are lrows[l] + 1 / rrows[r] + 1 (1-based rows in the node; identity if null).
 void emit_pairs(hipStream_t stream, const int32_t* idxLR, int nL, int k2, const int32_t* idxRL, int k1,
-                const int32_t* offL, const int32_t* lrows, const int32_t* rrows, int32_t* first, int32_t* second);
+                const int32_t* offL, const int32_t* lrows, const int32_t* rrows, int32_t* first, int32_t* second,
+                const int32_t* lsel = nullptr);
+// Rows (of n_rows) that occur in idx[0, n_entries): flag[r] = 0/1, off = exclusive scan of flag (n_rows + 1 entries:
+// off[r] = position of a listed row in sel, off[n_rows] = their number), sel = the listed rows, ascending.
+void select_listed_rows(hipStream_t stream, ScanWorkspace& ws, const int32_t* idx, int64_t n_entries, int n_rows,
+                        int32_t* flag, int32_t* off, int32_t* sel);
+// out[i] = rows[sel[i]]
+void compose_row_list(hipStream_t stream, const int32_t* sel, int n, const int32_t* rows, int32_t* out);
 // second_u = ascending positions r with cntR[r] > 0 (offR = exclusive scan of the 0/1 flags, computed here).
 void compact_mnn_cells(hipStream_t stream, ScanWorkspace& ws, const int32_t* cntR, int nR, int32_t* flagR,
                        int32_t* offR, int32_t* second_u);

@@ -134,24 +134,42 @@ Engine::MnnOut Engine::find_mnn(const Node& left, const Node& right, int k, doub
     o.k1 = std::min(choose_k(k, prop_k, nL), nL);  // neighbours sought in LEFT for each right cell
     o.k2 = std::min(choose_k(k, prop_k, nR), nR);  // neighbours sought in RIGHT for each left cell
     if (o.k1 < 1 || o.k2 < 1) throw Error(BMX_ERR_ARG, "'k' must be positive");
-    const int64_t perL = (nL + world_ - 1) / world_ * (int64_t)world_;
     const int64_t perR = (nR + world_ - 1) / world_ * (int64_t)world_;
-    int32_t* idxLR = idxLR_.reserve((size_t)perL * o.k2);
     int32_t* idxRL = idxRL_.reserve((size_t)perR * o.k1);
-    knn(right.data.p, rrows, nR, left.data.p, lrows, nL, o.k2, idxLR, nullptr);
+    // 1. every right cell's neighbours in LEFT
     knn(left.data.p, lrows, nL, right.data.p, rrows, nR, o.k1, idxRL, nullptr);
-    int32_t* cntL = cntL_.reserve(nL);
-    int32_t* offL = offL_.reserve((size_t)nL + 1);
+    // 2. a pair needs its left cell in some right cell's list, so only those left cells are searched in RIGHT (with a
+    //    growing merged reference most left cells are in nobody's list).  The result is the same set of pairs.
+    int32_t* flagL = flagL_.reserve(nL);
+    int32_t* offSel = offSel_.reserve((size_t)nL + 1);
+    int32_t* lsel = lsel_.reserve(nL);
+    select_listed_rows(stream_, scan_ws_, idxRL, (int64_t)nR * o.k1, nL, flagL, offSel, lsel);
+    int32_t nsel = 0;
+    BMX_HIP(hipMemcpyAsync(&nsel, offSel + nL, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+    BMX_HIP(hipStreamSynchronize(stream_));
+    o.nsel = nsel;
+    if (std::getenv("BMX_DEBUG")) fprintf(stderr, "[bmx] find_mnn: %d of %d left cells are in some right cell's list\n", nsel, nL);
+    const int32_t* qsel = lsel;  // rows of left.data to query with
+    if (lrows) {
+        int32_t* q = qsel_.reserve(nsel);
+        compose_row_list(stream_, lsel, nsel, lrows, q);
+        qsel = q;
+    }
+    const int64_t perL = (nsel + world_ - 1) / world_ * (int64_t)world_;
+    int32_t* idxLR = idxLR_.reserve((size_t)std::max<int64_t>(1, perL) * o.k2);
+    knn(right.data.p, rrows, nR, left.data.p, qsel, nsel, o.k2, idxLR, nullptr);
+    int32_t* cntL = cntL_.reserve(std::max(1, nsel));
+    int32_t* offL = offL_.reserve((size_t)nsel + 1);
     int32_t* partR = partR_.reserve((size_t)nR * o.k1);
     int32_t* cntR = cntR_.reserve(nR);
     int32_t* flagR = flagR_.reserve(nR);
     int32_t* offR = offR_.reserve((size_t)nR + 1);
     int32_t* second_u = second_u_.reserve(nR);
-    mutual_counts(stream_, idxLR, nL, o.k2, idxRL, nR, o.k1, cntL, partR, cntR);
-    exclusive_scan_i32(stream_, scan_ws_, cntL, offL, nL);
+    mutual_counts(stream_, idxLR, nsel, o.k2, idxRL, nR, o.k1, cntL, partR, cntR, lsel, offSel);
+    exclusive_scan_i32(stream_, scan_ws_, cntL, offL, nsel);
     compact_mnn_cells(stream_, scan_ws_, cntR, nR, flagR, offR, second_u);
     int32_t h[2] = {0, 0};
-    BMX_HIP(hipMemcpyAsync(&h[0], offL + nL, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+    BMX_HIP(hipMemcpyAsync(&h[0], offL + nsel, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
     BMX_HIP(hipMemcpyAsync(&h[1], offR + nR, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
     BMX_HIP(hipStreamSynchronize(stream_));
     o.P = h[0];
@@ -249,7 +267,7 @@ void Engine::merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p,
     rec.stats[5] = right.n;
     int32_t* first = rec.first.reserve((size_t)mo.P);
     int32_t* second = rec.second.reserve((size_t)mo.P);
-    emit_pairs(stream_, idxLR_.p, nLs, mo.k2, idxRL_.p, mo.k1, offL_.p, lrows, rrows, first, second);
+    emit_pairs(stream_, idxLR_.p, mo.nsel, mo.k2, idxRL_.p, mo.k1, offL_.p, lrows, rrows, first, second, lsel_.p);
 
     // .average_correction + overall.batch (R/fastMNN.R:480-481)
     double* averaged = averaged_.reserve((size_t)mo.U * d_);

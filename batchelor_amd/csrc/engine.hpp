@@ -69,8 +69,10 @@ class Engine {
         int64_t P = 0;
         int U = 0;
         int k1 = 0, k2 = 0;
+        int nsel = 0;  // left cells that occur in some right cell's list = rows of idxLR_ (see lsel_)
     };
-    // findMutualNN on (restricted) left / right rows; leaves idxLR_, idxRL_, cntL_, offL_, partR_, cntR_, second_u_
+    // findMutualNN on (restricted) left / right rows; leaves idxLR_ (one row per SELECTED left cell, lsel_), idxRL_,
+    // cntL_, offL_ (per row of idxLR_), partR_, cntR_, second_u_
     MnnOut find_mnn(const Node& left, const Node& right, int k, double prop_k);
 
     int d_ = 0;
@@ -78,6 +80,7 @@ class Engine {
     ScanWorkspace scan_ws_;
     ReduceWorkspace red_ws_;
     DevBuf<int32_t> idxLR_, idxRL_, cntL_, offL_, partR_, cntR_, flagR_, offR_, second_u_, second_rows_, idxT_;
+    DevBuf<int32_t> flagL_, offSel_, lsel_, qsel_;
     DevBuf<double> distT_, averaged_, loc_, vecs_, scal_;
 
   private:

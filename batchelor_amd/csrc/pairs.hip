@@ -68,27 +68,32 @@ __device__ __forceinline__ bool row_contains(const int32_t* __restrict__ row, in
     return f;
 }
 
+// idxLR may hold the lists of a SUBSET of the left cells (row c = left cell lsel[c], ascending; lpos2c maps a selected
+// left cell back to its row).  lsel == nullptr: every left cell has a row (c == l).
 __global__ void mutual_left(const int32_t* __restrict__ idxLR, int nL, int k2, const int32_t* __restrict__ idxRL, int k1,
-                            int32_t* __restrict__ cntL) {
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= nL) return;
+                            const int32_t* __restrict__ lsel, int32_t* __restrict__ cntL) {
+    const int c0 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c0 >= nL) return;
+    const int l = lsel ? lsel[c0] : c0;
     int c = 0;
     for (int j = 0; j < k2; ++j) {
-        const int32_t r = idxLR[(int64_t)l * k2 + j];
+        const int32_t r = idxLR[(int64_t)c0 * k2 + j];
         c += row_contains(idxRL + (int64_t)r * k1, k1, l) ? 1 : 0;
     }
-    cntL[l] = c;
+    cntL[c0] = c;
 }
 
 __global__ void mutual_right(const int32_t* __restrict__ idxLR, int k2, const int32_t* __restrict__ idxRL, int nR,
-                             int k1, int32_t* __restrict__ partR, int32_t* __restrict__ cntR) {
+                             int k1, const int32_t* __restrict__ lpos2c, int32_t* __restrict__ partR,
+                             int32_t* __restrict__ cntR) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nR) return;
     int32_t* row = partR + (int64_t)r * k1;
     int m = 0;
     for (int j = 0; j < k1; ++j) {
         const int32_t l = idxRL[(int64_t)r * k1 + j];
-        if (!row_contains(idxLR + (int64_t)l * k2, k2, r)) continue;
+        const int64_t c = lpos2c ? lpos2c[l] : l;
+        if (!row_contains(idxLR + c * k2, k2, r)) continue;
         int p = m++;  // insertion keeps the partners ascending = the order `rowsum` adds them in
         while (p > 0 && row[p - 1] > l) {
             row[p] = row[p - 1];
@@ -100,15 +105,16 @@ __global__ void mutual_right(const int32_t* __restrict__ idxLR, int k2, const in
 }
 
 __global__ void emit_pairs_kernel(const int32_t* __restrict__ idxLR, int nL, int k2, const int32_t* __restrict__ idxRL,
-                                  int k1, const int32_t* __restrict__ offL, const int32_t* __restrict__ lrows,
-                                  const int32_t* __restrict__ rrows, int32_t* __restrict__ first,
-                                  int32_t* __restrict__ second) {
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= nL) return;
-    int o = offL[l];
+                                  int k1, const int32_t* __restrict__ offL, const int32_t* __restrict__ lsel,
+                                  const int32_t* __restrict__ lrows, const int32_t* __restrict__ rrows,
+                                  int32_t* __restrict__ first, int32_t* __restrict__ second) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nL) return;
+    int o = offL[c];
+    const int l = lsel ? lsel[c] : c;
     const int32_t lid = (lrows ? lrows[l] : l) + 1;
     for (int j = 0; j < k2; ++j) {
-        const int32_t r = idxLR[(int64_t)l * k2 + j];
+        const int32_t r = idxLR[(int64_t)c * k2 + j];
         if (row_contains(idxRL + (int64_t)r * k1, k1, l)) {
             first[o] = lid;
             second[o] = (rrows ? rrows[r] : r) + 1;
@@ -120,6 +126,17 @@ __global__ void emit_pairs_kernel(const int32_t* __restrict__ idxLR, int nL, int
 __global__ void flag_positive(const int32_t* __restrict__ cnt, int n, int32_t* __restrict__ flag) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) flag[i] = cnt[i] > 0 ? 1 : 0;
+}
+
+__global__ void mark_listed(const int32_t* __restrict__ idx, int64_t n, int32_t* __restrict__ flag) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[idx[i]] = 1;  // same value from every writer: no atomics needed
+}
+
+__global__ void compose_rows(const int32_t* __restrict__ sel, int n, const int32_t* __restrict__ rows,
+                             int32_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = rows[sel[i]];
 }
 
 __global__ void scatter_positions(const int32_t* __restrict__ flag, const int32_t* __restrict__ off, int n,
@@ -145,23 +162,43 @@ void exclusive_scan_i32(hipStream_t stream, ScanWorkspace& ws, const int32_t* in
 }
 
 void mutual_counts(hipStream_t stream, const int32_t* idxLR, int nL, int k2, const int32_t* idxRL, int nR, int k1,
-                   int32_t* cntL, int32_t* partR, int32_t* cntR) {
+                   int32_t* cntL, int32_t* partR, int32_t* cntR, const int32_t* lsel, const int32_t* lpos2c) {
     if (nL > 0) {
-        hipLaunchKernelGGL(mutual_left, dim3(cdiv(nL, 256)), dim3(256), 0, stream, idxLR, nL, k2, idxRL, k1, cntL);
+        hipLaunchKernelGGL(mutual_left, dim3(cdiv(nL, 256)), dim3(256), 0, stream, idxLR, nL, k2, idxRL, k1, lsel,
+                           cntL);
         BMX_LAUNCH_CHECK();
     }
     if (nR > 0) {
-        hipLaunchKernelGGL(mutual_right, dim3(cdiv(nR, 256)), dim3(256), 0, stream, idxLR, k2, idxRL, nR, k1, partR,
-                           cntR);
+        hipLaunchKernelGGL(mutual_right, dim3(cdiv(nR, 256)), dim3(256), 0, stream, idxLR, k2, idxRL, nR, k1, lpos2c,
+                           partR, cntR);
         BMX_LAUNCH_CHECK();
     }
 }
 
 void emit_pairs(hipStream_t stream, const int32_t* idxLR, int nL, int k2, const int32_t* idxRL, int k1,
-                const int32_t* offL, const int32_t* lrows, const int32_t* rrows, int32_t* first, int32_t* second) {
+                const int32_t* offL, const int32_t* lrows, const int32_t* rrows, int32_t* first, int32_t* second,
+                const int32_t* lsel) {
     if (nL <= 0) return;
     hipLaunchKernelGGL(emit_pairs_kernel, dim3(cdiv(nL, 256)), dim3(256), 0, stream, idxLR, nL, k2, idxRL, k1, offL,
-                       lrows, rrows, first, second);
+                       lsel, lrows, rrows, first, second);
+    BMX_LAUNCH_CHECK();
+}
+
+void select_listed_rows(hipStream_t stream, ScanWorkspace& ws, const int32_t* idx, int64_t n_entries, int n_rows,
+                        int32_t* flag, int32_t* off, int32_t* sel) {
+    BMX_HIP(hipMemsetAsync(flag, 0, (size_t)n_rows * sizeof(int32_t), stream));
+    if (n_entries > 0) {
+        hipLaunchKernelGGL(mark_listed, dim3(cdiv(n_entries, 256)), dim3(256), 0, stream, idx, n_entries, flag);
+        BMX_LAUNCH_CHECK();
+    }
+    exclusive_scan_i32(stream, ws, flag, off, n_rows);
+    hipLaunchKernelGGL(scatter_positions, dim3(cdiv(n_rows, 256)), dim3(256), 0, stream, flag, off, n_rows, sel);
+    BMX_LAUNCH_CHECK();
+}
+
+void compose_row_list(hipStream_t stream, const int32_t* sel, int n, const int32_t* rows, int32_t* out) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(compose_rows, dim3(cdiv(n, 256)), dim3(256), 0, stream, sel, n, rows, out);
     BMX_LAUNCH_CHECK();
 }
 
