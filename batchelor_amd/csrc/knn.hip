@@ -38,8 +38,9 @@ constexpr int MAX_CHUNKS = 8;
 // ---------------------------------------------------------------------------------------------------
 // column sums over a row list (two deterministic stages)
 // ---------------------------------------------------------------------------------------------------
+// (row i of the sum is row i * stride of the list: a strided sample when stride > 1)
 __global__ void colsum_partial(const double* __restrict__ X, const int32_t* __restrict__ rows, int n, int d,
-                               int rows_per_block, double* __restrict__ partial) {
+                               int rows_per_block, int stride, double* __restrict__ partial) {
     __shared__ double sm[4][64];
     const int c0 = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int r0 = blockIdx.x * rows_per_block;
@@ -49,7 +50,8 @@ __global__ void colsum_partial(const double* __restrict__ X, const int32_t* __re
         double s = 0.0;
         if (c < d)
             for (int r = r0 + rl; r < r1; r += 4) {
-                const int64_t row = rows ? rows[r] : r;
+                const int64_t rs = (int64_t)r * stride;
+                const int64_t row = rows ? rows[rs] : rs;
                 s += X[row * d + c];
             }
         sm[rl][c0] = s;
@@ -909,13 +911,16 @@ void knn_device(hipStream_t stream, KnnWorkspace& ws, const double* X, const int
         unsigned long long* seed =
             seeded ? reinterpret_cast<unsigned long long*>(ws.seed.reserve((size_t)nq_pad * (KS + 1))) : nullptr;
 
-        // reference mean (any centre is valid; the mean keeps the error bound tight)
-        const int rpb = 1024;
-        const int nb = cdiv(nr, rpb);
+        // centre of the reference: any vector is valid (the error bound uses the norms actually obtained), a point
+        // near the mean keeps it tight -- the mean of a strided sample of <= 16k rows costs next to nothing
+        const int cstride = std::max(1, nr / 16384);
+        const int ncs = cdiv(nr, cstride);
+        const int rpb = 256;
+        const int nb = cdiv(ncs, rpb);
         double* red = ws.red.reserve((size_t)nb * d);
-        hipLaunchKernelGGL(colsum_partial, dim3(nb), dim3(256), 0, stream, X, ref_rows, nr, d, rpb, red);
+        hipLaunchKernelGGL(colsum_partial, dim3(nb), dim3(256), 0, stream, X, ref_rows, ncs, d, rpb, cstride, red);
         BMX_LAUNCH_CHECK();
-        hipLaunchKernelGGL(colsum_final, dim3(cdiv(d, 64)), dim3(64), 0, stream, red, nb, d, 1.0 / nr, mean);
+        hipLaunchKernelGGL(colsum_final, dim3(cdiv(d, 64)), dim3(64), 0, stream, red, nb, d, 1.0 / ncs, mean);
         BMX_LAUNCH_CHECK();
         BMX_HIP(hipMemsetAsync(maxbits, 0, sizeof(unsigned long long), stream));
 

@@ -223,11 +223,14 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
                 publish(rc, t + 2 * NPROD);
             }
         }
-        // one empty tile past the end, so that the consumers' prefetch of "tile t + 1" needs no last-tile case
-        if (ntiles > 0 && ntiles % NPROD == p) {
-            const int slot = ntiles % NSLOT;
-            wait_free(ntiles, slot);
-            if (lane == 0) __hip_atomic_store(&ready[slot], ntiles + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // two empty tiles past the end: the consumers' loop runs one tile longer than the data (the selection of a
+        // tile happens under the MFMAs of the next one) and always prefetches "tile t + 1", with no last-tile case
+        for (int e = ntiles; e < ntiles + 2; ++e) {
+            if (ntiles > 0 && e % NPROD == p) {
+                const int slot = e % NSLOT;
+                wait_free(e, slot);
+                if (lane == 0) __hip_atomic_store(&ready[slot], e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
         }
         return;
     }
@@ -297,37 +300,44 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
         seen = lds_load_volatile(&ready[slot_n]);
     };
 
-    auto step = [&](const f32x4 (&cur)[NS], f32x4 (&nxt)[NS], const int t) {
+    // One step = the MFMA chain of tile t into `cur`, with three other things issued in the gaps of the chain (the
+    // wave cannot issue the next, dependent MFMA before the previous one is through the pipe): the refill of each
+    // fragment register with tile t + 1 right after the MFMA that read it (a single fragment set: a refill lands a
+    // whole tile period before its use), and the clean-tile filter of tile t - 1, whose products sit in `prev`.
+    f32x4 a[NS];
+    auto step = [&](f32x16& cur, const f32x16& prev, const int t) {
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
         spin_until_staged(t + 1);
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
-        read_tile(nxt);
-        f32x16 acc;
+        typedef __attribute__((address_space(3))) const char* lds_cptr;
+        typedef __attribute__((address_space(3))) const f32x4* lds_f4ptr;
+        lds_cptr tbase = (lds_cptr)ring + (slot_n * TILE_BYTES + lane * 16);
+        asm volatile("" : "+v"(tbase));     // the address is formed here, ...
+        __builtin_amdgcn_sched_barrier(0);  // ... outside the interleaved block below
+        const lds_f4ptr tp = (lds_f4ptr)tbase;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        for (int e = 0; e < 16; ++e) cur[e] = 0.f;
 #pragma unroll
-        for (int s = 0; s < NS; ++s)
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur[s]), bq[s], acc, 0, 0, 0);
-        // the wave cannot issue the next (dependent) MFMA before the previous one is through the pipe: the fragment
-        // reads of the next tile go into those gaps instead of in front of the chain
+        for (int s = 0; s < NS; ++s) {
+            cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[s]), bq[s], cur, 0, 0, 0);
+            a[s] = tp[s * 64];
+        }
+        // group minima (4 registers each), then the lane minimum, of the previous tile
+        float g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            g[u] = fminf(fminf(prev[4 * u], prev[4 * u + 1]), fminf(prev[4 * u + 2], prev[4 * u + 3]));
+        const float mn = fminf(fminf(g[0], g[1]), fminf(g[2], g[3]));
+        asm volatile("" ::"v"(mn), "v"(g[0]), "v"(g[1]), "v"(g[2]), "v"(g[3]));  // keep the filter in this block
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one LDS read
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // two VALU
         }
         hand_back(t + 1);
 
-        const int r0 = r_begin + (t << 5);
-#ifdef BMX_ABLATE_SELECT
-#pragma unroll
-        for (int e = 0; e < 16; ++e) asm volatile("" ::"v"(acc[e]));
-#else
-        // group minima (4 registers each), then the lane minimum: the common case leaves after ~12 VALU instructions
-        float g[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            g[u] = fminf(fminf(acc[4 * u], acc[4 * u + 1]), fminf(acc[4 * u + 2], acc[4 * u + 3]));
-        const float mn = fminf(fminf(g[0], g[1]), fminf(g[2], g[3]));
+        const int r0 = r_begin + ((t - 1) << 5);  // the tile whose products are in `prev`
 #ifdef BMX_ABLATE_EVENTS
         if (!SAMPLE) { asm volatile("" ::"v"(mn)); return; }
 #endif
@@ -379,7 +389,7 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
                 const int rbase = r0 + 8 * u + 4 * h;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float v = acc[4 * u + e];
+                    const float v = prev[4 * u + e];
                     const bool pass = v < tau;
                     uint32_t* dst = reinterpret_cast<uint32_t*>(pend + (pass ? mycnt : PL - 1));
                     dst[0] = (uint32_t)(rbase + e);
@@ -392,28 +402,31 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
 #ifdef BMX_STAMPS
         dbg_evc += STAMP() - dbg_e0;
 #endif
-#endif
     };
 
-    f32x4 a0[NS], a1[NS];
+    f32x16 accA, accB;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) accA[e] = accB[e] = __builtin_inff();  // "previous tile" of step 0: nothing passes
     if (ntiles > 0) {
         spin_until_staged(0);
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
-        read_tile(a0);
+        read_tile(a);
         hand_back(0);
-    }
-    // two tiles per iteration so that the fragment registers ping-pong statically
-    for (int t2 = 0; t2 < ntiles; t2 += 2) {
-        if constexpr (!SAMPLE) {
-            // periodic refresh of the shared threshold: the (L1-bypassing) load is issued here and looked at one
-            // iteration later, so nobody waits for the round trip
-            if (shared_tau) {
-                if ((t2 & 15) == 2) tau = fminf(tau, orderable_f32(tau_fetch));
-                if ((t2 & 15) == 0) tau_fetch = __hip_atomic_load(&tau_g[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // steps 0 .. ntiles: step t multiplies tile t (step ntiles: an empty tile, product unused) and filters tile
+        // t - 1; two steps per iteration so that the two accumulators alternate statically
+        for (int t2 = 0; t2 <= ntiles; t2 += 2) {
+            if constexpr (!SAMPLE) {
+                // periodic refresh of the shared threshold: the (L1-bypassing) load is issued here and looked at one
+                // iteration later, so nobody waits for the round trip
+                if (shared_tau) {
+                    if ((t2 & 15) == 2) tau = fminf(tau, orderable_f32(tau_fetch));
+                    if ((t2 & 15) == 0)
+                        tau_fetch = __hip_atomic_load(&tau_g[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
+            step(accA, accB, t2);
+            if (t2 + 1 <= ntiles) step(accB, accA, t2 + 1);
         }
-        step(a0, a1, t2);
-        if (t2 + 1 < ntiles) step(a1, a0, t2 + 1);
     }
 
 #ifdef BMX_STAMPS
