@@ -840,7 +840,7 @@ void knn_device(hipStream_t stream, KnnWorkspace& ws, const double* X, const int
         ws.last_variant = variant;
         const int ncons = variant == 2 ? bf16_ncons(NS, KS) : 0;
         const int unit = variant == 2 ? 32 * ncons : (variant == 1 ? 32 : QB);  // queries per workgroup
-        const int nq_pad = (int)round_up(nq, 256);
+        const int nq_pad = (int)round_up(nq, variant == 2 ? unit : 256);
         const int nqb = nq_pad / unit;
         const int rmul = variant == 2 ? 32 : RT;  // range lengths are multiples of the kernels' tile step
 
@@ -857,8 +857,7 @@ void knn_device(hipStream_t stream, KnnWorkspace& ws, const double* X, const int
                 w_hi = std::min(KP <= 64 ? 16 : 12, (160 * 1024) / (32 * (KS + 2 * PL) * 8 + 256));
                 w_lo = std::min(8, w_hi);
             } else if (variant == 2) {
-                const size_t lds = (size_t)4 * NS * 1024 + (size_t)ncons * 32 * (KS + 2 * PL) * 8 + ncons * 256 + 64;
-                fixed_slots = 256 * std::max<int>(1, std::min<size_t>((160 * 1024) / lds, 32 / (ncons + 4)));
+                fixed_slots = 256;  // the ring kernel takes a CU's whole LDS: one workgroup per CU
             } else {
                 fixed_slots = topk_lds_for(KP, KS) <= 80 * 1024 ? 512 : 256;
             }

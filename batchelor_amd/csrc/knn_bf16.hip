@@ -27,7 +27,17 @@ namespace {
 using namespace sel;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int NPROD = 4;  // producer waves; producer p stages tiles p, p + 4, ... into ring slot (tile % NSLOT)
+// Workgroup shape per (fragment count, list size): NCONS consumer waves of 32 queries, NPROD producer waves (producer p
+// stages tiles p, p + NPROD, ... into ring slot tile % NSLOT), PLN entries per lane-private pending list.
+// 8 + 4 puts two consumers and one producer on every SIMD.  Measured alternatives at 100k x 100k, d = 50 (cycles per
+// tile per consumer wave, 1480 for 8 + 4): 9 + 3 -> 1750, 10 + 2 -> 1940 -- the SIMDs that get a third consumer fall
+// behind and the ring makes everybody else wait for them, so more queries per CU did not pay.
+struct RingShape {
+    int ncons, nprod, pln;
+};
+__host__ __device__ constexpr RingShape ring_shape(int NS, int KS) {
+    return (NS <= 10 && KS == 24) ? RingShape{8, 4, 12} : RingShape{4, 4, 12};
+}
 
 __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
     uint32_t u = __float_as_uint(f);
@@ -126,8 +136,8 @@ __global__ __launch_bounds__(256) void knn_prep_bf16(const double* __restrict__ 
 // Ring depth: as many staged tiles as the LDS left over by the candidate lists holds (at most 8).  The consumers of a
 // workgroup stall at different times (a compaction costs a couple of tile times); the deeper the ring, the less one
 // consumer's stall holds up the others.
-__host__ __device__ constexpr int ring_slots(int NS, int KS, int NCONS) {
-    const int rest = 160 * 1024 - NCONS * 32 * list_pitch(KS) * 8 - 320;
+__host__ __device__ constexpr int ring_slots(int NS, int KS, int NCONS, int PLN) {
+    const int rest = 160 * 1024 - NCONS * 32 * list_pitch(KS, PLN) * 8 - 512;
     const int n = rest / (NS * 1024);
     return n > 8 ? 8 : n;
 }
@@ -147,16 +157,16 @@ __device__ __forceinline__ int lds_load_volatile(const int* p) { return __hip_at
 // range benefits from what the others have already found and extra ranges cost no extra selection work.  Each
 // range's threshold is an upper bound of the KS-th nearest reference overall, hence so is their minimum; a stale
 // read only leaves the filter looser, never wrong.
-template <int NS, int KS, int NCONS, bool SAMPLE>
+template <int NS, int KS, int NCONS, int NPROD, int PL, bool SAMPLE>
 __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
     const uint16_t* __restrict__ Pq, const uint16_t* __restrict__ PrF, int first_begin, int range_len, int r_limit,
     int out_chunk0, int out_nchunks, uint32_t* __restrict__ tau_g, int32_t* __restrict__ cand,
     float* __restrict__ cand_v, float* __restrict__ tau_out) {
     constexpr int CAP = KS + 2 * PL;
-    constexpr int PITCH = list_pitch(KS);
+    constexpr int PITCH = list_pitch(KS, PL);
     constexpr int NQ = NCONS * 32;
     constexpr int TILE_BYTES = NS * 1024;
-    constexpr int NSLOT = ring_slots(NS, KS, NCONS);
+    constexpr int NSLOT = ring_slots(NS, KS, NCONS, PL);
     static_assert(CAP <= 64, "one candidate per lane during compaction");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -358,7 +368,7 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
                 while (fm) {
                     const int jj = __builtin_ctzll(fm);
                     fm &= fm - 1;
-                    compact_regs<KS>(buf, wave * 32 + jj, jj, lane, mycnt, nk, tau);
+                    compact_regs<KS, PL>(buf, wave * 32 + jj, jj, lane, mycnt, nk, tau);
                 }
                 if constexpr (!SAMPLE) {
                     // publish this list's threshold (fire and forget; what the other ranges publish is picked up by
@@ -444,7 +454,7 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
         atomicAdd(&bmx_dbg[10], dbg_evc);
     }
 #endif
-    for (int jj = 0; jj < 32; ++jj) compact_regs<KS>(buf, wave * 32 + jj, jj, lane, mycnt, nk, tau);
+    for (int jj = 0; jj < 32; ++jj) compact_regs<KS, PL>(buf, wave * 32 + jj, jj, lane, mycnt, nk, tau);
     if constexpr (SAMPLE) {
         if (h == 0) tau_g[q] = f32_orderable(tau);
         return;
@@ -470,15 +480,18 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
     }
 }
 
-template <int NS, int KS, int NCONS>
+template <int NS, int KS>
 void launch(hipStream_t stream, KnnWorkspace& ws, const Bf16Launch& L) {
-    constexpr size_t lds = (size_t)ring_slots(NS, KS, NCONS) * NS * 1024 + (size_t)NCONS * 32 * list_pitch(KS) * 8 + 320;
+    constexpr RingShape SH = ring_shape(NS, KS);
+    constexpr int NCONS = SH.ncons, NPROD = SH.nprod, PLN = SH.pln;
+    constexpr size_t lds = (size_t)ring_slots(NS, KS, NCONS, PLN) * NS * 1024 +
+                           (size_t)NCONS * 32 * list_pitch(KS, PLN) * 8 + 512;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set) {
-        BMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_topk_bf16<NS, KS, NCONS, false>),
+        BMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_topk_bf16<NS, KS, NCONS, NPROD, PLN, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        BMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_topk_bf16<NS, KS, NCONS, true>),
+        BMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_topk_bf16<NS, KS, NCONS, NPROD, PLN, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
@@ -488,11 +501,11 @@ void launch(hipStream_t stream, KnnWorkspace& ws, const Bf16Launch& L) {
         BMX_HIP(hipEventRecord(ev.first, stream));
     }
     if (L.sample)
-        hipLaunchKernelGGL((knn_topk_bf16<NS, KS, NCONS, true>), dim3(L.nqb, L.nranges), dim3((NCONS + NPROD) * 64),
+        hipLaunchKernelGGL((knn_topk_bf16<NS, KS, NCONS, NPROD, PLN, true>), dim3(L.nqb, L.nranges), dim3((NCONS + NPROD) * 64),
                            lds, stream, L.pq, L.pr, L.first_begin, L.range_len, L.r_limit, L.out_chunk0, L.out_nchunks,
                            L.tau_g, L.cand, L.cand_v, L.tau);
     else
-        hipLaunchKernelGGL((knn_topk_bf16<NS, KS, NCONS, false>), dim3(L.nqb, L.nranges), dim3((NCONS + NPROD) * 64),
+        hipLaunchKernelGGL((knn_topk_bf16<NS, KS, NCONS, NPROD, PLN, false>), dim3(L.nqb, L.nranges), dim3((NCONS + NPROD) * 64),
                            lds, stream, L.pq, L.pr, L.first_begin, L.range_len, L.r_limit, L.out_chunk0, L.out_nchunks,
                            L.tau_g, L.cand, L.cand_v, L.tau);
     BMX_LAUNCH_CHECK();
@@ -520,7 +533,7 @@ int bf16_pick_ns(int d) {
     return 0;
 }
 
-int bf16_ncons(int NS, int KS) { return (NS <= 10 && KS == 24) ? 8 : 4; }
+int bf16_ncons(int NS, int KS) { return ring_shape(NS, KS).ncons; }
 
 void bf16_prep(hipStream_t stream, const double* X, const int32_t* rows, int n, int n_pad, int d, int NS,
                const double* mean, int is_query, uint16_t* P, double* n2, unsigned long long* maxbits) {
@@ -531,19 +544,14 @@ void bf16_prep(hipStream_t stream, const double* X, const int32_t* rows, int n, 
 }
 
 bool bf16_launch(hipStream_t stream, KnnWorkspace& ws, int NS, int KS, const Bf16Launch& L) {
-#define BMX_CASE(N)                                                \
-    case N:                                                        \
-        if (KS == 24) {                                            \
-            if constexpr (N <= 10)                                 \
-                launch<N, 24, 8>(stream, ws, L);                   \
-            else                                                   \
-                launch<N, 24, 4>(stream, ws, L);                   \
-        } else {                                                   \
-            if constexpr (N <= 16)                                 \
-                launch<N, 40, 4>(stream, ws, L);                   \
-            else                                                   \
-                return false;                                      \
-        }                                                          \
+#define BMX_CASE(N)                        \
+    case N:                                \
+        if (KS == 24)                      \
+            launch<N, 24>(stream, ws, L);  \
+        else if constexpr (N <= 16)        \
+            launch<N, 40>(stream, ws, L);  \
+        else                               \
+            return false;                  \
         return true;
     switch (NS) {
         BMX_CASE(1)

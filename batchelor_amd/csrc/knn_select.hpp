@@ -26,7 +26,7 @@ __device__ __forceinline__ float orderable_f32(uint32_t o) {
 constexpr int PL = 12;
 // Row pitch of a query's list in 8-byte entries (register-state variant): one more than the capacity, so that the
 // lists of neighbouring queries start 2 banks apart and the appends of a wave's lanes do not pile up on one bank pair.
-__host__ __device__ constexpr int list_pitch(int KS) { return KS + 2 * PL + 1; }
+__host__ __device__ constexpr int list_pitch(int KS, int PLN) { return KS + 2 * PLN + 1; }
 
 template <int KS>
 __device__ __forceinline__ void compact_slot(unsigned long long* buf, int* kcnt, float* tau_s, int slot, int jj,
@@ -64,17 +64,17 @@ __device__ __forceinline__ void compact_slot(unsigned long long* buf, int* kcnt,
 // broadcast by readlane in 8-entry chunks with constant lane numbers.
 // Values closer than 2^-16 relative may therefore swap places at the cut; the new threshold is the cut key with the
 // lane bits cleared, which is <= the value of everything dropped, so "rejected => value >= tau" still holds exactly.
-template <int KS>
+template <int KS, int PLN>
 __device__ __forceinline__ void compact_regs(unsigned long long* buf, int slot, int jj, int lane, int& mycnt, int& nk_reg,
                                              float& tau) {
-    constexpr int CAP = KS + 2 * PL;
+    constexpr int CAP = KS + 2 * PLN;
     const int nk = __builtin_amdgcn_readlane(nk_reg, jj);
     const int n0 = __builtin_amdgcn_readlane(mycnt, jj);
     const int n1 = __builtin_amdgcn_readlane(mycnt, jj + 32);
     const int n = nk + n0 + n1;
-    unsigned long long* b = buf + slot * list_pitch(KS);
+    unsigned long long* b = buf + slot * list_pitch(KS, PLN);
     int src = lane;  // kept entries sit at [0, nk)
-    if (lane >= nk) src = lane < nk + n0 ? KS + (lane - nk) : KS + PL + (lane - nk - n0);
+    if (lane >= nk) src = lane < nk + n0 ? KS + (lane - nk) : KS + PLN + (lane - nk - n0);
     const unsigned long long raw = lane < n ? b[src] : 0ull;
     const uint32_t key =
         lane < n ? (((f32_orderable(__uint_as_float((uint32_t)(raw >> 32))) >> 1) & ~63u) | (uint32_t)lane) : 0x7FFFFFFFu;
