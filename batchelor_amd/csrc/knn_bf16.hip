@@ -148,10 +148,12 @@ __device__ unsigned long long bmx_dbg[16];
 #endif
 __device__ __forceinline__ int lds_load_volatile(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-// SAMPLE = true: threshold estimation only.  Each (tile, lane-half) contributes the minimum of its 16 values as ONE
-// candidate; the KS-th smallest of these group minima bounds the KS-th nearest reference from above (they are KS
-// distinct references), so it is a valid starting threshold for the full pass.  Nothing else is kept: the full pass
-// rescans the sample rows.  Output: tau_g[q] (order-preserving integer image of the threshold).
+// SAMPLE = true: threshold estimation only, entirely in registers and branch-free.  Each (tile, lane) contributes the
+// minimum of its 16 values as ONE candidate; a lane keeps the KS/2 smallest of its candidates in a sorted register
+// list (one min/max pair per entry and tile, issued in the gaps of the MFMA chain).  The two lanes of a query thus
+// hold KS distinct references, so the larger of their two last entries bounds the KS-th nearest reference from
+// above: a valid starting threshold for the full pass.  Nothing else is kept (the full pass rescans the sample
+// rows), no list in the LDS is touched.  Output: tau_g[q] (order-preserving integer image of the threshold).
 // SAMPLE = false: the full pass.  tau_g[q] is SHARED by all reference ranges of query q: every workgroup folds its
 // own list's threshold into it (atomicMin) whenever it compacts, and refreshes its working threshold from it, so a
 // range benefits from what the others have already found and extra ranges cost no extra selection work.  Each
@@ -315,6 +317,9 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
     // fragment register with tile t + 1 right after the MFMA that read it (a single fragment set: a refill lands a
     // whole tile period before its use), and the clean-tile filter of tile t - 1, whose products sit in `prev`.
     f32x4 a[NS];
+    uint32_t best[SAMPLE ? KS / 2 : 1];
+#pragma unroll
+    for (int i = 0; i < (SAMPLE ? KS / 2 : 1); ++i) best[i] = 0xFF800000u;  // image of +inf
     auto step = [&](f32x16& cur, const f32x16& prev, const int t) {
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
         spin_until_staged(t + 1);
@@ -338,14 +343,28 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
         for (int u = 0; u < 4; ++u)
             g[u] = fminf(fminf(prev[4 * u], prev[4 * u + 1]), fminf(prev[4 * u + 2], prev[4 * u + 3]));
         const float mn = fminf(fminf(g[0], g[1]), fminf(g[2], g[3]));
-        asm volatile("" ::"v"(mn), "v"(g[0]), "v"(g[1]), "v"(g[2]), "v"(g[3]));  // keep the filter in this block
+        if constexpr (SAMPLE) {
+            // sorted insertion on the order-preserving integer images (integer min/max need no NaN canonicalisation);
+            // at step 0 `prev` is +inf and changes nothing
+            uint32_t x = f32_orderable(mn);
+#pragma unroll
+            for (int i = 0; i < KS / 2; ++i) {
+                const uint32_t lo = min(best[i], x);
+                x = max(best[i], x);
+                best[i] = lo;
+            }
+            asm volatile("" ::"v"(best[KS / 2 - 1]));  // keep it in this block
+        } else {
+            asm volatile("" ::"v"(mn), "v"(g[0]), "v"(g[1]), "v"(g[2]), "v"(g[3]));  // keep the filter in this block
+        }
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one LDS read
-            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // two VALU
+            __builtin_amdgcn_sched_group_barrier(0x002, SAMPLE ? 2 + (KS + NS - 1) / NS : 2, 0);  // a share of the VALU
         }
         hand_back(t + 1);
+        if constexpr (SAMPLE) return;
 
         const int r0 = r_begin + ((t - 1) << 5);  // the tile whose products are in `prev`
 #ifdef BMX_ABLATE_EVENTS
@@ -380,13 +399,7 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
 #endif
             }
         };
-        if constexpr (SAMPLE) {
-            if (mn < tau) {
-                pend[mycnt] = ((unsigned long long)__float_as_uint(mn) << 32) | (uint32_t)(r0 + 4 * h);
-                ++mycnt;
-            }
-            flush_full();
-        } else {
+        {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (__builtin_amdgcn_ballot_w64(g[u] < tau) == 0) continue;
@@ -454,11 +467,12 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
         atomicAdd(&bmx_dbg[10], dbg_evc);
     }
 #endif
-    for (int jj = 0; jj < 32; ++jj) compact_regs<KS, PL>(buf, wave * 32 + jj, jj, lane, mycnt, nk, tau);
     if constexpr (SAMPLE) {
-        if (h == 0) tau_g[q] = f32_orderable(tau);
+        const uint32_t mine = best[KS / 2 - 1], other = __shfl_xor(mine, 32);
+        if (h == 0) tau_g[q] = max(mine, other);
         return;
     }
+    for (int jj = 0; jj < 32; ++jj) compact_regs<KS, PL>(buf, wave * 32 + jj, jj, lane, mycnt, nk, tau);
     for (int jj = 0; jj < 32; ++jj) {
         const int s = wave * 32 + jj;
         const int qq = blockIdx.x * NQ + s;
