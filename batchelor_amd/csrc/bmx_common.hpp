@@ -111,6 +111,7 @@ struct Bf16Launch {
     int32_t* cand;
     float* cand_v;          // approximate values of the candidates (null: not needed, single range)
     float* tau;
+    int n_full = 0;         // the first n_full query blocks sweep [first_begin, r_limit) as ONE range; the others split it
 };
 int bf16_pick_ns(int d);         // MFMA k-steps (16 bf16 each) for 3 d + 3 columns; 0 = unsupported
 int bf16_ncons(int NS, int KS);  // consumer waves (32 queries each) per workgroup

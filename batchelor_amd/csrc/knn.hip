@@ -882,7 +882,32 @@ void knn_device(hipStream_t stream, KnnWorkspace& ws, const double* X, const int
                     }
                 }
         }
-        if (std::getenv("BMX_FORCE_C")) C = std::atoi(std::getenv("BMX_FORCE_C"));
+        // Split-bf16 ring kernel: one workgroup per CU.  The query blocks that fill whole rounds of 256 workgroups
+        // sweep the reference as ONE range (tightest thresholds, one list per query); only the remaining b blocks are
+        // split into c ranges, chosen so that their b*c short items fill the last round evenly.  Measured work per
+        // pair evaluation relative to one range (100k x 400k): 3 ranges 1.12, 5: 1.17, 7: 1.21 ~ 1 + 0.105 ln c.
+        int n_full = 0;
+        if (variant == 2) {
+            const int a = nqb / 256, b = nqb % 256;
+            n_full = a * 256;
+            C = 1;
+            if (b > 0) {
+                double best = 1e30;
+                for (int c = 1; c <= MAX_CHUNKS - 1; ++c) {
+                    if (c > 1 && nr / c < 2048) break;
+                    const double tail = std::ceil((double)b * c / 256.0) / c * (1.0 + 0.105 * std::log((double)c));
+                    if (tail < best - 1e-9) {
+                        best = tail;
+                        C = c;
+                    }
+                }
+            }
+        }
+        if (variant == 2 && std::getenv("BMX_SPLIT_C")) C = std::max(1, std::atoi(std::getenv("BMX_SPLIT_C")));
+        if (std::getenv("BMX_FORCE_C")) {
+            C = std::atoi(std::getenv("BMX_FORCE_C"));
+            n_full = 0;
+        }
         const int main_rows = variant == 2 ? nr : nr - S;  // the bf16 full pass rescans the sample rows
         const int chunk_len = (int)round_up(cdiv(main_rows, C), rmul);
         C = std::max(1, cdiv(main_rows, chunk_len));
@@ -890,8 +915,8 @@ void knn_device(hipStream_t stream, KnnWorkspace& ws, const double* X, const int
         const bool seeded = variant == 1 && S > 0;
         const int nchunks = C + (S > 0 && variant == 0 ? 1 : 0);  // only variant 0 keeps the sample as its own column
         if (std::getenv("BMX_DEBUG"))
-            fprintf(stderr, "[bmx] knn nq=%d nr=%d d=%d KS=%d variant=%d S=%d C=%d W=%d chunk=%d\n", nq, nr, d, KS,
-                    variant, S, C, W, chunk_len);
+            fprintf(stderr, "[bmx] knn nq=%d nr=%d d=%d KS=%d variant=%d S=%d C=%d W=%d chunk=%d full-range blocks=%d of %d\n",
+                    nq, nr, d, KS, variant, S, C, W, chunk_len, C > 1 ? n_full : nqb, nqb);
         int lds_pad = 0;
         if (variant == 1) {
             const int base = 32 * (KS + 2 * PL) * 8 + 256;
@@ -943,6 +968,7 @@ void knn_device(hipStream_t stream, KnnWorkspace& ws, const double* X, const int
             L.first_begin = 0;
             L.range_len = chunk_len;
             L.nranges = C;
+            L.n_full = C > 1 ? n_full : 0;
             L.r_limit = nr_pad;
             L.sample = 0;
             ok = ok && bf16_launch(stream, ws, NS, KS, L);

@@ -162,7 +162,7 @@ __device__ __forceinline__ int lds_load_volatile(const int* p) { return __hip_at
 template <int NS, int KS, int NCONS, int NPROD, int PL, bool SAMPLE>
 __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
     const uint16_t* __restrict__ Pq, const uint16_t* __restrict__ PrF, int first_begin, int range_len, int r_limit,
-    int out_chunk0, int out_nchunks, uint32_t* __restrict__ tau_g, int32_t* __restrict__ cand,
+    int n_full, int nranges, int out_chunk0, int out_nchunks, uint32_t* __restrict__ tau_g, int32_t* __restrict__ cand,
     float* __restrict__ cand_v, float* __restrict__ tau_out) {
     constexpr int CAP = KS + 2 * PL;
     constexpr int PITCH = list_pitch(KS, PL);
@@ -178,10 +178,21 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
     int* done = ready + NSLOT;                                                                // [NSLOT][NCONS]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r_begin = first_begin + blockIdx.y * range_len;
-    const int r_end = min(r_limit, r_begin + range_len);
+    // work items in launch order: first the query blocks that sweep the whole reference as one range (best selection
+    // efficiency), then the remaining query blocks split into `nranges` ranges each (short items that fill the last
+    // round of workgroups evenly)
+    int qblock = blockIdx.x, rng = 0, nrng = 1, r_begin = first_begin, r_end = r_limit;
+    if ((int)blockIdx.x >= n_full) {
+        // range-major: the workgroups in flight at any time stream the same stretch of the reference (L2 reuse)
+        const int nsplit = (gridDim.x - n_full) / nranges, j = blockIdx.x - n_full;
+        rng = j / nsplit;
+        qblock = n_full + (j - rng * nsplit);
+        nrng = nranges;
+        r_begin = first_begin + rng * range_len;
+        r_end = min(r_limit, r_begin + range_len);
+    }
     const int ntiles = (r_end - r_begin) >> 5;
-    const int out_chunk = out_chunk0 + blockIdx.y;
+    const int out_chunk = out_chunk0 + rng;
     if (tid < NSLOT * (1 + NCONS)) ready[tid] = 0;  // ready[] and done[] are contiguous
     __syncthreads();
 
@@ -250,7 +261,7 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
     // ---------------------------------------------------------------------- consumer
     const int j = lane & 31, h = lane >> 5;
     const int qs = wave * 32 + j;
-    const int q = blockIdx.x * NQ + qs;
+    const int q = qblock * NQ + qs;
 
     float tau = (!SAMPLE && tau_g) ? orderable_f32(tau_g[q]) : __builtin_inff();
     int nk = 0;  // entries in this query's kept list (the same in both of its lanes, like tau)
@@ -277,7 +288,7 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
     // The explicit lgkmcnt(0) at the top of every tile is free (everything queued is a tile old, the fragments of
     // tile t included) and leaves the compiler's wait-count pass with nothing pending: without it the pass makes the
     // MFMAs of tile t wait for the reads of tile t + 1 issued just before them.
-    const bool shared_tau = !SAMPLE && tau_g != nullptr && gridDim.y > 1;
+    const bool shared_tau = !SAMPLE && tau_g != nullptr && nrng > 1;
     uint32_t tau_fetch = 0xFFFFFFFFu;
     int seen = 0;
     int slot_n = 0;  // slot of the tile to read next
@@ -475,7 +486,7 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
     for (int jj = 0; jj < 32; ++jj) compact_regs<KS, PL>(buf, wave * 32 + jj, jj, lane, mycnt, nk, tau);
     for (int jj = 0; jj < 32; ++jj) {
         const int s = wave * 32 + jj;
-        const int qq = blockIdx.x * NQ + s;
+        const int qq = qblock * NQ + s;
         const int n = __builtin_amdgcn_readlane(nk, jj);
         // what this range rejected was rejected against thresholds >= the final working threshold of its lane pair;
         // kept entries at or above that threshold are as good as rejected (another range holds KS better ones), so
@@ -486,11 +497,17 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
         if (lane < KS) {
             const unsigned long long key = buf[s * PITCH + lane];
             const float val = __uint_as_float((uint32_t)(key >> 32));
-            const bool keep = lane < n && (val < eff || out_nchunks == 1);
+            const bool keep = lane < n && (val < eff || nrng == 1);
             cand[((int64_t)qq * out_nchunks + out_chunk) * KS + lane] = keep ? (int32_t)(uint32_t)key : -1;
             if (cand_v) cand_v[((int64_t)qq * out_nchunks + out_chunk) * KS + lane] = val;
         }
         if (lane == 0) tau_out[(int64_t)qq * out_nchunks + out_chunk] = eff;
+        if (nrng == 1) {  // a whole-reference item owns every list column of its queries: the others stay empty
+            for (int c = 1; c < out_nchunks; ++c) {
+                if (lane < KS) cand[((int64_t)qq * out_nchunks + out_chunk + c) * KS + lane] = -1;
+                if (lane == 0) tau_out[(int64_t)qq * out_nchunks + out_chunk + c] = __builtin_inff();
+            }
+        }
     }
 }
 
@@ -514,13 +531,16 @@ void launch(hipStream_t stream, KnnWorkspace& ws, const Bf16Launch& L) {
         ev = ws.next_events();
         BMX_HIP(hipEventRecord(ev.first, stream));
     }
+    const int items = L.n_full + (L.nqb - L.n_full) * L.nranges;
     if (L.sample)
-        hipLaunchKernelGGL((knn_topk_bf16<NS, KS, NCONS, NPROD, PLN, true>), dim3(L.nqb, L.nranges), dim3((NCONS + NPROD) * 64),
-                           lds, stream, L.pq, L.pr, L.first_begin, L.range_len, L.r_limit, L.out_chunk0, L.out_nchunks,
+        hipLaunchKernelGGL((knn_topk_bf16<NS, KS, NCONS, NPROD, PLN, true>), dim3(items), dim3((NCONS + NPROD) * 64),
+                           lds, stream, L.pq, L.pr, L.first_begin, L.range_len, L.r_limit, L.n_full, L.nranges,
+                           L.out_chunk0, L.out_nchunks,
                            L.tau_g, L.cand, L.cand_v, L.tau);
     else
-        hipLaunchKernelGGL((knn_topk_bf16<NS, KS, NCONS, NPROD, PLN, false>), dim3(L.nqb, L.nranges), dim3((NCONS + NPROD) * 64),
-                           lds, stream, L.pq, L.pr, L.first_begin, L.range_len, L.r_limit, L.out_chunk0, L.out_nchunks,
+        hipLaunchKernelGGL((knn_topk_bf16<NS, KS, NCONS, NPROD, PLN, false>), dim3(items), dim3((NCONS + NPROD) * 64),
+                           lds, stream, L.pq, L.pr, L.first_begin, L.range_len, L.r_limit, L.n_full, L.nranges,
+                           L.out_chunk0, L.out_nchunks,
                            L.tau_g, L.cand, L.cand_v, L.tau);
     BMX_LAUNCH_CHECK();
     if (ws.profile) BMX_HIP(hipEventRecord(ev.second, stream));
