@@ -142,8 +142,11 @@ __host__ __device__ constexpr int ring_slots(int NS, int KS, int NCONS, int PLN)
     return n > 8 ? 8 : n;
 }
 
+#ifndef BMX_YIELD_TILES
+#define BMX_YIELD_TILES 8
+#endif
 #ifdef BMX_STAMPS
-__device__ unsigned long long bmx_dbg[16];
+__device__ unsigned long long bmx_dbg[48];
 #define STAMP() __builtin_readcyclecounter()
 #endif
 __device__ __forceinline__ int lds_load_volatile(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -177,7 +180,8 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
     int* ready = reinterpret_cast<int*>(buf + NQ * PITCH);                                     // [NSLOT]
     int* done = ready + NSLOT;                                                                // [NSLOT][NCONS]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: branches on it are scalar
     // work items in launch order: first the query blocks that sweep the whole reference as one range (best selection
     // efficiency), then the remaining query blocks split into `nranges` ranges each (short items that fill the last
     // round of workgroups evenly)
@@ -209,9 +213,22 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
         // tile t goes to slot t % NSLOT once every consumer has read the tile staged there NSLOT tiles earlier (that
         // tile may have come from another producer: the consumers' done words order the two).  done[slot][c] is the
         // number of the last tile consumer c has read from the slot, plus one.
+#ifdef BMX_STAMPS
+        unsigned long long dbg_pw = 0, dbg_pt0 = STAMP();
+#endif
         auto wait_free = [&](int t, int slot) {
             if (t < NSLOT) return;
             const int need = t - NSLOT + 1;
+#ifdef BMX_STAMPS
+            const unsigned long long s0 = STAMP();
+            for (;;) {
+                const int v = lane < NCONS ? lds_load_volatile(&done[slot * NCONS + lane]) : need;
+                if (__builtin_amdgcn_ballot_w64(v < need) == 0) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            dbg_pw += STAMP() - s0;
+            return;
+#endif
             for (;;) {
                 const int v = lane < NCONS ? lds_load_volatile(&done[slot * NCONS + lane]) : need;
                 if (__builtin_amdgcn_ballot_w64(v < need) == 0) break;
@@ -255,6 +272,12 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
                 if (lane == 0) __hip_atomic_store(&ready[slot], e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
+#ifdef BMX_STAMPS
+        if (!SAMPLE && lane == 0) {
+            atomicAdd(&bmx_dbg[32 + p], dbg_pw);
+            atomicAdd(&bmx_dbg[36 + p], STAMP() - dbg_pt0);
+        }
+#endif
         return;
     }
 
@@ -292,9 +315,12 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
     uint32_t tau_fetch = 0xFFFFFFFFu;
     int seen = 0;
     int slot_n = 0;  // slot of the tile to read next
+    int yield_tiles = 0;
+    constexpr int YIELD = BMX_YIELD_TILES;
     auto spin_until_staged = [&](int tile) {
 #ifdef BMX_STAMPS
-        if (seen < tile + 1) {
+        if (__builtin_amdgcn_readfirstlane(seen) < tile + 1) {
+            yield_tiles = YIELD;
             const unsigned long long s0 = STAMP();
             ++dbg_nspin;
             while (seen < tile + 1) {
@@ -304,9 +330,12 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
             dbg_spin += STAMP() - s0;
         }
 #else
-        while (seen < tile + 1) {
-            __builtin_amdgcn_s_sleep(1);
-            seen = lds_load_volatile(&ready[slot_n]);
+        if (__builtin_amdgcn_readfirstlane(seen) < tile + 1) {
+            yield_tiles = YIELD;
+            do {
+                __builtin_amdgcn_s_sleep(1);
+                seen = lds_load_volatile(&ready[slot_n]);
+            } while (seen < tile + 1);
         }
 #endif
     };
@@ -331,7 +360,17 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
     uint32_t best[SAMPLE ? KS / 2 : 1];
 #pragma unroll
     for (int i = 0; i < (SAMPLE ? KS / 2 : 1); ++i) best[i] = 0xFF800000u;  // image of +inf
-    auto step = [&](f32x16& cur, const f32x16& prev, const int t) {
+    auto step = [&](f32x16& cur, const f32x16& prev, const int t, const int phase) {
+        // Each SIMD hosts consumers w and w + 4; instruction arbitration goes by priority, then age, so at equal
+        // priority the younger half (w >= 4) loses every contested slot, falls behind, and the older half waits for
+        // it at the ring (measured: 290 vs 50 cycles of ring wait per tile).  A consumer that had to wait for the
+        // ring is ahead of the others: it yields (priority 0) for the next few tiles, everybody else runs at 1.
+        if (yield_tiles > 0) {
+            __builtin_amdgcn_s_setprio(0);
+            --yield_tiles;
+        } else {
+            __builtin_amdgcn_s_setprio(1);
+        }
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
         spin_until_staged(t + 1);
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
@@ -458,8 +497,8 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
                         tau_fetch = __hip_atomic_load(&tau_g[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
-            step(accA, accB, t2);
-            if (t2 + 1 <= ntiles) step(accB, accA, t2 + 1);
+            step(accA, accB, t2, 0);
+            if (t2 + 1 <= ntiles) step(accB, accA, t2 + 1, 1);
         }
     }
 
@@ -476,6 +515,8 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
         atomicAdd(&bmx_dbg[8], (unsigned long long)ntiles);
         atomicAdd(&bmx_dbg[9], 1ull);
         atomicAdd(&bmx_dbg[10], dbg_evc);
+        atomicAdd(&bmx_dbg[16 + wave], dbg_spin);
+        atomicAdd(&bmx_dbg[24 + wave], dbg_flush);
     }
 #endif
     if constexpr (SAMPLE) {
@@ -546,13 +587,20 @@ void launch(hipStream_t stream, KnnWorkspace& ws, const Bf16Launch& L) {
     if (ws.profile) BMX_HIP(hipEventRecord(ev.second, stream));
 #ifdef BMX_STAMPS
     if (!L.sample) {
-        unsigned long long h[16];
+        unsigned long long h[48];
         BMX_HIP(hipStreamSynchronize(stream));
         BMX_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(bmx_dbg), sizeof(h)));
         const double w = (double)h[9], nt = (double)h[8];
         fprintf(stderr, "[stamps] waves=%.0f tiles/wave=%.0f cyc/tile=%.0f spin/tile=%.0f flush/tile=%.0f nspin/tile=%.3f nflush/tile=%.3f ncomp/tile=%.3f evt/tile=%.3f grp/tile=%.3f cyc/flush=%.0f evpath/tile=%.0f\n",
                 w, nt / w, h[0] / nt, h[1] / nt, h[2] / nt, h[3] / nt, h[4] / nt, h[5] / nt, h[6] / nt, h[7] / nt, h[4] ? (double)h[2] / h[4] : 0.0, h[10] / nt);
-        unsigned long long z[16] = {0};
+        fprintf(stderr, "[stamps] spin/tile by consumer:");
+        for (int i = 0; i < 8; ++i) fprintf(stderr, " %.0f", h[16 + i] / (nt / 8));
+        fprintf(stderr, "  flush/tile:");
+        for (int i = 0; i < 8; ++i) fprintf(stderr, " %.0f", h[24 + i] / (nt / 8));
+        fprintf(stderr, "  producer waiting fraction:");
+        for (int i = 0; i < 4; ++i) fprintf(stderr, " %.2f", h[36 + i] ? (double)h[32 + i] / h[36 + i] : 0.0);
+        fprintf(stderr, "\n");
+        unsigned long long z[48] = {0};
         BMX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(bmx_dbg), z, sizeof(z)));
     }
 #endif
