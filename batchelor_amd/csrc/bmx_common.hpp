@@ -69,6 +69,7 @@ struct KnnWorkspace {
     DevBuf<float> tau;             // [nq][C]
     DevBuf<float> cand_v;          // [nq][C][KS] approximate values (multi-range runs: refine pre-ranks by them)
     DevBuf<uint32_t> tau_g;        // [nq] per-query thresholds shared across reference ranges (split-bf16 kernel)
+    DevBuf<unsigned long long> maxslots;  // 64 x 16 words: per-slot maxima of the reference norms (split-bf16 prep)
     DevBuf<uint64_t> seed;         // [nq][KS + 1] kept list of the sample range (wave-per-workgroup kernel)
     DevBuf<int32_t> flagged;       // [nq + 1] compact list of queries needing the exact path (+ counter)
     DevBuf<double> drow;           // exact-path distance rows
@@ -116,7 +117,8 @@ struct Bf16Launch {
 int bf16_pick_ns(int d);         // MFMA k-steps (16 bf16 each) for 3 d + 3 columns; 0 = unsupported
 int bf16_ncons(int NS, int KS);  // consumer waves (32 queries each) per workgroup
 void bf16_prep(hipStream_t stream, const double* X, const int32_t* rows, int n, int n_pad, int d, int NS,
-               const double* mean, int is_query, uint16_t* P, double* n2, unsigned long long* maxbits);
+               const double* mean, int is_query, uint16_t* P, double* n2, unsigned long long* maxbits,
+               unsigned long long* slots);  // slots: 64 x 16 words of scratch for the reference-norm maximum
 bool bf16_launch(hipStream_t stream, KnnWorkspace& ws, int NS, int KS, const Bf16Launch& L);
 
 // For rows q in [q_begin, q_end) of the query list: the k nearest rows of the reference list (exact, FP64 Euclidean,

@@ -951,8 +951,10 @@ void knn_device(hipStream_t stream, KnnWorkspace& ws, const double* X, const int
         double eps_k, eps_qr, eps_split;
         const float* cand_v = nullptr;
         if (variant == 2) {
-            bf16_prep(stream, X, ref_rows, nr, nr_pad, d, NS, mean, 0, reinterpret_cast<uint16_t*>(pr), rn2, maxbits);
-            bf16_prep(stream, Qs, qrs, nq, nq_pad, d, NS, mean, 1, reinterpret_cast<uint16_t*>(pq), qn2, maxbits);
+            bf16_prep(stream, X, ref_rows, nr, nr_pad, d, NS, mean, 0, reinterpret_cast<uint16_t*>(pr), rn2, maxbits,
+                      ws.maxslots.reserve(64 * 16));
+            bf16_prep(stream, Qs, qrs, nq, nq_pad, d, NS, mean, 1, reinterpret_cast<uint16_t*>(pq), qn2, maxbits,
+                      ws.maxslots.p);
             // sample pass: threshold estimation over rows [0, S); full pass: every row, starting from that threshold
             uint32_t* tau_g = ws.tau_g.reserve(nq_pad);
             if (S == 0) {  // no sample: +inf everywhere (0xFF800000 is the orderable image of +inf)

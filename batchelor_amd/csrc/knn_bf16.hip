@@ -55,8 +55,8 @@ __device__ __forceinline__ int64_t frag_pos(int r, int L, int NS) {
 }
 
 // One workgroup prepares one 32-row tile: rows are staged in LDS with coalesced reads, every output element is
-// computed from there, the tile image (fragment-major for references, row-major for queries -- both contiguous per
-// tile) is assembled in LDS and written out linearly.
+// computed from there, and the tile image (fragment-major for references, row-major for queries -- both contiguous
+// per tile) is written out in 16-byte pieces, consecutive threads writing consecutive pieces.
 __global__ __launch_bounds__(256) void knn_prep_bf16(const double* __restrict__ X, const int32_t* __restrict__ rows,
                                                      int n, int n_pad, int d, int NS, const double* __restrict__ mean,
                                                      int is_query, uint16_t* __restrict__ P, double* __restrict__ n2,
@@ -65,12 +65,21 @@ __global__ __launch_bounds__(256) void knn_prep_bf16(const double* __restrict__ 
     const int K = 16 * NS;
     float* xs = reinterpret_cast<float*>(smem_pp);                       // [32][d] centred, rounded to f32
     float* nrm = xs + 32 * d;                                            // [32] f32(|x~|^2)
-    uint16_t* img = reinterpret_cast<uint16_t*>(nrm + 32);               // [32 * K] tile image
     const int tid = threadIdx.x;
     const int r0 = blockIdx.x * 32;
     (void)n_pad;
+    // (row, column) of a flat element index without an integer division: e < 32 * 128, so the float quotient is exact
+    const float inv_d = 1.0f / (float)d;
     for (int e = tid; e < 32 * d; e += 256) {
-        const int rr = e / d, c = e - rr * d;
+        int rr = (int)(((float)e + 0.5f) * inv_d);
+        int c = e - rr * d;
+        if (c < 0) {
+            --rr;
+            c += d;
+        } else if (c >= d) {
+            ++rr;
+            c -= d;
+        }
         const int r = r0 + rr;
         float f = 0.f;
         if (r < n) {
@@ -80,57 +89,89 @@ __global__ __launch_bounds__(256) void knn_prep_bf16(const double* __restrict__ 
         xs[e] = f;
     }
     __syncthreads();
-    if (tid < 32) {
-        const int r = r0 + tid;
-        double s = 0.0;
-        for (int c = 0; c < d; ++c) {
-            const double f = (double)xs[tid * d + c];
+    // eight threads per row from here on: thread (rr, sub) owns the elements L = sub (mod 8) of row rr
+    const int rr = tid >> 3, sub = tid & 7;
+    const bool live = r0 + rr < n;
+    {
+        double s = 0.0;  // |x~|^2 of the f32-rounded centred row (exact products, FP64 sum; any order will do)
+        for (int c = sub; c < d; c += 8) {
+            const double f = (double)xs[rr * d + c];
             s += f * f;
         }
-        nrm[tid] = (float)s;
-        if (r < n) {
-            n2[r] = s;
-            if (!is_query) atomicMax(max_n2_bits, (unsigned long long)__double_as_longlong(s));
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        if (sub == 0) {
+            nrm[rr] = (float)s;
+            if (live) n2[r0 + rr] = s;
         }
-    }
-    __syncthreads();
-    const int hk = 8 * NS;
-    for (int e = tid; e < 32 * K; e += 256) {
-        const int rr = e / K, L = e - rr * K;
-        const bool live = r0 + rr < n;
-        uint16_t v = 0;
-        if (L < 3 * d) {
-            const int blk = L / d, c = L - blk * d;
-            const float f = xs[rr * d + c];
-            const float g = is_query ? -2.f * f : f;
-            const uint16_t hi = f32_to_bf16(g);
-            const bool want_lo = is_query ? blk == 2 : blk == 1;
-            v = want_lo ? f32_to_bf16(g - bf16_to_f32(hi)) : hi;
-        } else if (L < 3 * d + 3) {
-            const int piece = L - 3 * d;
-            if (is_query) {
-                v = live ? 0x3F80 : 0;  // 1.0 (padded queries stay all-zero)
-            } else if (!live) {
-                v = piece == 0 ? 0x7F80 : 0;  // +inf: a padded reference never passes a threshold
-            } else {
-                const float nf = nrm[rr];  // its three bf16 pieces reproduce the f32 value exactly
-                const uint16_t a = f32_to_bf16(nf);
-                const float r1 = nf - bf16_to_f32(a);
-                const uint16_t b2 = f32_to_bf16(r1);
-                v = piece == 0 ? a : (piece == 1 ? b2 : f32_to_bf16(r1 - bf16_to_f32(b2)));
-            }
-        }
-        int pos = e;  // queries: row-major inside the tile
         if (!is_query) {
-            const int h = L / hk, s = (L - h * hk) >> 3, j = L & 7;
-            pos = ((s * 64 + h * 32 + rr) << 3) + j;
+            // one atomic per wave, spread over 64 words a cache line apart (a single word serialises the whole
+            // launch in the L2's atomic unit: it was the bulk of this kernel's time); fold_max_slots() finishes
+            double m = live ? s : 0.0;
+            for (int o = 8; o < 64; o <<= 1) m = fmax(m, __shfl_xor(m, o));
+            if ((tid & 63) == 0)
+                atomicMax(max_n2_bits + (size_t)(blockIdx.x & 63) * 16, (unsigned long long)__double_as_longlong(m));
         }
-        img[pos] = v;
     }
     __syncthreads();
-    const uint4* src = reinterpret_cast<const uint4*>(img);
-    uint4* dst = reinterpret_cast<uint4*>(P + (int64_t)r0 * K);
-    for (int e = tid; e < 32 * K / 8; e += 256) dst[e] = src[e];
+    // 16-byte pieces (8 consecutive elements of a row) straight from the staged rows to global memory: consecutive
+    // threads write consecutive pieces of the tile image (fragment-major for references: k-step, lane half, row;
+    // row-major for queries)
+    uint4* out = reinterpret_cast<uint4*>(P + (int64_t)r0 * K);
+    const int npieces = 32 * 2 * NS;
+    const float inv_pc = 1.0f / (float)(2 * NS);
+    for (int p = tid; p < npieces; p += 256) {
+        int prow, i;  // row of the tile, 8-element chunk of the row
+        if (is_query) {
+            prow = (int)(((float)p + 0.5f) * inv_pc);
+            i = p - prow * 2 * NS;
+            if (i < 0) {
+                --prow;
+                i += 2 * NS;
+            } else if (i >= 2 * NS) {
+                ++prow;
+                i -= 2 * NS;
+            }
+        } else {
+            prow = p & 31;
+            const int ih = p >> 5;  // = 2 * k-step + lane half
+            i = (ih & 1) * NS + (ih >> 1);
+        }
+        const bool plive = r0 + prow < n;
+        const float nf = nrm[prow];  // its three bf16 pieces reproduce the f32 value exactly
+        const uint16_t na = f32_to_bf16(nf);
+        const float nr1 = nf - bf16_to_f32(na);
+        const uint16_t nb = f32_to_bf16(nr1);
+        const uint16_t nc = f32_to_bf16(nr1 - bf16_to_f32(nb));
+        uint32_t w[4];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int L = 8 * i + e;
+            uint16_t v = 0;
+            if (L < 3 * d) {
+                const int blk = (L >= d) + (L >= 2 * d), c = L - blk * d;
+                const float f = xs[prow * d + c];
+                const float g = is_query ? -2.f * f : f;
+                const uint16_t hi = f32_to_bf16(g);
+                const bool want_lo = is_query ? blk == 2 : blk == 1;
+                v = want_lo ? f32_to_bf16(g - bf16_to_f32(hi)) : hi;
+            } else if (L < 3 * d + 3) {
+                const int piece = L - 3 * d;
+                if (is_query)
+                    v = plive ? 0x3F80 : 0;  // 1.0 (padded queries stay all-zero)
+                else if (!plive)
+                    v = piece == 0 ? 0x7F80 : 0;  // +inf: a padded reference never passes a threshold
+                else
+                    v = piece == 0 ? na : (piece == 1 ? nb : nc);
+            }
+            if (e & 1)
+                w[e >> 1] |= (uint32_t)v << 16;
+            else
+                w[e >> 1] = v;
+        }
+        out[p] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
 }
 
 // Ring depth: as many staged tiles as the LDS left over by the candidate lists holds (at most 8).  The consumers of a
@@ -617,12 +658,24 @@ int bf16_pick_ns(int d) {
 
 int bf16_ncons(int NS, int KS) { return ring_shape(NS, KS).ncons; }
 
+__global__ void fold_max_slots(const unsigned long long* __restrict__ slots, unsigned long long* __restrict__ out) {
+    double m = __longlong_as_double((long long)slots[(size_t)threadIdx.x * 16]);
+    for (int o = 1; o < 64; o <<= 1) m = fmax(m, __shfl_xor(m, o));
+    if (threadIdx.x == 0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
+}
+
 void bf16_prep(hipStream_t stream, const double* X, const int32_t* rows, int n, int n_pad, int d, int NS,
-               const double* mean, int is_query, uint16_t* P, double* n2, unsigned long long* maxbits) {
-    const size_t lds = (size_t)32 * d * 4 + 128 + (size_t)32 * 16 * NS * 2 + 16;
+               const double* mean, int is_query, uint16_t* P, double* n2, unsigned long long* maxbits,
+               unsigned long long* slots) {
+    const size_t lds = (size_t)32 * d * 4 + 128 + 16;
+    if (!is_query) BMX_HIP(hipMemsetAsync(slots, 0, 64 * 16 * sizeof(unsigned long long), stream));
     hipLaunchKernelGGL(knn_prep_bf16, dim3(n_pad / 32), dim3(256), lds, stream, X, rows, n, n_pad, d, NS, mean, is_query,
-                       P, n2, maxbits);
+                       P, n2, slots);
     BMX_LAUNCH_CHECK();
+    if (!is_query) {
+        hipLaunchKernelGGL(fold_max_slots, dim3(1), dim3(64), 0, stream, slots, maxbits);
+        BMX_LAUNCH_CHECK();
+    }
 }
 
 bool bf16_launch(hipStream_t stream, KnnWorkspace& ws, int NS, int KS, const Bf16Launch& L) {
