@@ -430,6 +430,7 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
         }
         // group minima (4 registers each), then the lane minimum, of the previous tile
         float g[4];
+        unsigned long long gmask[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int u = 0; u < 4; ++u)
             g[u] = fminf(fminf(prev[4 * u], prev[4 * u + 1]), fminf(prev[4 * u + 2], prev[4 * u + 3]));
@@ -446,7 +447,12 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
             }
             asm volatile("" ::"v"(best[KS / 2 - 1]));  // keep it in this block
         } else {
-            asm volatile("" ::"v"(mn), "v"(g[0]), "v"(g[1]), "v"(g[2]), "v"(g[3]));  // keep the filter in this block
+            // the four group tests are evaluated here, under the MFMA chain, and leave scalar masks: the branches after
+            // the chain then hang on scalar registers only (a mask that a later merge of this tile makes stale is
+            // merely looser: every value is still compared with the current threshold)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) gmask[u] = __builtin_amdgcn_ballot_w64(g[u] < tau);
+            asm volatile("" ::"s"(gmask[0]), "s"(gmask[1]), "s"(gmask[2]), "s"(gmask[3]));  // keep the filter in this block
         }
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
@@ -461,7 +467,7 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
 #ifdef BMX_ABLATE_EVENTS
         if (!SAMPLE) { asm volatile("" ::"v"(mn)); return; }
 #endif
-        if (__builtin_amdgcn_ballot_w64(mn < tau) == 0) return;
+        if ((gmask[0] | gmask[1] | gmask[2] | gmask[3]) == 0) return;
 #ifdef BMX_STAMPS
         ++dbg_evt;
         const unsigned long long dbg_e0 = STAMP();
@@ -493,7 +499,7 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
         {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                if (__builtin_amdgcn_ballot_w64(g[u] < tau) == 0) continue;
+                if (gmask[u] == 0) continue;
 #ifdef BMX_STAMPS
                 ++dbg_grp;
 #endif
