@@ -219,12 +219,6 @@ __global__ __launch_bounds__(THREADS, 2) void knn_topk_mfma(const float* __restr
         // staging registers are dead during the selection below
         if (more) BMX_STAGE_STORE(cur ^ 1)
 
-#ifdef BMX_ABLATE_SELECT
-#pragma unroll
-        for (int t = 0; t < RT / 32; ++t)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) asm volatile("" ::"v"(acc[t][e]));
-#else
         // lane (j, h) now holds, for ITS query j, the values of references r0 + 32 t + (e&3) + 8 (e>>2) + 4 h
 #pragma unroll
         for (int t = 0; t < RT / 32; ++t) {
@@ -255,7 +249,6 @@ __global__ __launch_bounds__(THREADS, 2) void knn_topk_mfma(const float* __restr
                 }
             }
         }
-#endif
 
         __syncthreads();
         cur ^= 1;
@@ -369,10 +362,6 @@ __global__ __launch_bounds__(64, 3) void knn_topk_w1(const float* __restrict__ P
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].z, bq[4 * m + 2], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].w, bq[4 * m + 3], acc, 0, 0, 0);
         }
-#ifdef BMX_ABLATE_SELECT
-#pragma unroll
-        for (int e = 0; e < 16; ++e) asm volatile("" ::"v"(acc[e]));
-#else
         float mn = acc[0];
 #pragma unroll
         for (int e = 1; e < 16; ++e) mn = fminf(mn, acc[e]);
@@ -398,7 +387,6 @@ __global__ __launch_bounds__(64, 3) void knn_topk_w1(const float* __restrict__ P
                 tau = tau_s[j];
             }
         }
-#endif
     };
 
     for (int r0 = r_begin; r0 < r_end; r0 += 64) {

@@ -464,9 +464,6 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
         if constexpr (SAMPLE) return;
 
         const int r0 = r_begin + ((t - 1) << 5);  // the tile whose products are in `prev`
-#ifdef BMX_ABLATE_EVENTS
-        if (!SAMPLE) { asm volatile("" ::"v"(mn)); return; }
-#endif
         if ((gmask[0] | gmask[1] | gmask[2] | gmask[3]) == 0) return;
 #ifdef BMX_STAMPS
         ++dbg_evt;
