@@ -420,9 +420,23 @@ __global__ __launch_bounds__(64, 3) void knn_topk_w1(const float* __restrict__ P
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double exact_d2(const double* __restrict__ a, const double* __restrict__ b, int d) {
     double s = 0.0;
-    for (int c = 0; c < d; ++c) {
+    int c = 0;
+    if ((d & 1) == 0) {  // rows of an even number of doubles are 16-byte aligned: half as many load instructions
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        const d2* a2 = reinterpret_cast<const d2*>(a);
+        const d2* b2 = reinterpret_cast<const d2*>(b);
+        for (; c < d; c += 2) {
+            const d2 x = a2[c >> 1], y = b2[c >> 1];
+            const double t0 = x[0] - y[0];
+            s += t0 * t0;  // compiled with -ffp-contract=off: the reference's left-to-right sum, bit for bit
+            const double t1 = x[1] - y[1];
+            s += t1 * t1;
+        }
+        return s;
+    }
+    for (; c < d; ++c) {
         const double t = a[c] - b[c];
-        s += t * t;  // compiled with -ffp-contract=off: the reference's left-to-right sum, bit for bit
+        s += t * t;
     }
     return s;
 }
