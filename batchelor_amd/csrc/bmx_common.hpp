@@ -29,8 +29,44 @@ struct Error : std::runtime_error {
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 
+// Released device blocks are parked (a few, bounded) and handed out again: a merge engine rebuilds its node buffers at
+// every merge, and hipMalloc / hipFree cost hundreds of microseconds each (hipFree also waits for the device).  All
+// users of a block are ordered by the engine's stream, so reuse needs no extra synchronisation.
+struct DevBlockCache {
+    struct Block {
+        void* p;
+        size_t bytes;
+    };
+    static std::vector<Block>& blocks() {
+        static std::vector<Block>* b = new std::vector<Block>();  // never destroyed: no hipFree after runtime shutdown
+        return *b;
+    }
+    static void* take(size_t bytes, size_t* got) {
+        auto& b = blocks();
+        int best = -1;
+        for (int i = 0; i < (int)b.size(); ++i)
+            if (b[i].bytes >= bytes && b[i].bytes <= 2 * bytes + (1u << 20) && (best < 0 || b[i].bytes < b[best].bytes))
+                best = i;
+        if (best < 0) return nullptr;
+        void* p = b[best].p;
+        *got = b[best].bytes;
+        b.erase(b.begin() + best);
+        return p;
+    }
+    static void give(void* p, size_t bytes) {
+        auto& b = blocks();
+        size_t total = bytes;
+        for (const Block& x : b) total += x.bytes;
+        if (b.size() >= 48 || total > ((size_t)24 << 30)) {
+            (void)hipFree(p);
+            return;
+        }
+        b.push_back({p, bytes});
+    }
+};
+
 // Grow-only device buffer: the engine keeps these across calls so a steady-state run allocates nothing.
-template <class T>
+template <typename T>
 struct DevBuf {
     T* p = nullptr;
     size_t cap = 0;
@@ -44,16 +80,22 @@ struct DevBuf {
     }
     ~DevBuf() { release(); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) DevBlockCache::give(p, cap * sizeof(T));
         p = nullptr;
         cap = 0;
     }
     T* reserve(size_t n) {
         if (n > cap) {
             release();
-            size_t want = n + n / 8 + 64;
-            BMX_HIP(hipMalloc((void**)&p, want * sizeof(T)));
-            cap = want;
+            const size_t want = n + n / 8 + 64;
+            size_t got = 0;
+            if (void* q = DevBlockCache::take(want * sizeof(T), &got)) {
+                p = static_cast<T*>(q);
+                cap = got / sizeof(T);
+            } else {
+                BMX_HIP(hipMalloc((void**)&p, want * sizeof(T)));
+                cap = want;
+            }
         }
         return p;
     }
