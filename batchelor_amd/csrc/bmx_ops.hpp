@@ -21,12 +21,13 @@ void exclusive_scan_i32(hipStream_t stream, ScanWorkspace& ws, const int32_t* in
 // of a selected left cell l (both nullptr: one row per left cell).  nL = number of rows of idxLR.
 void mutual_counts(hipStream_t stream, const int32_t* idxLR, int nL, int k2, const int32_t* idxRL, int nR, int k1,
                    int32_t* cntL, int32_t* partR, int32_t* cntR, const int32_t* lsel = nullptr,
-                   const int32_t* lpos2c = nullptr);
+                   const int32_t* lpos2c = nullptr, unsigned long long* maskL = nullptr);
+// maskL (nullable, nL words): bit j of word c = neighbour j of row c is mutual; emit_pairs then skips the lookups.
 // Pairs in the reference order (src/find_mutual_nns.cpp:23-36): left ascending, then the left cell's neighbour rank.
 // offL = exclusive scan of cntL.  Ids written are lrows[l] + 1 / rrows[r] + 1 (1-based rows in the node; identity if null).
 void emit_pairs(hipStream_t stream, const int32_t* idxLR, int nL, int k2, const int32_t* idxRL, int k1,
                 const int32_t* offL, const int32_t* lrows, const int32_t* rrows, int32_t* first, int32_t* second,
-                const int32_t* lsel = nullptr);
+                const int32_t* lsel = nullptr, const unsigned long long* maskL = nullptr);
 // Rows (of n_rows) that occur in idx[0, n_entries): flag[r] = 0/1, off = exclusive scan of flag (n_rows + 1 entries:
 // off[r] = position of a listed row in sel, off[n_rows] = their number), sel = the listed rows, ascending.
 void select_listed_rows(hipStream_t stream, ScanWorkspace& ws, const int32_t* idx, int64_t n_entries, int n_rows,

@@ -165,7 +165,8 @@ Engine::MnnOut Engine::find_mnn(const Node& left, const Node& right, int k, doub
     int32_t* flagR = flagR_.reserve(nR);
     int32_t* offR = offR_.reserve((size_t)nR + 1);
     int32_t* second_u = second_u_.reserve(nR);
-    mutual_counts(stream_, idxLR, nsel, o.k2, idxRL, nR, o.k1, cntL, partR, cntR, lsel, offSel);
+    mutual_counts(stream_, idxLR, nsel, o.k2, idxRL, nR, o.k1, cntL, partR, cntR, lsel, offSel,
+                  maskL_.reserve(std::max(1, nsel)));
     exclusive_scan_i32(stream_, scan_ws_, cntL, offL, nsel);
     compact_mnn_cells(stream_, scan_ws_, cntR, nR, flagR, offR, second_u);
     int32_t h[2] = {0, 0};
@@ -267,7 +268,8 @@ void Engine::merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p,
     rec.stats[5] = right.n;
     int32_t* first = rec.first.reserve((size_t)mo.P);
     int32_t* second = rec.second.reserve((size_t)mo.P);
-    emit_pairs(stream_, idxLR_.p, mo.nsel, mo.k2, idxRL_.p, mo.k1, offL_.p, lrows, rrows, first, second, lsel_.p);
+    emit_pairs(stream_, idxLR_.p, mo.nsel, mo.k2, idxRL_.p, mo.k1, offL_.p, lrows, rrows, first, second, lsel_.p,
+               maskL_.p);
 
     // .average_correction + overall.batch (R/fastMNN.R:480-481)
     double* averaged = averaged_.reserve((size_t)mo.U * d_);

@@ -81,6 +81,7 @@ class Engine {
     ReduceWorkspace red_ws_;
     DevBuf<int32_t> idxLR_, idxRL_, cntL_, offL_, partR_, cntR_, flagR_, offR_, second_u_, second_rows_, idxT_;
     DevBuf<int32_t> flagL_, offSel_, lsel_, qsel_;
+    DevBuf<unsigned long long> maskL_;
     DevBuf<double> distT_, averaged_, loc_, vecs_, scal_;
 
   private:

@@ -71,16 +71,21 @@ __device__ __forceinline__ bool row_contains(const int32_t* __restrict__ row, in
 // idxLR may hold the lists of a SUBSET of the left cells (row c = left cell lsel[c], ascending; lpos2c maps a selected
 // left cell back to its row).  lsel == nullptr: every left cell has a row (c == l).
 __global__ void mutual_left(const int32_t* __restrict__ idxLR, int nL, int k2, const int32_t* __restrict__ idxRL, int k1,
-                            const int32_t* __restrict__ lsel, int32_t* __restrict__ cntL) {
+                            const int32_t* __restrict__ lsel, int32_t* __restrict__ cntL,
+                            unsigned long long* __restrict__ maskL) {
     const int c0 = blockIdx.x * blockDim.x + threadIdx.x;
     if (c0 >= nL) return;
     const int l = lsel ? lsel[c0] : c0;
     int c = 0;
+    unsigned long long m = 0;  // bit j: neighbour j is mutual (kept for emit_pairs when k2 <= 64)
     for (int j = 0; j < k2; ++j) {
         const int32_t r = idxLR[(int64_t)c0 * k2 + j];
-        c += row_contains(idxRL + (int64_t)r * k1, k1, l) ? 1 : 0;
+        const bool hit = row_contains(idxRL + (int64_t)r * k1, k1, l);
+        c += hit ? 1 : 0;
+        if (hit && j < 64) m |= 1ull << j;
     }
     cntL[c0] = c;
+    if (maskL) maskL[c0] = m;
 }
 
 __global__ void mutual_right(const int32_t* __restrict__ idxLR, int k2, const int32_t* __restrict__ idxRL, int nR,
@@ -107,15 +112,18 @@ __global__ void mutual_right(const int32_t* __restrict__ idxLR, int k2, const in
 __global__ void emit_pairs_kernel(const int32_t* __restrict__ idxLR, int nL, int k2, const int32_t* __restrict__ idxRL,
                                   int k1, const int32_t* __restrict__ offL, const int32_t* __restrict__ lsel,
                                   const int32_t* __restrict__ lrows, const int32_t* __restrict__ rrows,
-                                  int32_t* __restrict__ first, int32_t* __restrict__ second) {
+                                  const unsigned long long* __restrict__ maskL, int32_t* __restrict__ first,
+                                  int32_t* __restrict__ second) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nL) return;
     int o = offL[c];
+    if (o == offL[c + 1]) return;  // no pair starts at this left cell
     const int l = lsel ? lsel[c] : c;
     const int32_t lid = (lrows ? lrows[l] : l) + 1;
+    const unsigned long long m = maskL ? maskL[c] : 0;
     for (int j = 0; j < k2; ++j) {
         const int32_t r = idxLR[(int64_t)c * k2 + j];
-        if (row_contains(idxRL + (int64_t)r * k1, k1, l)) {
+        if (maskL ? ((m >> j) & 1ull) != 0 : row_contains(idxRL + (int64_t)r * k1, k1, l)) {
             first[o] = lid;
             second[o] = (rrows ? rrows[r] : r) + 1;
             ++o;
@@ -162,10 +170,11 @@ void exclusive_scan_i32(hipStream_t stream, ScanWorkspace& ws, const int32_t* in
 }
 
 void mutual_counts(hipStream_t stream, const int32_t* idxLR, int nL, int k2, const int32_t* idxRL, int nR, int k1,
-                   int32_t* cntL, int32_t* partR, int32_t* cntR, const int32_t* lsel, const int32_t* lpos2c) {
+                   int32_t* cntL, int32_t* partR, int32_t* cntR, const int32_t* lsel, const int32_t* lpos2c,
+                   unsigned long long* maskL) {
     if (nL > 0) {
         hipLaunchKernelGGL(mutual_left, dim3(cdiv(nL, 256)), dim3(256), 0, stream, idxLR, nL, k2, idxRL, k1, lsel,
-                           cntL);
+                           cntL, k2 <= 64 ? maskL : nullptr);
         BMX_LAUNCH_CHECK();
     }
     if (nR > 0) {
@@ -177,10 +186,10 @@ void mutual_counts(hipStream_t stream, const int32_t* idxLR, int nL, int k2, con
 
 void emit_pairs(hipStream_t stream, const int32_t* idxLR, int nL, int k2, const int32_t* idxRL, int k1,
                 const int32_t* offL, const int32_t* lrows, const int32_t* rrows, int32_t* first, int32_t* second,
-                const int32_t* lsel) {
+                const int32_t* lsel, const unsigned long long* maskL) {
     if (nL <= 0) return;
     hipLaunchKernelGGL(emit_pairs_kernel, dim3(cdiv(nL, 256)), dim3(256), 0, stream, idxLR, nL, k2, idxRL, k1, offL,
-                       lsel, lrows, rrows, first, second);
+                       lsel, lrows, rrows, k2 <= 64 ? maskL : nullptr, first, second);
     BMX_LAUNCH_CHECK();
 }
 
