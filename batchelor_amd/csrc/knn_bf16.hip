@@ -36,7 +36,7 @@ struct RingShape {
     int ncons, nprod, pln;
 };
 __host__ __device__ constexpr RingShape ring_shape(int NS, int KS) {
-    return (NS <= 10 && KS == 24) ? RingShape{8, 4, 12} : RingShape{4, 4, 12};
+    return (NS <= 13 && KS == 24) ? RingShape{8, 4, 12} : RingShape{4, 4, 12};
 }
 
 __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
