@@ -9,13 +9,16 @@
 // against.  10 MFMAs of 32 cycles per 32x32 tile at 50 PCs instead of 28 of 64 cycles.
 //
 // At that rate the matrix pipe is no longer the limit; staging and selection are.  Structure of a workgroup:
-//   * NCONS consumer waves, 32 queries each: query fragments resident in VGPRs, selection state in LDS
-//     (knn_select.hpp), exactly as in the f32 kernel;
-//   * 4 producer waves stream the reference tiles (fragment-major, 1 KiB coalesced reads, two tiles in flight per
-//     producer) into a 4-slot LDS ring shared by all consumers -- one read of the reference set per 32*NCONS queries;
-//   * no s_barrier in the main loop: slots are handed over through LDS words (ready[slot] = tile number + 1,
-//     done[slot] += 1 per consumer), which the in-order LDS queue of each wave makes safe without extra waits.
-//     A consumer that is busy compacting a candidate buffer therefore delays nobody until the ring runs dry.
+//   * NCONS consumer waves, 32 queries each: query fragments resident in VGPRs; per query a sorted kept list and two
+//     lane-private pending lists in the LDS, their lengths and the working threshold in registers (knn_select.hpp);
+//   * NPROD producer waves stream the reference tiles (fragment-major, 1 KiB coalesced reads, two or three tiles in
+//     flight per producer) into an LDS ring (as many slots as the LDS left by the lists holds) shared by all
+//     consumers -- one read of the reference set per 32*NCONS queries;
+//   * no s_barrier in the main loop: slots are handed over through LDS words (ready[slot] = tile number + 1, one
+//     done word per slot and consumer), which the in-order LDS queue of each wave makes safe without extra waits.
+//     A consumer that is busy merging a candidate list therefore delays nobody until the ring runs dry;
+//   * the consumer loop is software-pipelined: under the dependent MFMA chain of tile t the wave refills its
+//     fragment registers with tile t + 1 and filters tile t - 1; appends and list merges of tile t - 1 follow.
 #include "bmx_common.hpp"
 #include "knn_select.hpp"
 
@@ -344,14 +347,15 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_bf16(
     const unsigned long long dbg_t0 = STAMP();
 #endif
 
-    // Tile hand-over.  Tile t + 1 (the producers stage one empty tile past the end, so there always is one) is read
-    // into the other fragment set before tile t computes.  Its ready word was polled one tile earlier (`seen`), so in
-    // steady state no LDS round trip is waited for.  After its fragment reads the wave stores "read up to t + 1" in
-    // its done word of the slot -- queued behind the reads in the wave's in-order LDS queue, so the producer cannot
-    // overwrite them early -- and polls the ready word of tile t + 2.
+    // Tile hand-over.  Tile t + 1 (the producers stage two empty tiles past the end, so there always is one) is read
+    // into the fragment registers while tile t computes, each register right after the MFMA that consumed it.  Its
+    // ready word was polled one tile earlier (`seen`), so in steady state no LDS round trip is waited for.  After the
+    // fragment reads the wave stores "read up to t + 1" in its done word of the slot -- queued behind the reads in
+    // the wave's in-order LDS queue, so the producer cannot overwrite them early -- and polls the ready word of
+    // tile t + 2.
     // The explicit lgkmcnt(0) at the top of every tile is free (everything queued is a tile old, the fragments of
     // tile t included) and leaves the compiler's wait-count pass with nothing pending: without it the pass makes the
-    // MFMAs of tile t wait for the reads of tile t + 1 issued just before them.
+    // MFMAs of tile t wait for the reads of tile t + 1 issued between them.
     const bool shared_tau = !SAMPLE && tau_g != nullptr && nrng > 1;
     uint32_t tau_fetch = 0xFFFFFFFFu;
     int seen = 0;
