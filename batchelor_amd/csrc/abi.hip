@@ -122,6 +122,7 @@ int32_t bmx_query_knn(const double* X, int32_t nx, const double* query, int32_t 
         if (k > nx) throw bmx::Error(BMX_ERR_ARG, "queryKNN: 'k' exceeds the number of points in 'X'");
         if (nq == 0 || k == 0) return;
         bmx::Engine& e = prim(d);
+        bmx::CacheScope cache_scope(e.cache());
         hipStream_t s = e.stream();
         bmx::DevBuf<double> t1, t2, dX, dQ, dD;
         bmx::DevBuf<int32_t> dI, dIc;
@@ -165,6 +166,7 @@ int32_t bmx_find_mutual_nns(const int32_t* left, int32_t nL, int32_t k2, const i
                 r[(size_t)(i * k1 + j)] = v - 1;
             }
         bmx::Engine& e = prim(1);
+        bmx::CacheScope cache_scope(e.cache());
         hipStream_t s = e.stream();
         bmx::DevBuf<int32_t> dl, dr, cntL, offL, partR, cntR, f, sc;
         const int32_t* pl = upload(dl, l.data(), l.size(), s);
@@ -193,6 +195,7 @@ int32_t bmx_find_mutual_nn(const double* data1, int32_t n1, const double* data2,
         if (n1 < 1 || n2 < 1 || d < 1) throw bmx::Error(BMX_ERR_ARG, "findMutualNN: empty input");
         if (k1 < 1 || k2 < 1 || k1 > n1 || k2 > n2) throw bmx::Error(BMX_ERR_ARG, "findMutualNN: 'k1'/'k2' out of range");
         bmx::Engine& e = prim(d);
+        bmx::CacheScope cache_scope(e.cache());
         hipStream_t s = e.stream();
         bmx::Node L, R;
         bmx::DevBuf<double> t1, t2;
@@ -228,6 +231,7 @@ int32_t bmx_mnn_average_correction(const double* refdata, int32_t n1, const doub
         if (n1 < 1 || n2 < 1 || d < 1) throw bmx::Error(BMX_ERR_ARG, "empty input");
         if (k1 < 1 || k2 < 1 || k1 > n1 || k2 > n2) throw bmx::Error(BMX_ERR_ARG, "'k1'/'k2' out of range");
         bmx::Engine& e = prim(d);
+        bmx::CacheScope cache_scope(e.cache());
         hipStream_t s = e.stream();
         bmx::Node L, R;
         bmx::DevBuf<double> t1, t2;
@@ -264,6 +268,7 @@ int32_t bmx_center_along_batch_vector(double* mat, int32_t n, int32_t d, const d
     return guarded([&] {
         if (n < 1 || d < 1) throw bmx::Error(BMX_ERR_ARG, "empty input");
         bmx::Engine& e = prim(d);
+        bmx::CacheScope cache_scope(e.cache());
         hipStream_t s = e.stream();
         bmx::DevBuf<double> t, X, v, loc, cm;
         bmx::DevBuf<int32_t> rr;
@@ -295,6 +300,7 @@ int32_t bmx_tricube_weighted_correction(double* curdata, int32_t n, int32_t d, c
         if (n < 1 || d < 1) throw bmx::Error(BMX_ERR_ARG, "empty input");
         if (U < 0 || k < 0) throw bmx::Error(BMX_ERR_ARG, "negative size");
         bmx::Engine& e = prim(d);
+        bmx::CacheScope cache_scope(e.cache());
         hipStream_t s = e.stream();
         bmx::DevBuf<double> t1, t2, X, C, dist, cm;
         bmx::DevBuf<int32_t> rows, idx;
@@ -324,6 +330,7 @@ int32_t bmx_total_variance(const double* data, int32_t n, int32_t d, double* out
     return guarded([&] {
         if (n < 1 || d < 1) throw bmx::Error(BMX_ERR_ARG, "empty input");
         bmx::Engine& e = prim(d);
+        bmx::CacheScope cache_scope(e.cache());
         hipStream_t s = e.stream();
         bmx::DevBuf<double> t, X, v;
         const double* px = upload_rm(t, X, data, n, d, s);
@@ -348,6 +355,7 @@ int32_t bmx_smooth_gaussian_kernel(const double* averaged, int32_t g, int32_t U,
         for (int i = 0; i < U; ++i)  // upstream reads out of bounds here; refuse instead
             if (index[i] < 0 || index[i] >= n) throw bmx::Error(BMX_ERR_SUBSET, "subset indices out of range");
         bmx::Engine& e = prim(1);
+        bmx::CacheScope cache_scope(e.cache());
         hipStream_t s = e.stream();
         bmx::DevBuf<double> dA, dM, dO, dD;
         bmx::DevBuf<int32_t> dI;
@@ -380,6 +388,7 @@ int32_t bmx_adjust_shift_variance(const double* data1, int32_t g1, int32_t n1, c
         if (n2 == 0) return;
         const int g = g1;
         bmx::Engine& e = prim(1);
+        bmx::CacheScope cache_scope(e.cache());
         hipStream_t s = e.stream();
         bmx::DevBuf<double> d1, d2, dv, dO, dW;
         bmx::DevBuf<int32_t> dr1, dr2;
@@ -401,6 +410,7 @@ int32_t bmx_cosine_norm(const double* x, int32_t G, int32_t n, double* l2, doubl
         if (G < 0 || n < 0) throw bmx::Error(BMX_ERR_ARG, "negative dimension");
         if (n == 0) return;
         bmx::Engine& e = prim(1);
+        bmx::CacheScope cache_scope(e.cache());
         hipStream_t s = e.stream();
         bmx::DevBuf<double> dx, dl, dn;
         const double* px = upload(dx, x, (size_t)G * n, s);
@@ -422,6 +432,7 @@ int32_t bmx_cosnorm_project(const double* x, int32_t G, int32_t n, const double*
         if (G < 1 || n < 0 || d < 1) throw bmx::Error(BMX_ERR_ARG, "invalid dimension");
         if (n == 0) return;
         bmx::Engine& e = prim(1);
+        bmx::CacheScope cache_scope(e.cache());
         hipStream_t s = e.stream();
         bmx::DevBuf<double> dx, du, dc, dout, dcu;
         const double* px = upload(dx, x, (size_t)G * n, s);

@@ -4,6 +4,8 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <map>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -30,40 +32,71 @@ inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 
 // Released device blocks are parked (a few, bounded) and handed out again: a merge engine rebuilds its node buffers at
-// every merge, and hipMalloc / hipFree cost hundreds of microseconds each (hipFree also waits for the device).  All
-// users of a block are ordered by the engine's stream, so reuse needs no extra synchronisation.
+// every merge, and hipMalloc / hipFree cost hundreds of microseconds each (hipFree also waits for the device).
+// A cache belongs to ONE engine (one device, one stream): every user of a block is ordered by that engine's stream,
+// so reuse needs no extra synchronisation, and a block never crosses devices or streams.  The engine's public
+// methods install their cache for the calling thread (CacheScope); a DevBuf released or grown outside any scope
+// goes straight to hipFree / hipMalloc.
 struct DevBlockCache {
     struct Block {
         void* p;
         size_t bytes;
     };
-    static std::vector<Block>& blocks() {
-        static std::vector<Block>* b = new std::vector<Block>();  // never destroyed: no hipFree after runtime shutdown
-        return *b;
+    std::vector<Block> blocks;
+    DevBlockCache() = default;
+    DevBlockCache(const DevBlockCache&) = delete;
+    DevBlockCache& operator=(const DevBlockCache&) = delete;
+    ~DevBlockCache() {
+        for (const Block& b : blocks) (void)hipFree(b.p);
+        if (current() == this) current() = nullptr;
     }
-    static void* take(size_t bytes, size_t* got) {
-        auto& b = blocks();
+    static DevBlockCache*& current() {
+        static thread_local DevBlockCache* c = nullptr;
+        return c;
+    }
+    void* take(size_t bytes, size_t* got) {
         int best = -1;
-        for (int i = 0; i < (int)b.size(); ++i)
-            if (b[i].bytes >= bytes && b[i].bytes <= 2 * bytes + (1u << 20) && (best < 0 || b[i].bytes < b[best].bytes))
+        for (int i = 0; i < (int)blocks.size(); ++i)
+            if (blocks[i].bytes >= bytes && blocks[i].bytes <= 2 * bytes + (1u << 20) &&
+                (best < 0 || blocks[i].bytes < blocks[best].bytes))
                 best = i;
         if (best < 0) return nullptr;
-        void* p = b[best].p;
-        *got = b[best].bytes;
-        b.erase(b.begin() + best);
+        void* p = blocks[best].p;
+        *got = blocks[best].bytes;
+        blocks.erase(blocks.begin() + best);
         return p;
     }
-    static void give(void* p, size_t bytes) {
-        auto& b = blocks();
+    void give(void* p, size_t bytes) {
         size_t total = bytes;
-        for (const Block& x : b) total += x.bytes;
-        if (b.size() >= 48 || total > ((size_t)24 << 30)) {
+        for (const Block& x : blocks) total += x.bytes;
+        if (blocks.size() >= 48 || total > ((size_t)24 << 30)) {
             (void)hipFree(p);
             return;
         }
-        b.push_back({p, bytes});
+        blocks.push_back({p, bytes});
     }
 };
+struct CacheScope {
+    DevBlockCache* prev;
+    explicit CacheScope(DevBlockCache* c) : prev(DevBlockCache::current()) { DevBlockCache::current() = c; }
+    ~CacheScope() { DevBlockCache::current() = prev; }
+    CacheScope(const CacheScope&) = delete;
+    CacheScope& operator=(const CacheScope&) = delete;
+};
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies per device: remember (function, device) pairs already raised.
+inline void ensure_dynamic_lds(const void* func, size_t bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, size_t> done;
+    int dev = 0;
+    BMX_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& have = done[{func, dev}];
+    if (bytes > have) {
+        BMX_HIP(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        have = bytes;
+    }
+}
 
 // Grow-only device buffer: the engine keeps these across calls so a steady-state run allocates nothing.
 template <typename T>
@@ -80,7 +113,12 @@ struct DevBuf {
     }
     ~DevBuf() { release(); }
     void release() {
-        if (p) DevBlockCache::give(p, cap * sizeof(T));
+        if (p) {
+            if (DevBlockCache* c = DevBlockCache::current())
+                c->give(p, cap * sizeof(T));
+            else
+                (void)hipFree(p);
+        }
         p = nullptr;
         cap = 0;
     }
@@ -89,7 +127,8 @@ struct DevBuf {
             release();
             const size_t want = n + n / 8 + 64;
             size_t got = 0;
-            if (void* q = DevBlockCache::take(want * sizeof(T), &got)) {
+            DevBlockCache* c = DevBlockCache::current();
+            if (void* q = c ? c->take(want * sizeof(T), &got) : nullptr) {
                 p = static_cast<T*>(q);
                 cap = got / sizeof(T);
             } else {

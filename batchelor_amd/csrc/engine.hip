@@ -44,6 +44,7 @@ void bmx_shard_range_impl(int64_t n, int rank, int world, int64_t* begin, int64_
 }
 
 Engine::Engine(int device) : device_(device) {
+    CacheScope cache_scope(&cache_);
     BMX_HIP(hipSetDevice(device_));
     BMX_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     unsigned long long* tot = reinterpret_cast<unsigned long long*>(scal_.reserve(4096));
@@ -51,7 +52,13 @@ Engine::Engine(int device) : device_(device) {
 }
 
 Engine::~Engine() {
-    if (stream_) (void)hipStreamDestroy(stream_);
+    (void)hipSetDevice(device_);
+    if (stream_) {
+        (void)hipStreamSynchronize(stream_);
+        (void)hipStreamDestroy(stream_);
+    }
+    // the members' DevBufs are released after this body: into this engine's cache, which its own destructor frees
+    DevBlockCache::current() = &cache_;
 }
 
 void Engine::set_shard(int rank, int world, bmx_allgather_fn fn, void* ctx) {
@@ -72,7 +79,10 @@ void Engine::exchange(void* buf, int64_t bytes_per_rank) {
 
 void Engine::upload(int nbatches, int d, const double* const* data, const int32_t* nrows,
                     const int32_t* const* restrict_idx, const int32_t* n_restrict) {
+    CacheScope cache_scope(&cache_);
     BMX_HIP(hipSetDevice(device_));
+    root_.reset();  // results of an earlier run describe other inputs
+    merges_.clear();
     if (nbatches < 2) throw Error(BMX_ERR_ARG, "at least two batches must be specified");  // R/fastMNN.R:345
     if (d < 1 || d > 256) throw Error(BMX_ERR_ARG, "number of dimensions must be in [1, 256]");
     B_ = nbatches;
@@ -97,8 +107,6 @@ void Engine::upload(int nbatches, int d, const double* const* data, const int32_
             for (int i = 0; i < m; ++i) {
                 const int32_t v = restrict_idx[b][i];
                 if (v < 1 || v > nrows[b]) throw Error(BMX_ERR_SUBSET, "subset indices out of range");
-                if (i > 0 && v <= restrict_idx[b][i - 1])
-                    throw Error(BMX_ERR_ARG, "'restrict' must be strictly increasing within each batch");
                 z[i] = v - 1;
             }
             int32_t* rp = inputs_restrict_[b].reserve(m);
@@ -367,10 +375,12 @@ void Engine::merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p,
 }
 
 void Engine::run(const bmx_params_t& p, const int32_t* tree, int tree_len) {
+    CacheScope cache_scope(&cache_);
     BMX_HIP(hipSetDevice(device_));
     if (B_ < 2) throw Error(BMX_ERR_ARG, "at least two batches must be specified");
     if (p.k < 1) throw Error(BMX_ERR_ARG, "'k' must be positive");
     const int nmerges = B_ - 1;
+    root_.reset();  // a run that fails half-way leaves nothing to download
     merges_.clear();
     merges_.resize(nmerges);
     n_extras_ = 0;
@@ -519,6 +529,7 @@ void Engine::run(const bmx_params_t& p, const int32_t* tree, int tree_len) {
 
 void Engine::download(double* corrected, int32_t* batch, int32_t* merge_left, int32_t* merge_right,
                       double* batch_size, int32_t* skipped, double* lost_var) {
+    CacheScope cache_scope(&cache_);
     BMX_HIP(hipSetDevice(device_));
     if (!root_) throw Error(BMX_ERR_ARG, "no finished run to download");
     const int nmerges = B_ - 1;
@@ -561,8 +572,10 @@ void Engine::download(double* corrected, int32_t* batch, int32_t* merge_left, in
 }
 
 void Engine::pairs(int merge, int32_t** left, int32_t** right, int64_t* npairs) {
+    CacheScope cache_scope(&cache_);
     BMX_HIP(hipSetDevice(device_));
-    if (!root_ || merge < 0 || merge >= B_ - 1) throw Error(BMX_ERR_ARG, "merge index out of range");
+    if (!root_) throw Error(BMX_ERR_ARG, "no finished run to download");
+    if (merge < 0 || merge >= (int)merges_.size()) throw Error(BMX_ERR_ARG, "merge index out of range");
     const MergeRecord& rec = merges_[merge];
     const int64_t P = rec.npairs;
     std::vector<int32_t> f((size_t)P), s((size_t)P);

@@ -19,7 +19,7 @@ struct Node {
     DevBuf<double> data;     // [n][d] row-major
     int n = 0;
     bool has_restrict = false;
-    DevBuf<int32_t> restrict_rows;  // 0-based, strictly increasing
+    DevBuf<int32_t> restrict_rows;  // 0-based, in the caller's order (an R subsetting vector: any order, repeats allowed)
     int n_restrict = 0;
     std::vector<Segment> origin;  // MNN_treenode@origin as run lengths
     std::vector<int> extras;      // ids of batch vectors in the engine's pool (MNN_treenode@extras)
@@ -75,6 +75,10 @@ class Engine {
     // cntL_, offL_ (per row of idxLR_), partR_, cntR_, second_u_
     MnnOut find_mnn(const Node& left, const Node& right, int k, double prop_k);
 
+  private:
+    DevBlockCache cache_;  // first member: destroyed last, after every DevBuf below has handed its block back
+  public:
+    DevBlockCache* cache() { return &cache_; }
     int d_ = 0;
     KnnWorkspace knn_ws_;
     ScanWorkspace scan_ws_;

@@ -1056,7 +1056,9 @@ void knn_device(hipStream_t stream, KnnWorkspace& ws, const double* X, const int
         }
         if (count > 0) {
             const size_t budget = (size_t)512 << 20;
-            const int batch = (int)std::min<size_t>(std::max<size_t>(1, budget / ((size_t)nr * 8)), (size_t)count);
+            // grid.y carries the queries of a batch: at most 65535 of them
+            const int batch =
+                (int)std::min<size_t>({std::max<size_t>(1, budget / ((size_t)nr * 8)), (size_t)count, (size_t)65535});
             double* drow = ws.drow.reserve((size_t)batch * nr);
             for (int f0 = 0; f0 < count; f0 += batch) {
                 const int nb = std::min(batch, count - f0);

@@ -607,14 +607,8 @@ void launch(hipStream_t stream, KnnWorkspace& ws, const Bf16Launch& L) {
     constexpr size_t lds = (size_t)ring_slots(NS, KS, NCONS, PLN) * NS * 1024 +
                            (size_t)NCONS * 32 * list_pitch(KS, PLN) * 8 + 512;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static bool attr_set = false;
-    if (!attr_set) {
-        BMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_topk_bf16<NS, KS, NCONS, NPROD, PLN, false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        BMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_topk_bf16<NS, KS, NCONS, NPROD, PLN, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    ensure_dynamic_lds(reinterpret_cast<const void*>(&knn_topk_bf16<NS, KS, NCONS, NPROD, PLN, false>), lds);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(&knn_topk_bf16<NS, KS, NCONS, NPROD, PLN, true>), lds);
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     if (ws.profile) {
         ev = ws.next_events();

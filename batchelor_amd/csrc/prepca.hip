@@ -116,7 +116,8 @@ void cosnorm_project_device(hipStream_t stream, const double* x, int G, int n, c
     if (d > 256) throw Error(BMX_ERR_ARG, "more than 256 dimensions are not supported");
     hipLaunchKernelGGL(center_dot_kernel, dim3(cdiv(d, 4)), dim3(256), 0, stream, centers, u, G, d, cu_scratch);
     BMX_LAUNCH_CHECK();
-    const size_t lds = ((size_t)CB * (GT + 1) + (size_t)GT * d) * sizeof(double);
+    const size_t lds = ((size_t)CB * (GT + 1) + (size_t)GT * d) * sizeof(double);  // 139 KiB at d = 256
+    ensure_dynamic_lds(reinterpret_cast<const void*>(&cosnorm_project_kernel), lds);
     hipLaunchKernelGGL(cosnorm_project_kernel, dim3(cdiv(n, CB)), dim3(256), lds, stream, x, G, n, u, d, cu_scratch,
                        cos_norm, out, l2_out);
     BMX_LAUNCH_CHECK();
