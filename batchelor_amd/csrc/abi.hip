@@ -496,6 +496,14 @@ int32_t bmx_engine_profile(bmx_engine_t* e, double* topk_ms, int64_t* topk_launc
     return guarded([&] { e->impl->profile(topk_ms, topk_launches, exact_fallbacks); });
 }
 
+int32_t bmx_engine_set_snapshot(bmx_engine_t* e, int32_t merge) {
+    return guarded([&] { e->impl->set_snapshot(merge); });
+}
+
+int32_t bmx_engine_snapshot(bmx_engine_t* e, double* left_rm, double* right_rm, int64_t* n_left, int64_t* n_right) {
+    return guarded([&] { e->impl->snapshot(left_rm, right_rm, n_left, n_right); });
+}
+
 int32_t bmx_engine_knn_variant(bmx_engine_t* e) { return e && e->impl ? e->impl->knn_ws_.last_variant : -1; }
 
 int32_t bmx_fast_mnn(int32_t nbatches, int32_t d, const double* const* data, const int32_t* nrows,

@@ -261,6 +261,14 @@ void Engine::merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p,
     orthogonalize(right, left.extras);  // R/fastMNN.R:473-474
     orthogonalize(left, right.extras);
 
+    if (mdx == snap_merge_) {
+        snap_nl_ = left.n;
+        snap_nr_ = right.n;
+        BMX_HIP(hipMemcpyAsync(snap_l_.reserve((size_t)left.n * d_), left.data.p, (size_t)left.n * d_ * sizeof(double),
+                               hipMemcpyDeviceToDevice, stream_));
+        BMX_HIP(hipMemcpyAsync(snap_r_.reserve((size_t)right.n * d_), right.data.p,
+                               (size_t)right.n * d_ * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+    }
     const MnnOut mo = find_mnn(left, right, p.k, p.prop_k);  // R/fastMNN.R:476-477
     if (mo.P == 0) throw Error(BMX_ERR_NO_PAIRS, "no mutual nearest neighbours found between batches");
     const int nLs = left.has_restrict ? left.n_restrict : left.n;
@@ -623,6 +631,19 @@ void Engine::pairs(int merge, int32_t** left, int32_t** right, int64_t* npairs) 
     *right = R;
     *npairs = P;
     (void)root_start;
+}
+
+void Engine::snapshot(double* left_rm, double* right_rm, int64_t* nl, int64_t* nr) {
+    CacheScope cache_scope(&cache_);
+    BMX_HIP(hipSetDevice(device_));
+    if (snap_merge_ < 0 || !root_ || !snap_l_.p) throw Error(BMX_ERR_ARG, "no snapshot was taken");
+    if (nl) *nl = snap_nl_;
+    if (nr) *nr = snap_nr_;
+    if (left_rm)
+        BMX_HIP(hipMemcpyAsync(left_rm, snap_l_.p, (size_t)snap_nl_ * d_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    if (right_rm)
+        BMX_HIP(hipMemcpyAsync(right_rm, snap_r_.p, (size_t)snap_nr_ * d_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    BMX_HIP(hipStreamSynchronize(stream_));
 }
 
 void Engine::merge_stats(int merge, int64_t* out6) const {

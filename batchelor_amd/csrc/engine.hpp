@@ -57,6 +57,10 @@ class Engine {
     void pairs(int merge, int32_t** left, int32_t** right, int64_t* npairs);
     void merge_stats(int merge, int64_t* out6) const;
     void set_profiling(bool on) { knn_ws_.profile = on; }
+    // diagnostics: keep a copy of the two matrices merge `merge` searches (left and right node after
+    // orthogonalisation, R/fastMNN.R:473-477); -1 = off
+    void set_snapshot(int merge) { snap_merge_ = merge; }
+    void snapshot(double* left_rm, double* right_rm, int64_t* nl, int64_t* nr);
     void profile(double* topk_ms, int64_t* launches, int64_t* fallbacks);
     int nbatches() const { return B_; }
     int64_t total_cells() const { return N_; }
@@ -102,6 +106,9 @@ class Engine {
     bmx_allgather_fn gather_fn_ = nullptr;
     void* gather_ctx_ = nullptr;
     int64_t fallbacks_ = 0;
+    int snap_merge_ = -1;
+    DevBuf<double> snap_l_, snap_r_;
+    int64_t snap_nl_ = 0, snap_nr_ = 0;
 
     int B_ = 0;
     int64_t N_ = 0;

@@ -134,6 +134,19 @@ class MnnEngine:
         return {"topk_ms": ms.value, "topk_launches": n.value, "exact_fallbacks": fb.value,
                 "variant": int(_lib.lib().bmx_engine_knn_variant(self._h))}
 
+    def set_snapshot(self, merge):
+        """Diagnostics: keep the two matrices merge `merge` (0-based) searches; None switches it off."""
+        _lib.check(_lib.lib().bmx_engine_set_snapshot(self._h, -1 if merge is None else int(merge)))
+
+    def snapshot(self):
+        """(left, right) of the snapshot merge, row-major [n x d], as handed to findMutualNN."""
+        nl, nr = ctypes.c_int64(0), ctypes.c_int64(0)
+        _lib.check(_lib.lib().bmx_engine_snapshot(self._h, None, None, ctypes.byref(nl), ctypes.byref(nr)))
+        left = np.zeros((nl.value, self.d), dtype=np.float64)
+        right = np.zeros((nr.value, self.d), dtype=np.float64)
+        _lib.check(_lib.lib().bmx_engine_snapshot(self._h, _lib.f64p(left), _lib.f64p(right), None, None))
+        return left, right
+
     def merge_stats(self):
         out = []
         for m in range(self.nbatches - 1):

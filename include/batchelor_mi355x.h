@@ -125,6 +125,12 @@ int32_t bmx_engine_merge_stats(bmx_engine_t* e, int32_t merge, int64_t* out6);
  * stream; after a run: total milliseconds, number of launches, and queries that needed the exact re-scan. */
 int32_t bmx_engine_set_profiling(bmx_engine_t* e, int32_t on);
 int32_t bmx_engine_profile(bmx_engine_t* e, double* topk_ms, int64_t* topk_launches, int64_t* exact_fallbacks);
+/* Diagnostics for full-size parity checks: the next runs keep a device copy of the two matrices that merge `merge`
+ * (0-based; -1 = off) hands to findMutualNN -- the left and right node after orthogonalisation
+ * (R/fastMNN.R:473-477).  bmx_engine_snapshot copies them out ROW-major ([n x d], cells in node order); pass NULL
+ * matrices to read the sizes first. */
+int32_t bmx_engine_set_snapshot(bmx_engine_t* e, int32_t merge);
+int32_t bmx_engine_snapshot(bmx_engine_t* e, double* left_rm, double* right_rm, int64_t* n_left, int64_t* n_right);
 /* Candidate-pass kernel used by the engine's last MFMA-path search: 2 = knn_topk_bf16 (split-bf16 MFMA, LDS ring),
  * 1 = knn_topk_w1 (f32 MFMA, wave per workgroup), 0 = knn_topk_mfma (f32 MFMA, LDS staging), -1 = none yet.
  * The environment variable BMX_TOPK_VARIANT selects it for A/B runs. */

@@ -1,0 +1,90 @@
+"""GPU tests of the C ABI exactly as INTEGRATION.md's .Call shim drives it: the one-shot bmx_fast_mnn() with R's
+memory layout (column-major doubles, int32, 1-based ids), then bmx_engine_pairs() on the returned handle; plus
+edge shapes of the boundary: `restrict` as an arbitrary R subsetting vector, and the exact FP64 path with more
+queries than a launch grid's y dimension holds."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from tests.conftest import synth_batches
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bmx_fast_mnn_one_shot_as_the_shim_calls_it(oracle):
+    from batchelor_amd import _lib
+    from batchelor_amd.merge_tree import encode_postorder, resolve_merge_order
+    from batchelor_amd.reduced_mnn import BmxParams
+    L = _lib.lib()
+    B = synth_batches(8, [900, 700, 800], 25)
+    nb, d = len(B), 25
+    mats = [np.asfortranarray(b) for b in B]                       # REAL(x): column-major
+    data = (ctypes.c_void_p * nb)(*[m.ctypes.data for m in mats])
+    nrows = np.asarray([m.shape[0] for m in mats], dtype=np.int32)
+    n_restrict = np.full(nb, -1, dtype=np.int32)                   # restrict = NULL
+    tree = encode_postorder(resolve_merge_order(nb, [3, 1, 2]))    # merge.order = c(3, 1, 2)
+    params = BmxParams(20, float("nan"), 3.0, 0.0, 0)
+    N = int(nrows.sum())
+    corrected = np.zeros((N, d), dtype=np.float64, order="F")
+    batch = np.zeros(N, dtype=np.int32)
+    ml = np.zeros((nb - 1, nb), dtype=np.int32)
+    mr = np.zeros((nb - 1, nb), dtype=np.int32)
+    bs = np.zeros(nb - 1)
+    sk = np.zeros(nb - 1, dtype=np.int32)
+    lv = np.zeros((nb - 1, nb), dtype=np.float64, order="F")
+    h = ctypes.c_void_p()
+    rc = L.bmx_fast_mnn(nb, d, data, _lib.i32p(nrows), None, _lib.i32p(n_restrict), ctypes.byref(params),
+                        _lib.i32p(tree), int(tree.size), _lib.f64p(corrected), _lib.i32p(batch), _lib.i32p(ml),
+                        _lib.i32p(mr), _lib.f64p(bs), _lib.i32p(sk), _lib.f64p(lv), ctypes.byref(h))
+    _lib.check(rc)
+    try:
+        ref = oracle.reduced_mnn(*B, merge_order=[3, 1, 2])
+        np.testing.assert_allclose(corrected, ref.corrected, rtol=1e-5, atol=1e-12)
+        assert batch.tolist() == list(ref.batch)
+        assert [[int(x) for x in row if x] for row in ml] == ref.merge_info.left
+        assert [[int(x) for x in row if x] for row in mr] == ref.merge_info.right
+        np.testing.assert_allclose(bs, ref.merge_info.batch_size, rtol=1e-9)
+        assert sk.tolist() == [0, 0]
+        np.testing.assert_allclose(lv, ref.merge_info.lost_var, rtol=1e-7, atol=1e-12)
+        for m in range(nb - 1):
+            pl, pr, n = _lib.c_i32p(), _lib.c_i32p(), ctypes.c_int64(0)
+            _lib.check(L.bmx_engine_pairs(h, m, ctypes.byref(pl), ctypes.byref(pr), ctypes.byref(n)))
+            gl, gr = _lib.take_i32(pl, n.value), _lib.take_i32(pr, n.value)
+            assert np.array_equal(gl, ref.merge_info.pairs[m][0]) and np.array_equal(gr, ref.merge_info.pairs[m][1])
+        # error path: the reference's message, no engine handed back
+        bad = np.asarray([1, 2, 2, 0, 0], dtype=np.int32)
+        h2 = ctypes.c_void_p()
+        rc = L.bmx_fast_mnn(nb, d, data, _lib.i32p(nrows), None, _lib.i32p(n_restrict), ctypes.byref(params),
+                            _lib.i32p(bad), 5, None, None, None, None, None, None, None, ctypes.byref(h2))
+        assert rc != 0 and not h2.value
+        assert "invalid leaf nodes" in L.bmx_last_error().decode()
+    finally:
+        L.bmx_engine_destroy(h)
+
+
+def test_restrict_is_an_r_subsetting_vector_any_order_with_repeats(oracle):
+    # checkRestrictions() turns `restrict` into integer positions in the caller's order (R/checkInputs.R:96-120,
+    # R/utils_subset.R): unsorted and repeated entries are legal and change the order of the pairs
+    import batchelor_amd as bx
+    from tests.test_gpu_engine import assert_same_result
+    rng = np.random.default_rng(77)
+    B = synth_batches(9, [500, 400, 450], 15)
+    keep = [rng.permutation(500)[:300] + 1, None, np.concatenate([rng.permutation(450)[:200] + 1, [5, 5, 17]])]
+    out = bx.reducedMNN(*B, restrict=keep)
+    ref = oracle.reduced_mnn(*B, restrict=keep)
+    assert_same_result(out, ref)
+
+
+def test_exact_path_with_more_queries_than_grid_y(oracle):
+    # nr <= 48 references: below the candidate pass's minimum, every query takes the exact FP64 scan, whose launches
+    # carry the queries in grid.y (at most 65535 per launch)
+    from batchelor_amd import neighbors as nb
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((40, 6))
+    Q = rng.standard_normal((70000, 6))
+    idx, dist = nb.query_knn(X, Q, 7)
+    rows = np.concatenate([np.arange(0, 70000, 997), [65534, 65535, 65536, 69999]])
+    oi, od = oracle.query_knn(X, Q[rows], 7)
+    assert np.array_equal(idx[rows], oi) and np.array_equal(dist[rows], od)
+    assert idx.min() >= 1 and idx.max() <= 40 and np.all(np.diff(dist, axis=1) >= 0)

@@ -1,0 +1,48 @@
+"""GPU parity on the shape of BASELINE.json configs[4], scaled down: 16 unequal batches (log-uniform sizes), 100 PCs,
+a balanced merge.order tree over the size-sorted batches -- sibling subtrees, nodes that carry several batch vectors
+on BOTH sides of a merge, d = 100 (seven MFMA k-steps).  Whole result against the CPU oracle, pairs bit-exact."""
+import numpy as np
+import pytest
+
+from tests.conftest import synth_batches
+from tests.test_gpu_engine import assert_same_result
+
+pytestmark = pytest.mark.gpu
+
+
+def balanced_tree(ids):
+    if len(ids) == 1:
+        return ids[0]
+    h = len(ids) // 2
+    return [balanced_tree(ids[:h]), balanced_tree(ids[h:])]
+
+
+def config5_scaled():
+    rng = np.random.Generator(np.random.PCG64(20250314 + 5000))
+    sizes = [int(x) for x in np.exp(rng.uniform(np.log(300), np.log(6000), 16))]
+    order = [int(i) + 1 for i in np.argsort(sizes)[::-1]]
+    return sizes, balanced_tree(order)
+
+
+def test_config5_scaled_sixteen_batch_tree_vs_oracle(oracle):
+    import batchelor_amd as bx
+    sizes, tree = config5_scaled()
+    B = synth_batches(5, sizes, 100)
+    out = bx.reducedMNN(*B, merge_order=tree)
+    ref = oracle.reduced_mnn(*B, merge_order=tree)
+    assert_same_result(out, ref)
+    assert len(out.merge_info.pairs) == 15
+    # the last merge joins two 8-batch subtrees
+    assert len(out.merge_info.left[-1]) == 8 and len(out.merge_info.right[-1]) == 8
+
+
+def test_k30_d100_candidate_pass_vs_oracle(oracle):
+    # k in (20, 36] with d > 84: the shape the split-bf16 kernel does not cover (see knn.hip: tier selection)
+    from batchelor_amd import neighbors as nb
+    X, Q = synth_batches(6, [5000, 1500], 100)
+    idx, dist = nb.query_knn(X, Q, 30)
+    oi, od = oracle.query_knn(X, Q, 30)
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+    B = synth_batches(6, [1500, 1200], 100)
+    import batchelor_amd as bx
+    assert_same_result(bx.reducedMNN(*B, k=30), oracle.reduced_mnn(*B, k=30))
