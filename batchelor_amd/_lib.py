@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbatchelor_mi355x.so")
+# BMX_LIB: developer switch, another build of the same library (e.g. `make STAMPS=1`: per-wave cycle accounting)
+LIB_PATH = os.environ.get("BMX_LIB") or os.path.join(_HERE, "libbatchelor_mi355x.so")
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 c_i64p = ctypes.POINTER(ctypes.c_int64)

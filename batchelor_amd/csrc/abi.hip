@@ -46,7 +46,6 @@ bmx::Engine& prim(int d) {
     }
     g_prim->d_ = d;
     g_prim->knn_ws_.force_exact = g_force_exact;
-    g_prim->knn_ws_.flag_total = nullptr;
     return *g_prim;
 }
 
@@ -133,12 +132,10 @@ int32_t bmx_query_knn(const double* X, int32_t nx, const double* query, int32_t 
         e.knn(px, nullptr, nx, pq, nullptr, nq, k, pi, pd);
         std::vector<int32_t> hi((size_t)nq * k);
         std::vector<double> hd((size_t)nq * k);
-        int32_t nflag = 0;
         BMX_HIP(hipMemcpyAsync(hi.data(), pi, hi.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
         BMX_HIP(hipMemcpyAsync(hd.data(), pd, hd.size() * sizeof(double), hipMemcpyDeviceToHost, s));
-        BMX_HIP(hipMemcpyAsync(&nflag, e.knn_ws_.flagged.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         BMX_HIP(hipStreamSynchronize(s));
-        g_last_fallbacks = nflag;
+        g_last_fallbacks = e.knn_ws_.last_exact;
         for (int64_t q = 0; q < nq; ++q)
             for (int64_t j = 0; j < k; ++j) {
                 if (index) index[j * nq + q] = hi[(size_t)(q * k + j)] + 1;

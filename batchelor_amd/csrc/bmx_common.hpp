@@ -144,24 +144,27 @@ struct DevBuf {
 // Device-level operations (all on `stream`, all pointers device pointers, matrices row-major cells x dims)
 // ---------------------------------------------------------------------------------------------------
 struct KnnWorkspace {
-    DevBuf<float> pq, pr;          // prepared (centred, f32, augmented) queries / references
+    DevBuf<float> pq, pr;          // prepared (centred, fp16 / split-bf16, augmented) queries / references
     DevBuf<double> qn2, rn2, mean, red;
     DevBuf<int32_t> cand;          // [nq][C][KS]
     DevBuf<float> tau;             // [nq][C]
-    DevBuf<float> cand_v;          // [nq][C][KS] approximate values (multi-range runs: refine pre-ranks by them)
-    DevBuf<uint32_t> tau_g;        // [nq] per-query thresholds shared across reference ranges (split-bf16 kernel)
-    DevBuf<unsigned long long> maxslots;  // 64 x 16 words: per-slot maxima of the reference norms (split-bf16 prep)
-    DevBuf<uint64_t> seed;         // [nq][KS + 1] kept list of the sample range (wave-per-workgroup kernel)
-    DevBuf<int32_t> flagged;       // [nq + 1] compact list of queries needing the exact path (+ counter)
+    DevBuf<float> cand_v;          // [nq][C][KS] approximate values of the candidates (refine pre-ranks by them)
+    DevBuf<uint32_t> tau_g;        // [nq] per-query thresholds shared across reference ranges
+    DevBuf<unsigned long long> maxslots;  // 64 x 16 words: per-slot maxima of the reference norms (prep kernels)
+    // per candidate tier: [count + 1] compact list of the queries it could not certify (+ counter in word 0), their
+    // k-th candidate distances, and the scratch of the sub-search the next tier runs on them
+    DevBuf<int32_t> flagged_t[2], sub_rows[2], sub_idx[2];
+    DevBuf<double> flag_bound_t[2], sub_dist[2];
     DevBuf<double> drow;           // exact-path distance rows
-    DevBuf<double> flag_bound, xd; // k-th candidate distance of flagged queries; short exact lists
+    DevBuf<double> xd;             // short exact lists
     DevBuf<int32_t> xcnt, xi, slow;
-    DevBuf<int32_t> idx_tmp;
-    DevBuf<double> dist_tmp;
-    int64_t last_flagged = 0;      // diagnostics: queries that took the exact path in the last call
     int force_exact = 0;           // testing hook: route every query through the exact path
-    // profiling: when on, every launch of the MFMA top-k kernel is bracketed by an event pair from this pool
-    int last_variant = -1;  // candidate-pass variant used by the last MFMA-path search (2 bf16 ring, 1 f32 wave, 0 f32 LDS)
+    // diagnostics of the last search / totals since the engine reset them
+    int64_t last_exact = 0;             // queries that took the exact FP64 path
+    int64_t last_flagged_tier[2] = {0, 0};  // queries each candidate tier could not certify
+    int64_t exact_total = 0, tier2_total = 0;
+    // profiling: when on, every launch of a candidate-pass kernel is bracketed by an event pair from this pool
+    int last_variant = -1;  // candidate pass of the last search's first tier: 3 = fp16 ring, 2 = split-bf16 ring
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
@@ -180,7 +183,6 @@ struct KnnWorkspace {
             (void)hipEventDestroy(e.second);
         }
     }
-    unsigned long long* flag_total = nullptr;  // device counter accumulating exact-path queries (optional)
 };
 
 // split-bf16 candidate pass (knn_bf16.hip)
@@ -191,7 +193,7 @@ struct Bf16Launch {
     uint32_t* tau_g;        // per-query threshold shared by all ranges (orderable image); sample pass writes it
     int sample;             // non-zero: threshold-estimation pass, writes tau_g[q] only
     int32_t* cand;
-    float* cand_v;          // approximate values of the candidates (null: not needed, single range)
+    float* cand_v;          // approximate values of the candidates
     float* tau;
     int n_full = 0;         // the first n_full query blocks sweep [first_begin, r_limit) as ONE range; the others split it
 };

@@ -47,8 +47,7 @@ Engine::Engine(int device) : device_(device) {
     CacheScope cache_scope(&cache_);
     BMX_HIP(hipSetDevice(device_));
     BMX_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-    unsigned long long* tot = reinterpret_cast<unsigned long long*>(scal_.reserve(4096));
-    (void)tot;
+    scal_.reserve(4096);
 }
 
 Engine::~Engine() {
@@ -103,10 +102,15 @@ void Engine::upload(int nbatches, int d, const double* const* data, const int32_
         if (has) {
             const int m = n_restrict[b];
             if (m == 0) throw Error(BMX_ERR_ARG, "no cells remaining in a batch after restriction");  // R/checkInputs.R:116
+            // an R subsetting vector in the caller's order (R/checkInputs.R:96-120 keeps it as given).  Repeated cells
+            // are refused: the reference would search them as separate points but average them as one cell.
             std::vector<int32_t> z(m);
+            std::vector<char> seen((size_t)nrows[b], 0);
             for (int i = 0; i < m; ++i) {
                 const int32_t v = restrict_idx[b][i];
                 if (v < 1 || v > nrows[b]) throw Error(BMX_ERR_SUBSET, "subset indices out of range");
+                if (seen[v - 1]) throw Error(BMX_ERR_ARG, "'restrict' names a cell more than once");
+                seen[v - 1] = 1;
                 z[i] = v - 1;
             }
             int32_t* rp = inputs_restrict_[b].reserve(m);
@@ -405,7 +409,7 @@ void Engine::run(const bmx_params_t& p, const int32_t* tree, int tree_len) {
         BMX_HIP(hipMemsetAsync(scal_.p, 0, (size_t)off * sizeof(double), stream_));
         scal_host_.assign(off, 0.0);
     }
-    knn_ws_.flag_total = reinterpret_cast<unsigned long long*>(scal_.p);
+    knn_ws_.exact_total = knn_ws_.tier2_total = 0;
 
     // leaves: row-major working copies of the resident inputs
     std::vector<TreeSlot> slots;
@@ -530,9 +534,7 @@ void Engine::run(const bmx_params_t& p, const int32_t* tree, int tree_len) {
     BMX_HIP(hipMemcpyAsync(scal_host_.data(), scal_.p, scal_host_.size() * sizeof(double), hipMemcpyDeviceToHost,
                            stream_));
     BMX_HIP(hipStreamSynchronize(stream_));
-    unsigned long long tot = 0;
-    std::memcpy(&tot, scal_host_.data(), sizeof(tot));
-    fallbacks_ = (int64_t)tot;
+    fallbacks_ = knn_ws_.exact_total;
 }
 
 void Engine::download(double* corrected, int32_t* batch, int32_t* merge_left, int32_t* merge_right,

@@ -19,7 +19,7 @@ struct Node {
     DevBuf<double> data;     // [n][d] row-major
     int n = 0;
     bool has_restrict = false;
-    DevBuf<int32_t> restrict_rows;  // 0-based, in the caller's order (an R subsetting vector: any order, repeats allowed)
+    DevBuf<int32_t> restrict_rows;  // 0-based, in the caller's order (any order, no cell twice)
     int n_restrict = 0;
     std::vector<Segment> origin;  // MNN_treenode@origin as run lengths
     std::vector<int> extras;      // ids of batch vectors in the engine's pool (MNN_treenode@extras)

@@ -1,0 +1,824 @@
+// Tier 1 of the exact kNN: a single-product fp16 candidate pass (MI355X / gfx950).
+//
+// The candidate pass only has to be accurate enough for the FP64 certificate of knn_refine to hold for almost every
+// query; the few it cannot certify go on to the split-bf16 pass (knn_bf16.hip) and, failing that, to the exact
+// FP64 scan.  So here every operand is ONE fp16 value: with the centred coordinates scaled by a power of two s so
+// that the largest reference norm lands in (24, 48] (no overflow, no underflow that matters),
+//     v' = |r'|^2 - 2 q'.r'   comes out of one chain of K/16 v_mfma_f32_32x32x16_f16 over
+//     refs    [ r'_1 .. r'_d | n1 n2 n3 | 0 .. ],   n1 + n2 + n3 = f32(|r'|^2) exactly (three fp16 pieces)
+//     queries [ -2 q'_1 .. -2 q'_d | 1 1 1 | 0 .. ]
+// with |v' - exact| <= 2^-9 (1 + 2^-12) |q'||r'| + f32 accumulation terms: 4 MFMAs per 32 x 32 tile at 50 PCs
+// (K = 64) against 10 for the split-bf16 pass (K = 160).  At 50 PCs on 100 000 reference cells the bound is about
+// 0.05 against a gap of 0.35 between the 20th and the 32nd neighbour, so with KS = 32 kept candidates practically
+// every query is certified.
+//
+// With the matrix work that cheap the vector instructions of the selection set the pace, so the selection is built
+// to need few of them per tile:
+//   * filter: the 32 x 32 accumulator puts a query on each lane; min over its 16 values (v_min3 tree, issued in the
+//     gaps of the MFMA chain of the next tile), one compare, one scalar branch -- most tiles end here;
+//   * spill: a lane whose group of 4 consecutive references holds a survivor dumps the group's four raw values
+//     (one ds_write_b128) and a tag (tile, group, lane) into its wave's queue in the LDS: five vector instructions
+//     per group with survivors, whatever the number of lanes involved, no per-value work;
+//   * drain: when the queue is nearly full (every ~30 tiles) the wave works it off with all 64 lanes busy: 16
+//     records = 64 values per round, each lane re-tests one value against its query's current threshold
+//     (ds_bpermute from the owning lane's register) and appends it to the query's list with an LDS atomic;
+//   * compaction: a query's list (KS kept + pending, <= 64 entries, unsorted) is cut back to its KS smallest by a
+//     quickselect over the wave (pivot by readlane, ballot + popcount per round: ~2 vector instructions per round,
+//     ~8 rounds) and the threshold drops to the cut -- once per ~30 appended candidates.
+// Everything else (LDS ring of reference tiles filled by producer waves, hand-over through LDS words without
+// barriers, software-pipelined tile loop, shared thresholds across reference ranges, register-only sample pass)
+// follows knn_bf16.hip.
+#include "bmx_common.hpp"
+#include "knn_select.hpp"
+
+#include <cmath>
+
+namespace bmx {
+namespace {
+
+using namespace sel;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int NCONS = 8;   // consumer waves (32 queries each): two per SIMD
+constexpr int NPROD = 4;   // producer waves: one per SIMD
+constexpr int NQ = NCONS * 32;
+constexpr int QCAP = 64;   // spill records per consumer wave (one group of one tile can fill all 64)
+constexpr int QSOFT = 32;  // ... but the queue is worked off as soon as it holds this many: short, frequent stalls
+constexpr int HEAD = 8;    // a list is compacted ahead of time once fewer than HEAD slots are free
+
+__device__ __forceinline__ uint16_t f32_to_f16_bits(float f) {
+    const _Float16 h = (_Float16)f;  // v_cvt_f16_f32: round to nearest even, overflow to infinity
+    return __builtin_bit_cast(uint16_t, h);
+}
+__device__ __forceinline__ float f16_bits_to_f32(uint16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
+
+// power-of-two scale that puts the largest reference norm into (24, 48]; 1 for degenerate input
+__host__ __device__ __forceinline__ double f16_scale(double max_n2) {
+    const double rm = sqrt(max_n2);
+    if (!(rm > 1e-150) || !(rm < 1e150)) return 1.0;
+    int e = 0;
+    (void)frexp(48.0 / rm, &e);  // 48 / rm = f * 2^e, f in [0.5, 1)
+    return ldexp(1.0, e - 1);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// prep.  PHASE 0 (references only): centred f32 rows -> exact norms n2[] and their maximum (the scale needs it
+// before anything is written).  PHASE 1: the fp16 tile images (fragment-major for references, row-major for
+// queries; same addressing as knn_prep_bf16), scaled.
+// ---------------------------------------------------------------------------------------------------
+template <int PHASE>
+__global__ __launch_bounds__(256) void knn_prep_f16(const double* __restrict__ X, const int32_t* __restrict__ rows, int n,
+                                                    int d, int NS, const double* __restrict__ mean, int is_query,
+                                                    uint16_t* __restrict__ P, double* __restrict__ n2,
+                                                    unsigned long long* __restrict__ max_slots,
+                                                    const unsigned long long* __restrict__ max_n2_bits) {
+    extern __shared__ __attribute__((aligned(16))) char smem_pp[];
+    const int K = 16 * NS;
+    float* xs = reinterpret_cast<float*>(smem_pp);  // [32][d] centred, rounded to f32
+    float* nrm = xs + 32 * d;                       // [32] f32(|x'|^2), scaled
+    const int tid = threadIdx.x;
+    const int r0 = blockIdx.x * 32;
+    const float inv_d = 1.0f / (float)d;
+    for (int e = tid; e < 32 * d; e += 256) {
+        int rr = (int)(((float)e + 0.5f) * inv_d);  // e < 32 * 128: the float quotient is exact up to +-1
+        int c = e - rr * d;
+        if (c < 0) {
+            --rr;
+            c += d;
+        } else if (c >= d) {
+            ++rr;
+            c -= d;
+        }
+        const int r = r0 + rr;
+        float f = 0.f;
+        if (r < n) {
+            const int64_t row = rows ? rows[r] : r;
+            f = (float)(X[row * d + c] - mean[c]);
+        }
+        xs[e] = f;
+    }
+    __syncthreads();
+    const int rr = tid >> 3, sub = tid & 7;  // eight threads per row
+    const bool live = r0 + rr < n;
+    double s = 0.0;  // |x~|^2 of the f32-rounded centred row (exact products, FP64 sum)
+    for (int c = sub; c < d; c += 8) {
+        const double f = (double)xs[rr * d + c];
+        s += f * f;
+    }
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 4);
+    if constexpr (PHASE == 0) {
+        if (sub == 0 && live) n2[r0 + rr] = s;
+        double m = live ? s : 0.0;
+        for (int o = 8; o < 64; o <<= 1) m = fmax(m, __shfl_xor(m, o));
+        if ((tid & 63) == 0)  // one atomic per wave, spread over 64 words a cache line apart
+            atomicMax(max_slots + (size_t)(blockIdx.x & 63) * 16, (unsigned long long)__double_as_longlong(m));
+        return;
+    }
+    const double scale = f16_scale(__longlong_as_double((long long)*max_n2_bits));
+    const float sf = (float)scale;  // a power of two: every product below is exact
+    if (is_query) {
+        // a query so far out that -2 q' leaves the fp16 range cannot be handled here: poison its norm, the
+        // certificate of knn_refine then fails and the query goes to the next tier
+        bool bad = false;
+        for (int c = sub; c < d; c += 8) bad |= !(fabsf(-2.f * xs[rr * d + c] * sf) <= 65504.f);
+        bad |= __shfl_xor((int)bad, 1) != 0;
+        bad |= __shfl_xor((int)bad, 2) != 0;
+        bad |= __shfl_xor((int)bad, 4) != 0;
+        if (sub == 0 && live) n2[r0 + rr] = bad ? __builtin_nan("") : s;
+    }
+    if (sub == 0) nrm[rr] = (float)(s * scale * scale);
+    __syncthreads();
+    uint4* out = reinterpret_cast<uint4*>(P + (int64_t)r0 * K);
+    const int npieces = 32 * 2 * NS;
+    const float inv_pc = 1.0f / (float)(2 * NS);
+    for (int p = tid; p < npieces; p += 256) {
+        int prow, i;  // row of the tile, 8-element chunk of the row
+        if (is_query) {
+            prow = (int)(((float)p + 0.5f) * inv_pc);
+            i = p - prow * 2 * NS;
+            if (i < 0) {
+                --prow;
+                i += 2 * NS;
+            } else if (i >= 2 * NS) {
+                ++prow;
+                i -= 2 * NS;
+            }
+        } else {
+            prow = p & 31;
+            const int ih = p >> 5;  // = 2 * k-step + lane half
+            i = (ih & 1) * NS + (ih >> 1);
+        }
+        const bool plive = r0 + prow < n;
+        const float nf = nrm[prow];  // three fp16 pieces reproduce the f32 value exactly (33 bits)
+        const uint16_t na = f32_to_f16_bits(nf);
+        const float nr1 = nf - f16_bits_to_f32(na);
+        const uint16_t nb = f32_to_f16_bits(nr1);
+        const uint16_t nc = f32_to_f16_bits(nr1 - f16_bits_to_f32(nb));
+        uint32_t w[4];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int L = 8 * i + e;
+            uint16_t v = 0;
+            if (L < d) {
+                const float f = xs[prow * d + L] * sf;
+                v = f32_to_f16_bits(is_query ? -2.f * f : f);
+            } else if (L < d + 3) {
+                const int piece = L - d;
+                if (is_query)
+                    v = plive ? 0x3C00 : 0;  // 1.0 (padded queries stay all-zero)
+                else if (!plive)
+                    v = piece == 0 ? 0x7C00 : 0;  // +inf: a padded reference never passes a threshold
+                else
+                    v = piece == 0 ? na : (piece == 1 ? nb : nc);
+            }
+            if (e & 1)
+                w[e >> 1] |= (uint32_t)v << 16;
+            else
+                w[e >> 1] = v;
+        }
+        out[p] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LDS budget: ring of reference tiles | per-query lists | per-wave spill queues | list counters | hand-over words
+// ---------------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int lds_fixed_bytes() { return NCONS * QCAP * 20 + NQ * 4 + 512; }
+__host__ __device__ constexpr int ring_slots_for(int NS, int LCAP) {
+    const int rest = 160 * 1024 - lds_fixed_bytes() - NQ * LCAP * 8;
+    const int n = rest / (NS * 1024);
+    return n > 8 ? 8 : n;
+}
+// list capacity: as long as the ring keeps at least four slots, else as short as a useful pending part allows
+__host__ __device__ constexpr int list_cap(int NS, int KS) {
+    for (int c = 64; c >= KS + 16; c -= 8)
+        if (ring_slots_for(NS, c) >= 4) return c;
+    return KS + 16 <= 64 ? KS + 16 : 64;
+}
+
+__device__ __forceinline__ int lds_load_volatile(const int* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ int mbcnt64(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+#ifdef BMX_STAMPS
+__device__ unsigned long long bmx_dbg16[48];
+#define STAMP() __builtin_readcyclecounter()
+#endif
+
+template <int NS, int KS, int LCAP, bool SAMPLE>
+__global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
+    const uint16_t* __restrict__ Pq, const uint16_t* __restrict__ PrF, int first_begin, int range_len, int r_limit,
+    int n_full, int nranges, int out_chunk0, int out_nchunks, uint32_t* __restrict__ tau_g, int32_t* __restrict__ cand,
+    float* __restrict__ cand_v, float* __restrict__ tau_out) {
+    constexpr int TILE_BYTES = NS * 1024;
+    constexpr int NSLOT = ring_slots_for(NS, LCAP);
+    static_assert(NSLOT >= 2, "LDS ring");
+    static_assert(LCAP <= 64 && LCAP > KS, "one list entry per lane during compaction");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring = smem;                                                                           // [NSLOT][TILE_BYTES]
+    unsigned long long* lists = reinterpret_cast<unsigned long long*>(smem + NSLOT * TILE_BYTES);  // [NQ][LCAP]
+    float* qvals = reinterpret_cast<float*>(lists + NQ * LCAP);                                   // [NCONS][QCAP][4]
+    uint32_t* qtags = reinterpret_cast<uint32_t*>(qvals + NCONS * QCAP * 4);                      // [NCONS][QCAP]
+    int* cnt = reinterpret_cast<int*>(qtags + NCONS * QCAP);                                      // [NQ]
+    int* ready = cnt + NQ;                                                                        // [NSLOT]
+    int* done = ready + NSLOT;                                                                    // [NSLOT][NCONS]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: branches on it are scalar
+    // work items in launch order: first the query blocks that sweep the whole reference as one range, then the
+    // remaining query blocks split into `nranges` ranges each, range-major (see knn_bf16.hip)
+    int qblock = blockIdx.x, rng = 0, nrng = 1, r_begin = first_begin, r_end = r_limit;
+    if ((int)blockIdx.x >= n_full) {
+        const int nsplit = (gridDim.x - n_full) / nranges, jx = blockIdx.x - n_full;
+        rng = jx / nsplit;
+        qblock = n_full + (jx - rng * nsplit);
+        nrng = nranges;
+        r_begin = first_begin + rng * range_len;
+        r_end = min(r_limit, r_begin + range_len);
+    }
+    const int ntiles = (r_end - r_begin) >> 5;
+    const int out_chunk = out_chunk0 + rng;
+    if (tid < NSLOT * (1 + NCONS)) ready[tid] = 0;  // ready[] and done[] are contiguous
+    if (tid < NQ) cnt[tid] = 0;
+    __syncthreads();
+
+    if (wave >= NCONS) {
+        // ------------------------------------------------------------------ producer (as in knn_bf16.hip)
+        const int p = wave - NCONS;
+        f32x4 ra[NS], rb[NS], rc[NS];
+        const f32x4* src = reinterpret_cast<const f32x4*>(PrF) + ((int64_t)(r_begin >> 5) * NS) * 64 + lane;
+        f32x4* ring_l = reinterpret_cast<f32x4*>(ring) + lane;
+        auto load = [&](f32x4(&r)[NS], int t) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) r[s] = src[((int64_t)t * NS + s) * 64];
+        };
+        // tile t goes to slot t % NSLOT once every consumer has read the tile staged there NSLOT tiles earlier;
+        // done[slot][c] = number of the last tile consumer c has read from the slot, plus one
+        auto wait_free = [&](int t, int slot) {
+            if (t < NSLOT) return;
+            const int need = t - NSLOT + 1;
+            for (;;) {
+                const int v = lane < NCONS ? lds_load_volatile(&done[slot * NCONS + lane]) : need;
+                if (__builtin_amdgcn_ballot_w64(v < need) == 0) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+        };
+        auto publish = [&](const f32x4(&r)[NS], int t) {
+            const int slot = t % NSLOT;
+            wait_free(t, slot);
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            f32x4* dst = ring_l + slot * (TILE_BYTES / 16);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) dst[s * 64] = r[s];
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            // same wave, in-order LDS queue: the flag lands after the tile
+            if (lane == 0) __hip_atomic_store(&ready[slot], t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        int t = p;
+        if (t < ntiles) load(ra, t);
+        if (t + NPROD < ntiles) load(rb, t + NPROD);
+        for (; t < ntiles; t += 3 * NPROD) {
+            if (t + 2 * NPROD < ntiles) load(rc, t + 2 * NPROD);
+            publish(ra, t);
+            if (t + NPROD < ntiles) {
+                if (t + 3 * NPROD < ntiles) load(ra, t + 3 * NPROD);
+                publish(rb, t + NPROD);
+            }
+            if (t + 2 * NPROD < ntiles) {
+                if (t + 4 * NPROD < ntiles) load(rb, t + 4 * NPROD);
+                publish(rc, t + 2 * NPROD);
+            }
+        }
+        // two empty tiles past the end: the consumers' loop runs one tile longer than the data and always
+        // prefetches "tile t + 1"
+        for (int e = ntiles; e < ntiles + 2; ++e) {
+            if (ntiles > 0 && e % NPROD == p) {
+                const int slot = e % NSLOT;
+                wait_free(e, slot);
+                if (lane == 0) __hip_atomic_store(&ready[slot], e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumer
+    const int j = lane & 31, h = lane >> 5;
+    const int q = qblock * NQ + wave * 32 + j;
+
+    float tau = (!SAMPLE && tau_g) ? orderable_f32(tau_g[q]) : __builtin_inff();
+
+    f16x8 bq[NS];
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(Pq + (int64_t)q * (16 * NS) + h * (8 * NS));
+#pragma unroll
+        for (int s = 0; s < NS; ++s) bq[s] = __builtin_bit_cast(f16x8, src[s]);
+    }
+
+    unsigned long long* mylists = lists + wave * 32 * LCAP;  // this wave's 32 lists
+    int* mycnt = cnt + wave * 32;
+    float* qv = qvals + wave * QCAP * 4;
+    uint32_t* qt = qtags + wave * QCAP;
+    int qcount = 0;  // records in the queue (wave-uniform)
+    const bool shared_tau = !SAMPLE && tau_g != nullptr && nrng > 1;
+#ifdef BMX_STAMPS
+    unsigned long long dbg_spin = 0, dbg_drain = 0, dbg_ndrain = 0, dbg_ncomp = 0, dbg_evt = 0, dbg_grp = 0, dbg_evc = 0,
+                       dbg_comp = 0, dbg_rounds = 0;
+    const unsigned long long dbg_t0 = STAMP();
+#endif
+
+    // ---- compaction of query jj's list (jj wave-uniform): cut it back to about KS entries, tighten the threshold.
+    // The cut need not sit exactly at rank KS: any entry with at least KS - 1 smaller ones is a valid new threshold
+    // (everything above it is dropped, at least KS stay).  Eight entries from fixed, evenly spread places of the
+    // (unordered) list are tried at once -- eight independent readlane / compare / popcount chains instead of a
+    // dependent chain of quickselect rounds -- and the one that keeps the fewest, at least KS, wins: on average KS + 3
+    // stay.  Only when none qualifies (all eight below rank KS: ~1 %) or the best would free too little does the exact
+    // quickselect run.
+    auto compact = [&](const int jj, const bool exact = false) {
+        const int n_raw = __builtin_amdgcn_readfirstlane(lds_load_volatile(&mycnt[jj]));
+        const int n = n_raw < LCAP ? n_raw : LCAP;
+        if (n <= KS) return;
+#ifdef BMX_STAMPS
+        const unsigned long long c0 = STAMP();
+        ++dbg_ncomp;
+#endif
+        const unsigned long long raw = lane < n ? mylists[jj * LCAP + lane] : 0ull;
+        // 31-bit rank key: order-preserving image of the value with its low bits replaced by the lane number
+        // (unique keys; values closer than 2^-17 relative may swap places at the cut, see below)
+        const uint32_t key =
+            lane < n ? (((f32_orderable(__uint_as_float((uint32_t)(raw >> 32))) >> 1) & ~63u) | (uint32_t)lane)
+                     : 0x7FFFFFFFu;
+        unsigned long long M = 0;
+        int pl = 0, kept = 0x7FFFFFFF;
+        uint32_t pk = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int p = ((2 * i + 1) * n) >> 4;  // < n
+            const uint32_t k_i = (uint32_t)__builtin_amdgcn_readlane((int)key, p);
+            const unsigned long long m_i = __builtin_amdgcn_ballot_w64(key < k_i);
+            const int c_i = __builtin_popcountll(m_i);
+            if (c_i >= KS - 1 && c_i < kept) {
+                kept = c_i;
+                M = m_i;
+                pl = p;
+                pk = k_i;
+            }
+        }
+        if (exact ? kept != KS - 1 : kept > KS + 11) {
+            // quickselect for the key with exactly KS - 1 smaller keys; B = lanes that can still be it
+            unsigned long long B = n == 64 ? ~0ull : ((1ull << n) - 1ull);
+            if (kept != 0x7FFFFFFF) B &= M;  // below the best pivot found
+            int it = 0;
+            for (;;) {
+                const int rot = (it * 29 + jj * 7) & 63;  // pivots from changing places
+                ++it;
+                const unsigned long long Br = B >> rot;
+                pl = Br ? rot + __builtin_ctzll(Br) : __builtin_ctzll(B);
+                pk = (uint32_t)__builtin_amdgcn_readlane((int)key, pl);
+                M = __builtin_amdgcn_ballot_w64(key < pk);
+                const int c = __builtin_popcountll(M);
+                if (c == KS - 1) break;
+                if (c > KS - 1)
+                    B &= M;
+                else
+                    B &= ~M & ~(1ull << pl);
+            }
+            kept = KS - 1;
+#ifdef BMX_STAMPS
+            dbg_rounds += it;
+#endif
+        }
+        const unsigned long long keep = M | (1ull << pl);  // kept + 1 lanes, at least KS
+        // the new threshold: the cut key with its lane bits cleared, which is <= the value of everything dropped,
+        // so "rejected => value >= threshold" holds exactly
+        const float newtau = orderable_f32((pk & ~63u) << 1);
+        const int pos = mbcnt64(keep);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // every lane holds its entry before slots are rewritten
+        if ((keep >> lane) & 1ull) mylists[jj * LCAP + pos] = raw;
+        if (lane == 0) mycnt[jj] = kept + 1;
+        if (lane == jj || lane == jj + 32) tau = newtau < tau ? newtau : tau;
+        if (shared_tau && lane == jj) atomicMin(&tau_g[q], f32_orderable(newtau));  // lane jj's q is query jj's
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#ifdef BMX_STAMPS
+        dbg_comp += STAMP() - c0;
+#endif
+    };
+
+    // ---- drain: work off the spill queue.  32 records = 128 values per pass: every lane takes one value of a record
+    // of the first half and one of the second (two independent chains of LDS read -> threshold of the owning lane by
+    // ds_bpermute -> LDS atomic slot -> store, issued together).  The wave holds the ring up while it is here, so it
+    // runs at the highest issue priority.
+    auto drain = [&]() {
+#ifdef BMX_STAMPS
+        const unsigned long long d0 = STAMP();
+        ++dbg_ndrain;
+#endif
+        __builtin_amdgcn_s_setprio(3);
+        const int n = qcount;
+        for (int base = 0; base < n; base += 32) {
+            bool pend[2];
+            uint32_t tag[2];
+            float v[2];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                const int rec = base + 16 * x + (lane >> 2);
+                pend[x] = rec < n;
+                tag[x] = qt[pend[x] ? rec : 0];
+                v[x] = qv[((base + 16 * x) << 2) + lane];
+            }
+            int jq[2], srcl[2], ref[2];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                srcl[x] = tag[x] & 63;  // the lane that spilled the record: query srcl & 31, row half srcl >> 5
+                jq[x] = srcl[x] & 31;
+                ref[x] = r_begin + ((int)(tag[x] >> 8) << 5) + (int)((tag[x] >> 6) & 3u) * 8 + (srcl[x] >> 5) * 4 +
+                         (lane & 3);
+            }
+            for (;;) {
+                float tq[2];
+                int slot[2];
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+                    tq[x] = __uint_as_float(
+                        (uint32_t)__builtin_amdgcn_ds_bpermute(srcl[x] << 2, (int)__float_as_uint(tau)));
+#pragma unroll
+                for (int x = 0; x < 2; ++x) {
+                    pend[x] = pend[x] && v[x] < tq[x];
+                    slot[x] = LCAP;
+                    if (pend[x]) slot[x] = atomicAdd(&mycnt[jq[x]], 1);  // ds_add_rtn_u32
+                }
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+                    if (slot[x] < LCAP) {
+                        mylists[jq[x] * LCAP + slot[x]] =
+                            ((unsigned long long)__float_as_uint(v[x]) << 32) | (uint32_t)ref[x];
+                        pend[x] = false;
+                    }
+                unsigned long long ov0 = __builtin_amdgcn_ballot_w64(pend[0]);
+                unsigned long long ov1 = __builtin_amdgcn_ballot_w64(pend[1]);
+                if ((ov0 | ov1) == 0) break;
+                // full lists: cut them back (the threshold drops), then the lanes left over try again
+                while (ov0 | ov1) {
+                    const int qq = ov0 ? __builtin_amdgcn_readlane(jq[0], __builtin_ctzll(ov0))
+                                       : __builtin_amdgcn_readlane(jq[1], __builtin_ctzll(ov1));
+                    compact(qq);
+                    ov0 &= ~__builtin_amdgcn_ballot_w64(jq[0] == qq);
+                    ov1 &= ~__builtin_amdgcn_ballot_w64(jq[1] == qq);
+                }
+            }
+        }
+        qcount = 0;
+        // lists about to fill are cut back now, so that the appends of the next drain rarely find one full
+        const int c = lane < 32 ? lds_load_volatile(&mycnt[lane]) : 0;
+        unsigned long long need = __builtin_amdgcn_ballot_w64(c > LCAP - HEAD);
+        while (need) {
+            const int jj = __builtin_ctzll(need);
+            need &= need - 1;
+            compact(jj);
+        }
+        if (wave >= NCONS / 2)
+            __builtin_amdgcn_s_setprio(1);
+        else
+            __builtin_amdgcn_s_setprio(0);
+#ifdef BMX_STAMPS
+        dbg_drain += STAMP() - d0;
+#endif
+    };
+
+    // Tile hand-over: as in knn_bf16.hip (tile t + 1 is read into the fragment registers while tile t computes,
+    // its ready word was polled a tile earlier, the done word is queued behind the fragment reads).
+    uint32_t tau_fetch = 0xFFFFFFFFu;
+    int seen = 0;
+    int slot_n = 0;  // slot of the tile to read next
+    auto spin_until_staged = [&](int tile) {
+        if (__builtin_amdgcn_readfirstlane(seen) < tile + 1) {
+#ifdef BMX_STAMPS
+            const unsigned long long s0 = STAMP();
+#endif
+            do {
+                __builtin_amdgcn_s_sleep(1);
+                seen = lds_load_volatile(&ready[slot_n]);
+            } while (seen < tile + 1);
+#ifdef BMX_STAMPS
+            dbg_spin += STAMP() - s0;
+#endif
+        }
+    };
+    auto read_tile = [&](f32x4(&a)[NS]) {
+        const f32x4* tp = reinterpret_cast<const f32x4*>(ring + slot_n * TILE_BYTES) + lane;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) a[s] = tp[s * 64];
+    };
+    auto hand_back = [&](int tile) {
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        {
+            // lane 0 stores the done word: EXEC is all ones here (uniform control flow), so it is narrowed and restored
+            // with two scalar moves instead of a compare / saveexec / branch sequence
+            typedef __attribute__((address_space(3))) int* lds_iptr;
+            const lds_iptr dp = (lds_iptr)&done[slot_n * NCONS + wave];
+            const int val = tile + 1;
+            asm volatile("s_mov_b64 exec, 1\n\tds_write_b32 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(dp), "v"(val) : "memory");
+        }
+        slot_n = slot_n + 1 == NSLOT ? 0 : slot_n + 1;
+        seen = lds_load_volatile(&ready[slot_n]);
+    };
+
+    f32x4 a[NS], b[NS];  // fragment sets of alternate tiles
+    uint32_t best[SAMPLE ? KS / 2 : 1];
+#pragma unroll
+    for (int i = 0; i < (SAMPLE ? KS / 2 : 1); ++i) best[i] = 0xFF800000u;  // image of +inf
+
+    // One step = the MFMA chain of tile t (fragments in `fa`) into `cur`, with the filter of tile t - 1 (products in
+    // `prev`) issued in its gaps; then the spill of tile t - 1's groups with survivors.  The fragments of tile t + 1
+    // are read into the other register set `fn` BEFORE the chain starts, and the slot is handed back at once: by the
+    // time the next step waits for them (lgkmcnt(0) at its top) they are a whole chain old.
+    auto step = [&](f32x16& cur, const f32x16& prev, const f32x4(&fa)[NS], f32x4(&fn)[NS], const int t) {
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the fragments of tile t and the ready word of tile t + 1
+        spin_until_staged(t + 1);
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        read_tile(fn);
+        hand_back(t + 1);
+        __builtin_amdgcn_sched_barrier(0);  // the reads stay in front of the chain
+#pragma unroll
+        for (int e = 0; e < 16; ++e) cur[e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            cur = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[s]), bq[s], cur, 0, 0, 0);
+        // group minima (4 consecutive references each), then the lane minimum, of the previous tile
+        float g[4];
+        // every fminf below is half of a three-way minimum: the compiler forms v_min3_f32 from such pairs and, unlike
+        // for a lone v_min_f32, does not put a v_max x, x (signalling-NaN quieting) in front of its inputs.  The
+        // threshold rides along as the sixth operand of a group: min(group, tau) < tau iff min(group) < tau
+        // (SAMPLE: tau = +inf, the plain minimum)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float m3 = fminf(fminf(prev[4 * u], prev[4 * u + 1]), prev[4 * u + 2]);
+            g[u] = fminf(fminf(m3, prev[4 * u + 3]), tau);
+        }
+        const float mn = fminf(fminf(fminf(fminf(g[0], g[1]), g[2]), g[3]), tau);
+        unsigned long long any = 0;
+        if constexpr (SAMPLE) {
+            // sorted insertion of the lane minimum on the order-preserving integer images (see knn_bf16.hip)
+            uint32_t x = f32_orderable(mn);
+#pragma unroll
+            for (int i = 0; i < KS / 2; ++i) {
+                const uint32_t lo = min(best[i], x);
+                x = max(best[i], x);
+                best[i] = lo;
+            }
+            asm volatile("" ::"v"(best[KS / 2 - 1]));  // keep it in this block
+        } else {
+            any = __builtin_amdgcn_ballot_w64(mn < tau);
+            asm volatile("" ::"s"(any), "v"(g[0]), "v"(g[1]), "v"(g[2]), "v"(g[3]));  // keep the filter in this block
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, SAMPLE ? 2 + (KS + 15 + NS - 1) / NS : (12 + NS - 1) / NS, 0);
+        }
+        if constexpr (SAMPLE) return;
+        if (any == 0) return;
+#ifdef BMX_STAMPS
+        ++dbg_evt;
+        const unsigned long long dbg_e0 = STAMP();
+#endif
+        // ---- spill the groups with survivors of tile t - 1
+        const uint32_t tagbase = ((uint32_t)(t - 1) << 8) | (uint32_t)lane;
+        auto spill = [&](const int u, const unsigned long long m) {
+            if (g[u] < tau) {  // the lanes of m
+                const int slot = qcount + mbcnt64(m);
+                f32x4 rec;
+                rec[0] = prev[4 * u];
+                rec[1] = prev[4 * u + 1];
+                rec[2] = prev[4 * u + 2];
+                rec[3] = prev[4 * u + 3];
+                *reinterpret_cast<f32x4*>(qv + slot * 4) = rec;
+                qt[slot] = tagbase | ((uint32_t)u << 6);
+            }
+            qcount += __builtin_popcountll(m);
+#ifdef BMX_STAMPS
+            ++dbg_grp;
+#endif
+        };
+        unsigned long long m[4];
+        int tot = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            m[u] = __builtin_amdgcn_ballot_w64(g[u] < tau);
+            tot += __builtin_popcountll(m[u]);
+        }
+        if (qcount + tot > QSOFT) {
+            drain();  // may tighten thresholds: the masks are taken again
+            tot = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                m[u] = __builtin_amdgcn_ballot_w64(g[u] < tau);
+                tot += __builtin_popcountll(m[u]);
+            }
+            if (tot > QCAP) {
+                // the first tiles of a sweep that starts without a threshold: one group (<= 64 records) at a time
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned long long mu = __builtin_amdgcn_ballot_w64(g[u] < tau);
+                    if (mu) {
+                        spill(u, mu);
+                        drain();
+                    }
+                }
+                return;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (m[u]) spill(u, m[u]);
+#ifdef BMX_STAMPS
+        dbg_evc += STAMP() - dbg_e0;
+#endif
+    };
+
+    f32x16 accA, accB;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) accA[e] = accB[e] = __builtin_inff();  // "previous tile" of step 0: nothing passes
+    // at equal priority the second-dispatched half of the consumers (waves 4..7, one per SIMD) loses every contested
+    // issue slot to its older partner: it gets the higher static priority (MI355X_MICROARCH.md, two waves per SIMD)
+    if (wave >= NCONS / 2) __builtin_amdgcn_s_setprio(1);
+    if (ntiles > 0) {
+        spin_until_staged(0);
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        read_tile(a);
+        hand_back(0);
+        // steps 0 .. ntiles: step t multiplies tile t (step ntiles: an empty tile, product unused) and filters tile
+        // t - 1; two steps per iteration so that the two accumulators alternate statically
+        for (int t2 = 0; t2 <= ntiles; t2 += 2) {
+            if constexpr (!SAMPLE) {
+                // periodic refresh of the shared threshold: the (L1-bypassing) load is issued here and looked at one
+                // iteration later, so nobody waits for the round trip
+                if (shared_tau) {
+                    if ((t2 & 15) == 2) tau = fminf(tau, orderable_f32(tau_fetch));
+                    if ((t2 & 15) == 0)
+                        tau_fetch = __hip_atomic_load(&tau_g[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            step(accA, accB, a, b, t2);
+            if (t2 + 1 <= ntiles) step(accB, accA, b, a, t2 + 1);
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+
+    if constexpr (SAMPLE) {
+        const uint32_t mine = best[KS / 2 - 1], other = __shfl_xor(mine, 32);
+        if (h == 0) tau_g[q] = max(mine, other);
+        return;
+    } else {
+        drain();
+        for (int jj = 0; jj < 32; ++jj) compact(jj, true);  // the output holds exactly KS entries per list
+#ifdef BMX_STAMPS
+        if (lane == 0) {
+            atomicAdd(&bmx_dbg16[0], STAMP() - dbg_t0);
+            atomicAdd(&bmx_dbg16[1], dbg_spin);
+            atomicAdd(&bmx_dbg16[2], dbg_drain);
+            atomicAdd(&bmx_dbg16[3], dbg_ndrain);
+            atomicAdd(&bmx_dbg16[4], dbg_ncomp);
+            atomicAdd(&bmx_dbg16[5], dbg_comp);
+            atomicAdd(&bmx_dbg16[6], dbg_evt);
+            atomicAdd(&bmx_dbg16[7], dbg_grp);
+            atomicAdd(&bmx_dbg16[8], (unsigned long long)ntiles);
+            atomicAdd(&bmx_dbg16[9], 1ull);
+            atomicAdd(&bmx_dbg16[10], dbg_evc);
+            atomicAdd(&bmx_dbg16[11], dbg_rounds);
+        }
+#endif
+        for (int jj = 0; jj < 32; ++jj) {
+            const int qq = qblock * NQ + wave * 32 + jj;
+            const int n = __builtin_amdgcn_readfirstlane(lds_load_volatile(&mycnt[jj]));  // <= KS now
+            // what this range rejected was rejected against thresholds >= the final working threshold; kept
+            // entries at or above it are as good as rejected (another range holds KS better ones): dropped here
+            const float eff = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(tau), jj));
+            if (lane < KS) {
+                const unsigned long long e = lane < n ? mylists[jj * LCAP + lane] : 0ull;
+                const float val = __uint_as_float((uint32_t)(e >> 32));
+                const bool keep = lane < n && (val < eff || nrng == 1);
+                const int64_t o = ((int64_t)qq * out_nchunks + out_chunk) * KS + lane;
+                cand[o] = keep ? (int32_t)(uint32_t)e : -1;
+                cand_v[o] = lane < n ? val : __builtin_inff();
+            }
+            if (lane == 0) tau_out[(int64_t)qq * out_nchunks + out_chunk] = eff;
+            if (nrng == 1) {  // a whole-reference item owns every list column of its queries: the others stay empty
+                for (int c = 1; c < out_nchunks; ++c) {
+                    if (lane < KS) cand[((int64_t)qq * out_nchunks + out_chunk + c) * KS + lane] = -1;
+                    if (lane == 0) tau_out[(int64_t)qq * out_nchunks + out_chunk + c] = __builtin_inff();
+                }
+            }
+        }
+    }
+}
+
+template <int NS, int KS>
+void launch(hipStream_t stream, KnnWorkspace& ws, const Bf16Launch& L) {
+    constexpr int LCAP = list_cap(NS, KS);
+    constexpr size_t lds = (size_t)ring_slots_for(NS, LCAP) * NS * 1024 + (size_t)NQ * LCAP * 8 + lds_fixed_bytes();
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    ensure_dynamic_lds(reinterpret_cast<const void*>(&knn_topk_f16<NS, KS, LCAP, false>), lds);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(&knn_topk_f16<NS, KS, LCAP, true>), lds);
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    if (ws.profile) {
+        ev = ws.next_events();
+        BMX_HIP(hipEventRecord(ev.first, stream));
+    }
+    const int items = L.n_full + (L.nqb - L.n_full) * L.nranges;
+    if (L.sample)
+        hipLaunchKernelGGL((knn_topk_f16<NS, KS, LCAP, true>), dim3(items), dim3((NCONS + NPROD) * 64), lds, stream,
+                           L.pq, L.pr, L.first_begin, L.range_len, L.r_limit, L.n_full, L.nranges, L.out_chunk0,
+                           L.out_nchunks, L.tau_g, L.cand, L.cand_v, L.tau);
+    else
+        hipLaunchKernelGGL((knn_topk_f16<NS, KS, LCAP, false>), dim3(items), dim3((NCONS + NPROD) * 64), lds, stream,
+                           L.pq, L.pr, L.first_begin, L.range_len, L.r_limit, L.n_full, L.nranges, L.out_chunk0,
+                           L.out_nchunks, L.tau_g, L.cand, L.cand_v, L.tau);
+    BMX_LAUNCH_CHECK();
+    if (ws.profile) BMX_HIP(hipEventRecord(ev.second, stream));
+#ifdef BMX_STAMPS
+    if (!L.sample) {
+        unsigned long long hh[48];
+        BMX_HIP(hipStreamSynchronize(stream));
+        BMX_HIP(hipMemcpyFromSymbol(hh, HIP_SYMBOL(bmx_dbg16), sizeof(hh)));
+        const double nt = (double)hh[8];
+        fprintf(stderr,
+                "[stamps f16] waves=%.0f tiles/wave=%.0f cyc/tile=%.0f spin/tile=%.0f drain/tile=%.0f (every %.1f tiles, "
+                "%.0f cyc each) compact/tile=%.0f (every %.1f tiles, %.0f cyc, %.1f rounds each) event tiles=%.3f "
+                "groups/tile=%.3f evpath/tile=%.0f\n",
+                (double)hh[9], nt / hh[9], hh[0] / nt, hh[1] / nt, hh[2] / nt, hh[3] ? nt / hh[3] : 0.0,
+                hh[3] ? (double)hh[2] / hh[3] : 0.0, hh[5] / nt, hh[4] ? nt / hh[4] : 0.0, hh[4] ? (double)hh[5] / hh[4] : 0.0,
+                hh[4] ? (double)hh[11] / hh[4] : 0.0, hh[6] / nt, hh[7] / nt, hh[10] / nt);
+        unsigned long long z[48] = {0};
+        BMX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(bmx_dbg16), z, sizeof(z)));
+    }
+#endif
+}
+
+}  // namespace
+
+// MFMA k-steps (16 fp16 each) for d + 3 columns; 0 = this tier does not take the shape
+int f16_pick_ns(int d, int KS) {
+    const int ns = (d + 3 + 15) / 16;
+    if (KS == 32) return ns <= 8 ? ns : 0;
+    if (KS == 48) return ns <= 4 ? ns : 0;
+    return 0;
+}
+
+__global__ void fold_max_slots16(const unsigned long long* __restrict__ slots, unsigned long long* __restrict__ out) {
+    double m = __longlong_as_double((long long)slots[(size_t)threadIdx.x * 16]);
+    for (int o = 1; o < 64; o <<= 1) m = fmax(m, __shfl_xor(m, o));
+    if (threadIdx.x == 0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
+}
+
+// references: two passes (norms + maximum, then the scaled image); queries: one
+void f16_prep(hipStream_t stream, const double* X, const int32_t* rows, int n, int n_pad, int d, int NS,
+              const double* mean, int is_query, uint16_t* P, double* n2, unsigned long long* maxbits,
+              unsigned long long* slots) {
+    const size_t lds = (size_t)32 * d * 4 + 128 + 16;
+    if (!is_query) {
+        BMX_HIP(hipMemsetAsync(slots, 0, 64 * 16 * sizeof(unsigned long long), stream));
+        hipLaunchKernelGGL(knn_prep_f16<0>, dim3(n_pad / 32), dim3(256), lds, stream, X, rows, n, d, NS, mean, 0, P, n2,
+                           slots, maxbits);
+        BMX_LAUNCH_CHECK();
+        hipLaunchKernelGGL(fold_max_slots16, dim3(1), dim3(64), 0, stream, slots, maxbits);
+        BMX_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(knn_prep_f16<1>, dim3(n_pad / 32), dim3(256), lds, stream, X, rows, n, d, NS, mean, is_query, P,
+                       n2, slots, maxbits);
+    BMX_LAUNCH_CHECK();
+}
+
+bool f16_launch(hipStream_t stream, KnnWorkspace& ws, int NS, int KS, const Bf16Launch& L) {
+#define BMX_CASE(N)                       \
+    case N:                               \
+        if (KS == 32)                     \
+            launch<N, 32>(stream, ws, L); \
+        else if constexpr (N <= 4)        \
+            launch<N, 48>(stream, ws, L); \
+        else                              \
+            return false;                 \
+        return true;
+    switch (NS) {
+        BMX_CASE(1)
+        BMX_CASE(2)
+        BMX_CASE(3)
+        BMX_CASE(4)
+        BMX_CASE(5)
+        BMX_CASE(6)
+        BMX_CASE(7)
+        BMX_CASE(8)
+        default:
+            return false;
+    }
+#undef BMX_CASE
+}
+
+double f16_scale_host(double max_n2) { return f16_scale(max_n2); }
+
+}  // namespace bmx

@@ -31,10 +31,9 @@ sys.path.insert(0, ROOT)
 
 # Dense MFMA peaks from /opt/skills/guides/MI355X_MICROARCH.md ("Chip-level parameters" / "Matrix cores")
 KERNELS = {
+    3: {"kernel": "knn_topk_f16", "dtype": "fp16 MFMA candidate pass (f32 accumulate) + FP64 exact re-rank", "peak": 2500.0},
     2: {"kernel": "knn_topk_bf16", "dtype": "bf16 MFMA (f32 operands split into 3 bf16 products) + FP64 exact re-rank",
         "peak": 2500.0},
-    1: {"kernel": "knn_topk_w1", "dtype": "f32 MFMA + FP64 exact re-rank", "peak": 157.3},
-    0: {"kernel": "knn_topk_mfma", "dtype": "f32 MFMA + FP64 exact re-rank", "peak": 157.3},
 }
 
 def _config5_sizes():
@@ -196,7 +195,7 @@ def main():
     stats = eng.merge_stats()
     prof = eng.profile()
     fallbacks = prof["exact_fallbacks"]
-    kern = KERNELS.get(prof["variant"], KERNELS[2])
+    kern = KERNELS.get(prof["variant"], KERNELS[3])
     if rank == 0:
         flops = algorithmic_flops(stats, d) / world  # this rank's share of the query rows
         achieved = flops * args.steps / (topk_ms * 1e-3) / 1e12 if topk_ms > 0 else 0.0

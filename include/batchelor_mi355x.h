@@ -103,7 +103,7 @@ int32_t bmx_engine_create(int32_t device, bmx_engine_t** out);
 void bmx_engine_destroy(bmx_engine_t* e);
 /* Every kNN search is split by query rows over `world` ranks and completed with `fn`; all ranks hold all batches. */
 int32_t bmx_engine_set_shard(bmx_engine_t* e, int32_t rank, int32_t world, bmx_allgather_fn fn, void* ctx);
-/* Copies the batches to HBM.  data[b]: nrows[b] x d column-major; restrict_idx[b]: 1-based, any order (an R subsetting vector),
+/* Copies the batches to HBM.  data[b]: nrows[b] x d column-major; restrict_idx[b]: 1-based, any order, no cell twice,
  * n_restrict[b] entries, or NULL / n_restrict[b] < 0 for "all cells" (R/checkInputs.R:96-120 normalises them). */
 int32_t bmx_engine_upload(bmx_engine_t* e, int32_t nbatches, int32_t d, const double* const* data,
                           const int32_t* nrows, const int32_t* const* restrict_idx, const int32_t* n_restrict);

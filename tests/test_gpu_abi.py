@@ -63,17 +63,21 @@ def test_bmx_fast_mnn_one_shot_as_the_shim_calls_it(oracle):
         L.bmx_engine_destroy(h)
 
 
-def test_restrict_is_an_r_subsetting_vector_any_order_with_repeats(oracle):
+def test_restrict_is_an_r_subsetting_vector_in_any_order(oracle):
     # checkRestrictions() turns `restrict` into integer positions in the caller's order (R/checkInputs.R:96-120,
-    # R/utils_subset.R): unsorted and repeated entries are legal and change the order of the pairs
+    # R/utils_subset.R): an unsorted vector is legal and changes the order of the pairs.  A cell named twice is
+    # refused here (the reference would search it as two points and average it as one).
     import batchelor_amd as bx
     from tests.test_gpu_engine import assert_same_result
     rng = np.random.default_rng(77)
     B = synth_batches(9, [500, 400, 450], 15)
-    keep = [rng.permutation(500)[:300] + 1, None, np.concatenate([rng.permutation(450)[:200] + 1, [5, 5, 17]])]
+    keep = [rng.permutation(500)[:300] + 1, None, rng.permutation(450)[:200] + 1]
     out = bx.reducedMNN(*B, restrict=keep)
     ref = oracle.reduced_mnn(*B, restrict=keep)
     assert_same_result(out, ref)
+    keep[2] = np.concatenate([keep[2], keep[2][:2]])
+    with pytest.raises(RuntimeError, match="more than once"):
+        bx.reducedMNN(*B, restrict=keep)
 
 
 def test_exact_path_with_more_queries_than_grid_y(oracle):

@@ -66,8 +66,22 @@ def test_query_knn_large_k_uses_exact_scan(oracle, nb):
 
 
 def test_query_knn_near_ties_take_the_bounded_exact_path(oracle, nb):
-    # clusters of 30 near-duplicates (1e-9 apart): the f32 / bf16 candidate pass cannot certify any of these queries,
-    # so all of them go through knn_exact_filter / knn_exact_pick and must still match the oracle bit for bit
+    # clusters of 70 near-duplicates (1e-9 apart), more than either candidate tier keeps per query (32 / 24): neither
+    # pass can certify any of these queries, so all of them go through knn_exact_filter / knn_exact_pick and must still
+    # match the oracle bit for bit
+    rng = np.random.default_rng(5)
+    base = rng.standard_normal((70, 20))
+    X = np.repeat(base, 70, axis=0) + 1e-9 * rng.standard_normal((4900, 20))
+    Q = base[:64] + 1e-9 * rng.standard_normal((64, 20))
+    idx, dist = nb.query_knn(X, Q, 20)
+    oi, od = oracle.query_knn(X, Q, 20)
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+    assert nb.last_knn_exact_fallbacks() >= 32
+
+
+def test_query_knn_clusters_the_first_tier_certifies(oracle, nb):
+    # 30 near-duplicates per cluster: the fp16 tier keeps 32 candidates, the whole cluster, and the gap to the next
+    # cluster certifies it; the exact FP64 re-rank orders the duplicates
     rng = np.random.default_rng(5)
     base = rng.standard_normal((150, 20))
     X = np.repeat(base, 30, axis=0) + 1e-9 * rng.standard_normal((4500, 20))
@@ -75,4 +89,3 @@ def test_query_knn_near_ties_take_the_bounded_exact_path(oracle, nb):
     idx, dist = nb.query_knn(X, Q, 20)
     oi, od = oracle.query_knn(X, Q, 20)
     assert np.array_equal(idx, oi) and np.array_equal(dist, od)
-    assert nb.last_knn_exact_fallbacks() >= 32
