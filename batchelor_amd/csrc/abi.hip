@@ -10,6 +10,7 @@
 #include "bmx_common.hpp"
 #include "bmx_ops.hpp"
 #include "engine.hpp"
+#include "rccl_dyn.hpp"
 
 struct bmx_engine {
     std::unique_ptr<bmx::Engine> impl;
@@ -282,8 +283,12 @@ int32_t bmx_center_along_batch_vector(double* mat, int32_t n, int32_t d, const d
             }
             pr = upload(rr, z.data(), z.size(), s);
         }
-        double* pl = loc.reserve((size_t)n + 8);
-        bmx::center_along_batch_vector(s, e.red_ws_, px, n, d, pv, pr, n_restrict, pl, pl + n);
+        // the engine's own pass: column mean over the restrict rows, then x <- x - ((x - mu) . v^) v^
+        double* mu = loc.reserve((size_t)d);
+        const int m = pr ? n_restrict : n;
+        bmx::col_reduce(s, e.red_ws_, px, pr, 0, m, d, 0, nullptr, 1.0 / (double)m, mu);
+        const int start = 0, vid = 0;
+        bmx::rows_apply_stats(s, e.red_ws_, px, d, &start, &n, 1, mu, pv, &vid, 1, nullptr, nullptr, nullptr);
         double* pc = cm.reserve((size_t)n * d);
         bmx::transpose_rm_to_cm(s, px, n, d, pc, n, 0);
         BMX_HIP(hipMemcpyAsync(mat, pc, (size_t)n * d * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -331,11 +336,12 @@ int32_t bmx_total_variance(const double* data, int32_t n, int32_t d, double* out
         hipStream_t s = e.stream();
         bmx::DevBuf<double> t, X, v;
         const double* px = upload_rm(t, X, data, n, d, s);
-        double* pv = v.reserve((size_t)2 * d + 1);
-        bmx::col_reduce(s, e.red_ws_, px, nullptr, 0, n, d, 0, nullptr, 1.0 / (double)n, pv);
-        bmx::col_reduce(s, e.red_ws_, px, nullptr, 0, n, d, 2, pv, 1.0 / (double)(n - 1), pv + d);
-        bmx::sum_vector(s, pv + d, d, 1.0, pv + 2 * d);
-        BMX_HIP(hipMemcpyAsync(out, pv + 2 * d, sizeof(double), hipMemcpyDeviceToHost, s));
+        // the engine's own statistics pass (one segment, slot 0): column means + total sample variance
+        double* pv = v.reserve((size_t)d + 1);
+        const int start = 0, slot = 0;
+        bmx::rows_apply_stats(s, e.red_ws_, const_cast<double*>(px), d, &start, &n, 1, nullptr, nullptr, nullptr, 0, &slot,
+                              pv + 1, pv);
+        BMX_HIP(hipMemcpyAsync(out, pv, sizeof(double), hipMemcpyDeviceToHost, s));
         BMX_HIP(hipStreamSynchronize(s));
     });
 }
@@ -457,6 +463,35 @@ void bmx_engine_destroy(bmx_engine_t* e) { delete e; }
 
 int32_t bmx_engine_set_shard(bmx_engine_t* e, int32_t rank, int32_t world, bmx_allgather_fn fn, void* ctx) {
     return guarded([&] { e->impl->set_shard(rank, world, fn, ctx); });
+}
+
+int32_t bmx_rccl_load(const char* librccl_path) {
+    return guarded([&] { bmx::rccl::load(librccl_path); });
+}
+
+int32_t bmx_rccl_unique_id(void* id_out, int32_t bytes) {
+    return guarded([&] {
+        if (!id_out || bytes < 128) throw bmx::Error(BMX_ERR_ARG, "the RCCL unique id needs 128 bytes");
+        if (!bmx::rccl::api().ready()) throw bmx::Error(BMX_ERR_EXCHANGE, "RCCL is not loaded (bmx_rccl_load)");
+        bmx::rccl::UniqueId id;
+        const int rc = bmx::rccl::api().GetUniqueId(&id);
+        if (rc != 0) throw bmx::Error(BMX_ERR_EXCHANGE, "ncclGetUniqueId failed");
+        std::memcpy(id_out, id.internal, 128);
+    });
+}
+
+int32_t bmx_engine_init_rccl(bmx_engine_t* e, int32_t rank, int32_t world, const void* unique_id, int32_t bytes) {
+    return guarded([&] {
+        if (bytes < 128) throw bmx::Error(BMX_ERR_ARG, "the RCCL unique id needs 128 bytes");
+        e->impl->init_rccl(rank, world, unique_id);
+    });
+}
+
+int32_t bmx_engine_exchange_stats(bmx_engine_t* e, int64_t* calls, int64_t* bytes) {
+    return guarded([&] {
+        if (calls) *calls = e->impl->exchange_calls();
+        if (bytes) *bytes = e->impl->exchange_bytes();
+    });
 }
 
 int32_t bmx_engine_upload(bmx_engine_t* e, int32_t nbatches, int32_t d, const double* const* data,

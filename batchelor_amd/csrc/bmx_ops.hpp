@@ -46,10 +46,21 @@ struct ReduceWorkspace {
 // out[c] = scale * sum.  Deterministic two-stage reduction.
 void col_reduce(hipStream_t stream, ReduceWorkspace& ws, const double* X, const int32_t* rows, int r0, int r1, int d,
                 int mode, const double* centre, double scale, double* out);
-// .compute_perbatch_var for all segments (row ranges [starts[i], starts[i] + ns[i])) of one node: the sum over dims of
-// the sample variance of segment i lands in out[i * out_stride].  Two-pass (mean, then squared deviations).
-void segment_variances(hipStream_t stream, ReduceWorkspace& ws, const double* X, int d, const int* starts,
-                       const int* ns, int nseg, double* out, int out_stride);
+// Fused row pass over the segments (row ranges) of one node, in place on X [*][d]:
+//   * nvec > 0: centre along the batch vectors vec_pool[vec_ids[e]] in turn, x <- x - ((x - mu) . v^) v^  with mu [d]
+//     the column mean over the node's restrict rows BEFORE the pass (it is invariant under every step), i.e.
+//     .center_along_batch_vector / .orthogonalize_other (R/fastMNN.R:626-647) without their three passes per vector;
+//   * stat_slots != nullptr: per segment i, the column means of the rows as written go to
+//     means_pool[stat_slots[i]][d] and the sum over columns of the sample variance (.compute_perbatch_var,
+//     R/fastMNN.R:651-658) to scal[stat_slots[i]] -- one pass, shifted sums.
+void rows_apply_stats(hipStream_t stream, ReduceWorkspace& ws, double* X, int d, const int* starts, const int* ns,
+                      int nseg, const double* mu, const double* vec_pool, const int* vec_ids, int nvec,
+                      const int* stat_slots, double* means_pool, double* scal);
+// mu [d] = row-weighted mean of the segment means means_pool[slots[i]] (at most 16 segments)
+void node_mean_from_segments(hipStream_t stream, const double* means_pool, const int* ns, const int* slots, int nseg,
+                             int d, double* mu);
+// .get_batch_magnitude (R/fastMNN.R:582-595) from overall = colMeans(averaged), msq = colMeans(averaged^2)
+void batch_magnitude(hipStream_t stream, const double* overall, const double* msq, int d, double* out);
 // out[0] = scale * sum_c in[c]   (single thread; d is tiny)
 void sum_vector(hipStream_t stream, const double* in, int d, double scale, double* out);
 
@@ -58,11 +69,6 @@ void sum_vector(hipStream_t stream, const double* in, int d, double scale, doubl
 void average_correction(hipStream_t stream, const double* L, const int32_t* lrows, const double* R,
                         const int32_t* rrows, int d, const int32_t* second_u, int U, const int32_t* partR,
                         const int32_t* cntR, int k1, double* averaged);
-
-// .center_along_batch_vector (R/fastMNN.R:626-640) in place on X [n][d]; vec [d] un-normalised; the centre is the
-// mean projection over the restrict rows (or all rows when restrict == nullptr).  loc: scratch [n].
-void center_along_batch_vector(hipStream_t stream, ReduceWorkspace& ws, double* X, int n, int d, const double* vec,
-                               const int32_t* restrict_rows, int n_restrict, double* loc, double* scratch3);
 
 // .compute_tricube_average + add (R/utils_tricube.R:1-27, R/fastMNN.R:606-607) in place on X [n][d].
 // idx [n][k] positions into `averaged` rows, dist [n][k] ascending Euclidean distances.

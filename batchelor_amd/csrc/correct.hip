@@ -56,67 +56,15 @@ __global__ __launch_bounds__(256) void col_reduce_final(const double* __restrict
     }
 }
 
-// ---- per-segment variants: all original batches of a node in one launch (.compute_perbatch_var) -----------------
+// ---- segments: the original batches of a node (row ranges), at most 16 per launch ------------------------------
 struct SegDesc {
     int start[16];
     int n[16];
     int nseg;
 };
-
-__global__ __launch_bounds__(256) void seg_reduce_partial(const double* __restrict__ X, int d, SegDesc sd, int mode,
-                                                          const double* __restrict__ centres, int maxnb,
-                                                          double* __restrict__ partial) {
-    __shared__ double sm[4][64];
-    const int seg = blockIdx.y;
-    const int c0 = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int b0 = sd.start[seg] + blockIdx.x * RED_ROWS;
-    const int b1 = min(sd.start[seg] + sd.n[seg], b0 + RED_ROWS);
-    if (blockIdx.x * RED_ROWS >= sd.n[seg]) return;
-    for (int cb = 0; cb < d; cb += 64) {
-        const int c = cb + c0;
-        double s = 0.0;
-        if (c < d) {
-            const double m = mode == 2 ? centres[(int64_t)seg * d + c] : 0.0;
-            for (int r = b0 + rl; r < b1; r += 4) {
-                const double x = X[(int64_t)r * d + c];
-                s += mode == 0 ? x : (x - m) * (x - m);
-            }
-        }
-        sm[rl][c0] = s;
-        __syncthreads();
-        if (rl == 0 && c < d)
-            partial[((int64_t)seg * maxnb + blockIdx.x) * d + c] = (sm[0][c0] + sm[1][c0]) + (sm[2][c0] + sm[3][c0]);
-        __syncthreads();
-    }
-}
-
-__global__ __launch_bounds__(256) void seg_reduce_final(const double* __restrict__ partial, int maxnb, int d, SegDesc sd,
-                                                        int mode, double* __restrict__ out) {
-    __shared__ double sm[4][64];
-    const int seg = blockIdx.x;
-    const int nb = (sd.n[seg] + RED_ROWS - 1) / RED_ROWS;
-    const double scale = mode == 0 ? 1.0 / (double)sd.n[seg] : 1.0 / (double)(sd.n[seg] - 1);
-    const int c0 = threadIdx.x & 63, g = threadIdx.x >> 6;
-    for (int cb = 0; cb < d; cb += 64) {
-        const int c = cb + c0;
-        double s = 0.0;
-        if (c < d)
-            for (int b = g; b < nb; b += 4) s += partial[((int64_t)seg * maxnb + b) * d + c];
-        sm[g][c0] = s;
-        __syncthreads();
-        if (g == 0 && c < d) out[(int64_t)seg * d + c] = ((sm[0][c0] + sm[1][c0]) + (sm[2][c0] + sm[3][c0])) * scale;
-        __syncthreads();
-    }
-}
-
-__global__ void seg_sum_kernel(const double* __restrict__ vars, int d, int nseg, double* __restrict__ out,
-                               int out_stride) {
-    const int seg = blockIdx.x * blockDim.x + threadIdx.x;
-    if (seg >= nseg) return;
-    double s = 0.0;
-    for (int c = 0; c < d; ++c) s += vars[(int64_t)seg * d + c];
-    out[(int64_t)seg * out_stride] = s;
-}
+struct StatSlots {
+    int slot[16];
+};
 
 __global__ void sum_vector_kernel(const double* __restrict__ in, int d, double scale, double* __restrict__ out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -145,70 +93,6 @@ __global__ __launch_bounds__(256) void average_correction_kernel(
             s += L[(int64_t)(lrows ? lrows[l] : l) * d + c] - rc;
         }
         averaged[(int64_t)u * d + c] = s / (double)m;
-    }
-}
-
-// projections onto the unit batch vector; one wave per row
-__global__ __launch_bounds__(256) void project_rows(const double* __restrict__ X, int n, int d,
-                                                    const double* __restrict__ vec, double* __restrict__ loc) {
-    __shared__ double vhat[256];
-    __shared__ double nrm;
-    if (threadIdx.x == 0) {
-        double s = 0.0;
-        for (int c = 0; c < d; ++c) s += vec[c] * vec[c];
-        nrm = sqrt(s);
-    }
-    __syncthreads();
-    for (int c = threadIdx.x; c < d; c += 256) vhat[c] = vec[c] / nrm;
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += gridDim.x * 4) {
-        double s = 0.0;
-        for (int c = lane; c < d; c += 64) s += X[(int64_t)i * d + c] * vhat[c];
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0) loc[i] = s;
-    }
-}
-
-// deterministic mean of loc over a row list: block partials then one thread
-__global__ __launch_bounds__(256) void mean_partial(const double* __restrict__ loc, const int32_t* __restrict__ rows,
-                                                    int n, double* __restrict__ partial) {
-    __shared__ double sm[256];
-    double s = 0.0;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) s += loc[rows ? rows[i] : i];
-    sm[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) partial[blockIdx.x] = sm[0];
-}
-
-__global__ void mean_final(const double* __restrict__ partial, int nb, double inv_n, double* __restrict__ out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double s = 0.0;
-    for (int b = 0; b < nb; ++b) s += partial[b];
-    *out = s * inv_n;
-}
-
-__global__ __launch_bounds__(256) void shift_rows(double* __restrict__ X, int n, int d, const double* __restrict__ vec,
-                                                  const double* __restrict__ loc, const double* __restrict__ central) {
-    __shared__ double vhat[256];
-    __shared__ double nrm;
-    if (threadIdx.x == 0) {
-        double s = 0.0;
-        for (int c = 0; c < d; ++c) s += vec[c] * vec[c];
-        nrm = sqrt(s);
-    }
-    __syncthreads();
-    for (int c = threadIdx.x; c < d; c += 256) vhat[c] = vec[c] / nrm;
-    __syncthreads();
-    const double cen = *central;
-    const int64_t total = (int64_t)n * d;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const int i = (int)(e / d), c = (int)(e - (int64_t)i * d);
-        X[e] = X[e] + (cen - loc[i]) * vhat[c];  // mat + outer(central.loc - batch.loc, batch.vec)
     }
 }
 
@@ -245,6 +129,208 @@ __global__ __launch_bounds__(256) void tricube_apply_kernel(double* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Fused row passes.  Every step of the merge that touches all rows of a node is one of
+//   * .orthogonalize_other (R/fastMNN.R:642-647): centre along E batch vectors in turn;
+//   * .center_along_batch_vector (R/fastMNN.R:626-640) for the new batch vector;
+//   * .compute_perbatch_var (R/fastMNN.R:651-658) before and after.
+// Centring along v:  x <- x + (mean_restrict(x.v^) - x.v^) v^  =  x - ((x - mu).v^) v^  with mu the column mean over
+// the restrict rows -- and mu does not change under the step (the mean of the removed components is zero), so the E
+// steps of an orthogonalisation are row-local given ONE mu: a single pass applies them all, where the reference's
+// formulation makes 3 E passes (project, mean, shift).  The same pass can accumulate, per original batch (segment),
+// shifted column sums and sums of squares of what it writes: mean and sample variance without another pass.
+// One wave per row (lanes over the columns, <= 4 per lane), 256 rows per workgroup inside one segment, deterministic
+// two-stage reduction of the statistics.
+// ---------------------------------------------------------------------------------------------------
+constexpr int PASS_ROWS = 512;
+constexpr int PASS_EMAX = 8;
+
+struct VecIds {
+    int n;
+    int id[PASS_EMAX];
+};
+
+template <bool APPLY, bool STATS>
+__global__ __launch_bounds__(256) void rows_pass(double* __restrict__ X, int d, SegDesc sd, const double* __restrict__ mu,
+                                                 const double* __restrict__ vec_pool, VecIds ids,
+                                                 const double* __restrict__ pivots, int maxnb,
+                                                 double* __restrict__ partial) {
+    __shared__ double vhat[APPLY ? PASS_EMAX : 1][256];
+    __shared__ double red[STATS ? 4 : 1][2][256];
+    const int seg = blockIdx.y;
+    const int b0 = sd.start[seg] + blockIdx.x * PASS_ROWS;
+    const int b1 = min(sd.start[seg] + sd.n[seg], b0 + PASS_ROWS);
+    if (blockIdx.x * PASS_ROWS >= sd.n[seg]) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if constexpr (APPLY) {
+        // unit vectors of this launch's batch vectors: wave e normalises vector e, e + 4
+        for (int e = w; e < ids.n; e += 4) {
+            const double* v = vec_pool + (int64_t)ids.id[e] * d;
+            double s = 0.0;
+            for (int c = lane; c < d; c += 64) s += v[c] * v[c];
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            const double nrm = sqrt(s);
+            for (int c = lane; c < d; c += 64) vhat[e][c] = v[c] / nrm;
+        }
+        __syncthreads();
+    }
+    double m_[4], pv[4], s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        m_[i] = (APPLY && c < d) ? mu[c] : 0.0;
+        pv[i] = (STATS && c < d) ? pivots[(int64_t)seg * d + c] : 0.0;
+    }
+    // two rows per wave and trip: their loads are in flight together
+    for (int r = b0 + w; r < b1; r += 8) {
+        double x[2][4];
+        const bool has2 = r + 4 < b1;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const double* row = X + (int64_t)(rr == 0 || has2 ? r + 4 * rr : r) * d;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = lane + 64 * i;
+                x[rr][i] = c < d ? row[c] : 0.0;
+            }
+        }
+        if constexpr (APPLY) {
+            for (int e = 0; e < ids.n; ++e) {
+                double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = lane + 64 * i;
+                    if (c < d) {
+                        p0 += (x[0][i] - m_[i]) * vhat[e][c];
+                        p1 += (x[1][i] - m_[i]) * vhat[e][c];
+                    }
+                }
+                for (int o = 32; o > 0; o >>= 1) {
+                    p0 += __shfl_xor(p0, o);
+                    p1 += __shfl_xor(p1, o);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = lane + 64 * i;
+                    if (c < d) {
+                        x[0][i] = x[0][i] - p0 * vhat[e][c];
+                        x[1][i] = x[1][i] - p1 * vhat[e][c];
+                    }
+                }
+            }
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                if (rr == 1 && !has2) break;
+                double* row = X + (int64_t)(r + 4 * rr) * d;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = lane + 64 * i;
+                    if (c < d) row[c] = x[rr][i];
+                }
+            }
+        }
+        if constexpr (STATS) {
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                if (rr == 1 && !has2) break;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const double t = x[rr][i] - pv[i];
+                    s1[i] += t;
+                    s2[i] += t * t;
+                }
+            }
+        }
+    }
+    if constexpr (STATS) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            red[w][0][lane + 64 * i] = s1[i];
+            red[w][1][lane + 64 * i] = s2[i];
+        }
+        __syncthreads();
+        double* out = partial + ((int64_t)seg * maxnb + blockIdx.x) * 2 * d;
+        for (int e = threadIdx.x; e < 2 * d; e += 256) {
+            const int which = e / d, c = e - which * d;
+            out[e] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+        }
+    }
+}
+
+// first row of every segment: the shift of the one-pass variance
+__global__ void gather_pivots(const double* __restrict__ X, int d, SegDesc sd, double* __restrict__ pivots) {
+    const int seg = blockIdx.x;
+    for (int c = threadIdx.x; c < d; c += blockDim.x) pivots[(int64_t)seg * d + c] = X[(int64_t)sd.start[seg] * d + c];
+}
+
+// per segment: column means and the sum over columns of the sample variance.  Four thread groups share each column's
+// partials and are combined in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void rows_stats_final(const double* __restrict__ partial, int maxnb, int d, SegDesc sd,
+                                                        const double* __restrict__ pivots, StatSlots slots,
+                                                        double* __restrict__ means_pool, double* __restrict__ scal) {
+    __shared__ double sa[4][64], sb[4][64];
+    __shared__ double sacc[64];
+    const int seg = blockIdx.x;
+    const int n = sd.n[seg];
+    const int nb = (n + PASS_ROWS - 1) / PASS_ROWS;
+    const int c0 = threadIdx.x & 63, g = threadIdx.x >> 6;
+    double acc = 0.0;
+    for (int cb = 0; cb < d; cb += 64) {
+        const int c = cb + c0;
+        double a = 0.0, b = 0.0;
+        if (c < d) {
+            const double* p = partial + (int64_t)seg * maxnb * 2 * d + c;
+#pragma unroll 4
+            for (int blk = g; blk < nb; blk += 4) {
+                a += p[(int64_t)blk * 2 * d];
+                b += p[(int64_t)blk * 2 * d + d];
+            }
+        }
+        sa[g][c0] = a;
+        sb[g][c0] = b;
+        __syncthreads();
+        if (g == 0 && c < d) {
+            a = (sa[0][c0] + sa[1][c0]) + (sa[2][c0] + sa[3][c0]);
+            b = (sb[0][c0] + sb[1][c0]) + (sb[2][c0] + sb[3][c0]);
+            means_pool[(int64_t)slots.slot[seg] * d + c] = pivots[(int64_t)seg * d + c] + a / (double)n;
+            acc += (b - a * a / (double)n) / (double)(n - 1);  // one cell: 0 / 0 = NaN, as colVars gives NA
+        }
+        __syncthreads();
+    }
+    if (g == 0) sacc[c0] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 64; ++i) t += sacc[i];
+        scal[slots.slot[seg]] = t;
+    }
+}
+
+// mu = sum_s n_s mean_s / sum_s n_s over the segments of a node (their means are current)
+__global__ void combine_means(const double* __restrict__ means_pool, SegDesc sd, StatSlots slots, int d,
+                              double* __restrict__ mu) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d) return;
+    double s = 0.0, n = 0.0;
+    for (int i = 0; i < sd.nseg; ++i) {
+        s += (double)sd.n[i] * means_pool[(int64_t)slots.slot[i] * d + c];
+        n += (double)sd.n[i];
+    }
+    mu[c] = s / n;
+}
+
+// .get_batch_magnitude (R/fastMNN.R:582-595): sqrt(sum(ave^2) / sum(colMeans(correction^2))), 0 if the latter is 0
+__global__ void batch_magnitude_kernel(const double* __restrict__ overall, const double* __restrict__ msq, int d,
+                                       double* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double l2sq = 0.0, ave = 0.0;
+    for (int c = 0; c < d; ++c) {
+        ave += msq[c];
+        l2sq += overall[c] * overall[c];
+    }
+    *out = ave == 0.0 ? 0.0 : sqrt(l2sq / ave);
+}
+
 __global__ void transpose_kernel(const double* __restrict__ in, int rows_in, int cols_in, double* __restrict__ out,
                                  int ld_out, int out_col_off) {
     // in: [cols_in][rows_in] viewed as column-major (rows_in x cols_in) i.e. in[c * rows_in + r];
@@ -275,33 +361,6 @@ void col_reduce(hipStream_t stream, ReduceWorkspace& ws, const double* X, const 
     BMX_LAUNCH_CHECK();
 }
 
-void segment_variances(hipStream_t stream, ReduceWorkspace& ws, const double* X, int d, const int* starts,
-                       const int* ns, int nseg, double* out, int out_stride) {
-    for (int s0 = 0; s0 < nseg; s0 += 16) {
-        SegDesc sd;
-        sd.nseg = std::min(16, nseg - s0);
-        int maxn = 1;
-        for (int i = 0; i < sd.nseg; ++i) {
-            sd.start[i] = starts[s0 + i];
-            sd.n[i] = ns[s0 + i];
-            maxn = std::max(maxn, ns[s0 + i]);
-        }
-        const int maxnb = cdiv(maxn, RED_ROWS);
-        double* partial = ws.partial.reserve((size_t)sd.nseg * maxnb * d + (size_t)2 * 16 * d);
-        double* means = partial + (size_t)sd.nseg * maxnb * d;
-        double* vars = means + (size_t)16 * d;
-        hipLaunchKernelGGL(seg_reduce_partial, dim3(maxnb, sd.nseg), dim3(256), 0, stream, X, d, sd, 0, nullptr, maxnb,
-                           partial);
-        hipLaunchKernelGGL(seg_reduce_final, dim3(sd.nseg), dim3(256), 0, stream, partial, maxnb, d, sd, 0, means);
-        hipLaunchKernelGGL(seg_reduce_partial, dim3(maxnb, sd.nseg), dim3(256), 0, stream, X, d, sd, 2, means, maxnb,
-                           partial);
-        hipLaunchKernelGGL(seg_reduce_final, dim3(sd.nseg), dim3(256), 0, stream, partial, maxnb, d, sd, 2, vars);
-        hipLaunchKernelGGL(seg_sum_kernel, dim3(1), dim3(64), 0, stream, vars, d, sd.nseg, out + (size_t)s0 * out_stride,
-                           out_stride);
-        BMX_LAUNCH_CHECK();
-    }
-}
-
 void sum_vector(hipStream_t stream, const double* in, int d, double scale, double* out) {
     hipLaunchKernelGGL(sum_vector_kernel, dim3(1), dim3(64), 0, stream, in, d, scale, out);
     BMX_LAUNCH_CHECK();
@@ -313,25 +372,6 @@ void average_correction(hipStream_t stream, const double* L, const int32_t* lrow
     if (U <= 0) return;
     hipLaunchKernelGGL(average_correction_kernel, dim3(cdiv(U, 4)), dim3(256), 0, stream, L, lrows, R, rrows, d,
                        second_u, U, partR, cntR, k1, averaged);
-    BMX_LAUNCH_CHECK();
-}
-
-void center_along_batch_vector(hipStream_t stream, ReduceWorkspace& ws, double* X, int n, int d, const double* vec,
-                               const int32_t* restrict_rows, int n_restrict, double* loc, double* scratch3) {
-    if (n <= 0) return;
-    if (d > 256) throw Error(BMX_ERR_ARG, "more than 256 dimensions are not supported");
-    const int gp = std::min(cdiv(n, 4), 4096);
-    hipLaunchKernelGGL(project_rows, dim3(gp), dim3(256), 0, stream, X, n, d, vec, loc);
-    BMX_LAUNCH_CHECK();
-    const int m = restrict_rows ? n_restrict : n;
-    const int nb = std::min(std::max(1, cdiv(m, 1024)), 1024);
-    double* partial = ws.partial.reserve(nb);
-    hipLaunchKernelGGL(mean_partial, dim3(nb), dim3(256), 0, stream, loc, restrict_rows, m, partial);
-    BMX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(mean_final, dim3(1), dim3(64), 0, stream, partial, nb, 1.0 / (double)m, scratch3);
-    BMX_LAUNCH_CHECK();
-    const int gs = (int)std::min<int64_t>(((int64_t)n * d + 255) / 256, 8192);
-    hipLaunchKernelGGL(shift_rows, dim3(gs), dim3(256), 0, stream, X, n, d, vec, loc, scratch3);
     BMX_LAUNCH_CHECK();
 }
 
@@ -354,6 +394,88 @@ void transpose_rm_to_cm(hipStream_t stream, const double* rm, int n, int d, doub
     if (n <= 0) return;
     hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(d, 32), cdiv(n, 32)), dim3(32, 8), 0, stream, rm, d, n, cm, ld_cm,
                        row_off);
+    BMX_LAUNCH_CHECK();
+}
+
+
+// ---- fused row passes (host side) -------------------------------------------------------------------
+namespace {
+void fill_desc(SegDesc& sd, StatSlots* sl, const int* starts, const int* ns, const int* slots, int s0, int cnt, int* maxn) {
+    sd.nseg = cnt;
+    *maxn = 1;
+    for (int i = 0; i < cnt; ++i) {
+        sd.start[i] = starts[s0 + i];
+        sd.n[i] = ns[s0 + i];
+        if (sl) sl->slot[i] = slots[s0 + i];
+        *maxn = std::max(*maxn, ns[s0 + i]);
+    }
+}
+}  // namespace
+
+void rows_apply_stats(hipStream_t stream, ReduceWorkspace& ws, double* X, int d, const int* starts, const int* ns,
+                      int nseg, const double* mu, const double* vec_pool, const int* vec_ids, int nvec,
+                      const int* stat_slots, double* means_pool, double* scal) {
+    if (d > 256) throw Error(BMX_ERR_ARG, "more than 256 dimensions are not supported");
+    const bool stats = stat_slots != nullptr;
+    if (nvec == 0 && !stats) return;
+    for (int s0 = 0; s0 < nseg; s0 += 16) {
+        SegDesc sd;
+        StatSlots sl;
+        int maxn = 1;
+        fill_desc(sd, stats ? &sl : nullptr, starts, ns, stat_slots, s0, std::min(16, nseg - s0), &maxn);
+        const int maxnb = cdiv(maxn, PASS_ROWS);
+        double* partial = nullptr;
+        double* pivots = nullptr;
+        if (stats) {
+            partial = ws.partial.reserve((size_t)sd.nseg * maxnb * 2 * d + (size_t)16 * d);
+            pivots = partial + (size_t)sd.nseg * maxnb * 2 * d;
+        }
+        const dim3 grid(maxnb, sd.nseg);
+        // batch vectors in launches of PASS_EMAX; the statistics ride on the last one (they describe the final rows)
+        int e0 = 0;
+        do {
+            VecIds ids;
+            ids.n = std::min(PASS_EMAX, nvec - e0);
+            for (int e = 0; e < ids.n; ++e) ids.id[e] = vec_ids[e0 + e];
+            const bool last = e0 + ids.n >= nvec;
+            if (stats && last) {
+                // the pivots are read from rows this very launch rewrites: take them first, after the earlier launches
+                hipLaunchKernelGGL(gather_pivots, dim3(sd.nseg), dim3(64), 0, stream, X, d, sd, pivots);
+                if (ids.n > 0)
+                    hipLaunchKernelGGL((rows_pass<true, true>), grid, dim3(256), 0, stream, X, d, sd, mu, vec_pool, ids,
+                                       pivots, maxnb, partial);
+                else
+                    hipLaunchKernelGGL((rows_pass<false, true>), grid, dim3(256), 0, stream, X, d, sd, mu, vec_pool, ids,
+                                       pivots, maxnb, partial);
+                hipLaunchKernelGGL(rows_stats_final, dim3(sd.nseg), dim3(256), 0, stream, partial, maxnb, d, sd, pivots, sl,
+                                   means_pool, scal);
+            } else if (ids.n > 0) {
+                hipLaunchKernelGGL((rows_pass<true, false>), grid, dim3(256), 0, stream, X, d, sd, mu, vec_pool, ids,
+                                   nullptr, maxnb, nullptr);
+            }
+            BMX_LAUNCH_CHECK();
+            e0 += ids.n;
+        } while (e0 < nvec);
+    }
+}
+
+void node_mean_from_segments(hipStream_t stream, const double* means_pool, const int* ns, const int* slots, int nseg,
+                             int d, double* mu) {
+    if (nseg > 16) throw Error(BMX_ERR_ARG, "node_mean_from_segments: more than 16 segments");
+    SegDesc sd;
+    StatSlots sl;
+    sd.nseg = nseg;
+    for (int i = 0; i < nseg; ++i) {
+        sd.start[i] = 0;
+        sd.n[i] = ns[i];
+        sl.slot[i] = slots[i];
+    }
+    hipLaunchKernelGGL(combine_means, dim3(cdiv(d, 64)), dim3(64), 0, stream, means_pool, sd, sl, d, mu);
+    BMX_LAUNCH_CHECK();
+}
+
+void batch_magnitude(hipStream_t stream, const double* overall, const double* msq, int d, double* out) {
+    hipLaunchKernelGGL(batch_magnitude_kernel, dim3(1), dim3(64), 0, stream, overall, msq, d, out);
     BMX_LAUNCH_CHECK();
 }
 

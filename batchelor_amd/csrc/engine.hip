@@ -1,5 +1,6 @@
 // Merge engine (host orchestration of the HIP kernels): R/fastMNN.R:398-562, R/MNN_tree.R:61-77,113-226.
 #include "engine.hpp"
+#include "rccl_dyn.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -52,6 +53,10 @@ Engine::Engine(int device) : device_(device) {
 
 Engine::~Engine() {
     (void)hipSetDevice(device_);
+    if (comm_ && rccl::api().CommDestroy) {
+        if (stream_) (void)hipStreamSynchronize(stream_);
+        (void)rccl::api().CommDestroy(comm_);
+    }
     if (stream_) {
         (void)hipStreamSynchronize(stream_);
         (void)hipStreamDestroy(stream_);
@@ -63,14 +68,60 @@ Engine::~Engine() {
 void Engine::set_shard(int rank, int world, bmx_allgather_fn fn, void* ctx) {
     if (world < 1 || rank < 0 || rank >= world) throw Error(BMX_ERR_ARG, "invalid rank / world size");
     if (world > 1 && !fn) throw Error(BMX_ERR_ARG, "a multi-rank engine needs an all-gather callback");
+    if (comm_ && rccl::api().CommDestroy) {  // a callback replaces an RCCL communicator
+        if (stream_) (void)hipStreamSynchronize(stream_);
+        (void)rccl::api().CommDestroy(comm_);
+        comm_ = nullptr;
+    }
     rank_ = rank;
     world_ = world;
     gather_fn_ = fn;
     gather_ctx_ = ctx;
 }
 
+void Engine::init_rccl(int rank, int world, const void* unique_id) {
+    CacheScope cache_scope(&cache_);
+    BMX_HIP(hipSetDevice(device_));
+    if (world < 1 || rank < 0 || rank >= world) throw Error(BMX_ERR_ARG, "invalid rank / world size");
+    if (!unique_id) throw Error(BMX_ERR_ARG, "null RCCL unique id");
+    rccl::Api& a = rccl::api();
+    if (!a.ready()) throw Error(BMX_ERR_EXCHANGE, "RCCL is not loaded (bmx_rccl_load)");
+    if (comm_) {
+        BMX_HIP(hipStreamSynchronize(stream_));
+        (void)a.CommDestroy(comm_);
+        comm_ = nullptr;
+    }
+    rccl::UniqueId id;
+    std::memcpy(id.internal, unique_id, sizeof(id.internal));
+    const int rc = a.CommInitRank(&comm_, world, id, rank);
+    if (rc != 0) {
+        comm_ = nullptr;
+        throw Error(BMX_ERR_EXCHANGE, std::string("ncclCommInitRank failed: ") +
+                                          (a.GetErrorString ? a.GetErrorString(rc) : std::to_string(rc).c_str()));
+    }
+    rank_ = rank;
+    world_ = world;
+    gather_fn_ = nullptr;
+    gather_ctx_ = nullptr;
+}
+
 void Engine::exchange(void* buf, int64_t bytes_per_rank) {
-    if (world_ == 1) return;
+    // BMX_EXCHANGE_ALWAYS (testing hook): a single rank goes through its transport too (an in-place all-gather of one)
+    static const bool always = std::getenv("BMX_EXCHANGE_ALWAYS") != nullptr;
+    if (world_ == 1 && !(always && (comm_ || gather_fn_))) return;
+    ++xchg_calls_;
+    xchg_bytes_ += bytes_per_rank * world_;
+    if (comm_) {
+        // in place (send buffer = this rank's slice of the receive buffer), ordered on the engine's stream: no host
+        // synchronisation, the next kernel simply queues behind the collective
+        char* base = static_cast<char*>(buf);
+        const int rc = rccl::api().AllGather(base + (int64_t)rank_ * bytes_per_rank, base, (size_t)bytes_per_rank,
+                                             /* ncclUint8 */ 1, comm_, stream_);
+        if (rc != 0)
+            throw Error(BMX_ERR_EXCHANGE, std::string("ncclAllGather failed: ") +
+                                              (rccl::api().GetErrorString ? rccl::api().GetErrorString(rc) : "?"));
+        return;
+    }
     BMX_HIP(hipStreamSynchronize(stream_));
     const int rc = gather_fn_(gather_ctx_, buf, bytes_per_rank);
     if (rc != 0) throw Error(BMX_ERR_EXCHANGE, "the all-gather callback failed with code " + std::to_string(rc));
@@ -129,7 +180,7 @@ void Engine::knn(const double* X, const int32_t* ref_rows, int nr, const double*
     int64_t b = 0, e = nq;
     bmx_shard_range_impl(nq, rank_, world_, &b, &e);
     knn_device(stream_, knn_ws_, X, ref_rows, nr, Q, q_rows, nq, d_, k, idx, dist, (int)b, (int)e);
-    if (world_ > 1) {
+    {
         const int64_t per = (nq + world_ - 1) / world_;
         exchange(idx, per * k * (int64_t)sizeof(int32_t));
         if (dist) exchange(dist, per * k * (int64_t)sizeof(double));
@@ -190,25 +241,75 @@ Engine::MnnOut Engine::find_mnn(const Node& left, const Node& right, int k, doub
     return o;
 }
 
-void Engine::perbatch_var(const Node& node, int scal_off) {
-    // .compute_perbatch_var (R/fastMNN.R:651-658): per original batch, sum over dims of the sample variance
-    std::vector<int> starts, ns;
+namespace {
+void segment_layout(const Node& node, std::vector<int>& starts, std::vector<int>& ns) {
     int r0 = 0;
     for (const Segment& s : node.origin) {
         starts.push_back(r0);
         ns.push_back(s.n);
         r0 += s.n;
     }
-    segment_variances(stream_, red_ws_, node.data.p, d_, starts.data(), ns.data(), (int)ns.size(), scal_.p + scal_off, 2);
+}
+}  // namespace
+
+void Engine::node_mean(const Node& node, double* mu) {
+    bool fresh = !node.has_restrict && node.origin.size() <= 16 && node.stat_slot.size() == node.origin.size();
+    for (int sl : node.stat_slot) fresh = fresh && sl >= 0;
+    if (fresh) {
+        std::vector<int> starts, ns;
+        segment_layout(node, starts, ns);
+        node_mean_from_segments(stream_, means_pool_.p, ns.data(), node.stat_slot.data(), (int)ns.size(), d_, mu);
+    } else if (node.has_restrict) {
+        col_reduce(stream_, red_ws_, node.data.p, node.restrict_rows.p, 0, node.n_restrict, d_, 0, nullptr,
+                   1.0 / (double)node.n_restrict, mu);
+    } else {
+        col_reduce(stream_, red_ws_, node.data.p, nullptr, 0, node.n, d_, 0, nullptr, 1.0 / (double)node.n, mu);
+    }
+}
+
+void Engine::row_pass(Node& node, const std::vector<int>& vec_ids, bool with_stats, const double* mu_known) {
+    if (vec_ids.empty() && !with_stats) return;
+    double* mu_own = vecs_.p + (size_t)(2 * B_ + 5) * d_;
+    if (!vec_ids.empty() && !mu_known) node_mean(node, mu_own);
+    const double* mu = mu_known ? mu_known : mu_own;
+    std::vector<int> starts, ns, slots;
+    segment_layout(node, starts, ns);
+    if (with_stats) {
+        if (n_slots_ + (int)ns.size() > slot_cap_) throw Error(BMX_ERR_ARG, "internal: statistics slots exhausted");
+        for (size_t i = 0; i < ns.size(); ++i) slots.push_back(n_slots_++);
+    }
+    rows_apply_stats(stream_, red_ws_, node.data.p, d_, starts.data(), ns.data(), (int)ns.size(), mu, vecs_.p,
+                     vec_ids.data(), (int)vec_ids.size(), with_stats ? slots.data() : nullptr, means_pool_.p, scal_.p);
+    if (with_stats)
+        node.stat_slot = slots;
+    else
+        node.stat_slot.assign(node.origin.size(), -1);  // the rows moved: their statistics are stale
+}
+
+void Engine::ensure_stats(Node& node) {
+    // .compute_perbatch_var (R/fastMNN.R:651-658) only for the segments whose rows changed since their last statistics
+    if (node.stat_slot.size() != node.origin.size()) node.stat_slot.assign(node.origin.size(), -1);
+    std::vector<int> starts, ns, slots, which;
+    int r0 = 0;
+    for (size_t i = 0; i < node.origin.size(); ++i) {
+        if (node.stat_slot[i] < 0) {
+            starts.push_back(r0);
+            ns.push_back(node.origin[i].n);
+            which.push_back((int)i);
+        }
+        r0 += node.origin[i].n;
+    }
+    if (which.empty()) return;
+    if (n_slots_ + (int)which.size() > slot_cap_) throw Error(BMX_ERR_ARG, "internal: statistics slots exhausted");
+    for (size_t i = 0; i < which.size(); ++i) slots.push_back(n_slots_++);
+    rows_apply_stats(stream_, red_ws_, node.data.p, d_, starts.data(), ns.data(), (int)ns.size(), nullptr, vecs_.p, nullptr,
+                     0, slots.data(), means_pool_.p, scal_.p);
+    for (size_t i = 0; i < which.size(); ++i) node.stat_slot[which[i]] = slots[i];
 }
 
 void Engine::orthogonalize(Node& node, const std::vector<int>& extras) {
-    // .orthogonalize_other (R/fastMNN.R:642-647): sequentially, each on the result of the previous
-    double* loc = loc_.reserve((size_t)node.n + 8);
-    for (int id : extras)
-        center_along_batch_vector(stream_, red_ws_, node.data.p, node.n, d_, vecs_.p + (size_t)id * d_,
-                                  node.has_restrict ? node.restrict_rows.p : nullptr, node.n_restrict, loc,
-                                  loc + node.n);
+    // .orthogonalize_other (R/fastMNN.R:642-647): sequentially, each on the result of the previous -- one pass
+    row_pass(node, extras, false);
 }
 
 std::unique_ptr<Node> Engine::clone_node(const Node& src) {
@@ -216,6 +317,7 @@ std::unique_ptr<Node> Engine::clone_node(const Node& src) {
     n->index = src.index;
     n->n = src.n;
     n->origin = src.origin;
+    n->stat_slot = src.stat_slot;
     n->extras = src.extras;
     n->has_restrict = src.has_restrict;
     n->n_restrict = src.n_restrict;
@@ -252,18 +354,25 @@ void Engine::merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p,
     MergeRecord& rec = merges_[mdx];
     rec.left_set = left.index;
     rec.right_set = right.index;
-    const int nseg = (int)(left.origin.size() + right.origin.size());
     rec.var_batches.clear();
     for (const Segment& s : left.origin) rec.var_batches.push_back(s.batch);
     for (const Segment& s : right.origin) rec.var_batches.push_back(s.batch);
-    const int off_l = rec.scal_off, off_r = rec.scal_off + 2 * (int)left.origin.size();
-    (void)nseg;
 
-    perbatch_var(left, off_l);   // "old" variances (R/fastMNN.R:467-468)
-    perbatch_var(right, off_r);
+    // "old" variances (R/fastMNN.R:467-468): a segment untouched since its last statistics keeps them (the left
+    // node's segments carry the "new" variances of the merge that made it)
+    ensure_stats(left);
+    ensure_stats(right);
+    rec.old_slot = left.stat_slot;
+    rec.old_slot.insert(rec.old_slot.end(), right.stat_slot.begin(), right.stat_slot.end());
 
-    orthogonalize(right, left.extras);  // R/fastMNN.R:473-474
-    orthogonalize(left, right.extras);
+    // the restrict-row column means of both sides: centring along a vector never moves them, so the ones taken here
+    // (from the fresh segment statistics where there is no restriction) serve every pass of this merge
+    double* mu_l = vecs_.p + (size_t)(2 * B_ + 6) * d_;
+    double* mu_r = vecs_.p + (size_t)(2 * B_ + 7) * d_;
+    node_mean(left, mu_l);
+    node_mean(right, mu_r);
+    row_pass(right, left.extras, false, mu_r);  // .orthogonalize_other, R/fastMNN.R:473-474
+    row_pass(left, right.extras, false, mu_l);
 
     if (mdx == snap_merge_) {
         snap_nl_ = left.n;
@@ -302,34 +411,32 @@ void Engine::merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p,
     bool do_correct = true;
     rec.batch_size_na = std::isnan(p.min_batch_skip);
     rec.skipped = false;
+    rec.bs_slot = -1;
     if (!rec.batch_size_na) {
-        // .get_batch_magnitude (R/fastMNN.R:582-595): sqrt(sum(ave^2) / sum(colMeans(correction^2)))
+        // .get_batch_magnitude (R/fastMNN.R:582-595) on the device; the host only looks at it here when a merge can
+        // actually be skipped (min.batch.skip > 0), otherwise with everything else at the end of the run
         double* msq = vecs_.p + (size_t)(2 * B_ + 4) * d_;
         col_reduce(stream_, red_ws_, averaged, nullptr, 0, mo.U, d_, 1, nullptr, 1.0 / (double)mo.U, msq);
-        std::vector<double> h(2 * (size_t)d_);
-        BMX_HIP(hipMemcpyAsync(h.data(), overall, d_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
-        BMX_HIP(hipMemcpyAsync(h.data() + d_, msq, d_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
-        BMX_HIP(hipStreamSynchronize(stream_));
-        double l2sq = 0.0, ave_l2sq = 0.0;
-        for (int c = 0; c < d_; ++c) {
-            ave_l2sq += h[d_ + c];
-            l2sq += h[c] * h[c];
-        }
-        rec.batch_size = ave_l2sq == 0.0 ? 0.0 : std::sqrt(l2sq / ave_l2sq);
-        if (rec.batch_size < p.min_batch_skip) {
-            do_correct = false;
-            rec.skipped = true;
+        if (n_slots_ + 1 > slot_cap_) throw Error(BMX_ERR_ARG, "internal: statistics slots exhausted");
+        rec.bs_slot = n_slots_++;
+        batch_magnitude(stream_, overall, msq, d_, scal_.p + rec.bs_slot);
+        if (p.min_batch_skip > 0.0) {
+            double h = 0.0;
+            BMX_HIP(hipMemcpyAsync(&h, scal_.p + rec.bs_slot, sizeof(double), hipMemcpyDeviceToHost, stream_));
+            BMX_HIP(hipStreamSynchronize(stream_));
+            if (h < p.min_batch_skip) {
+                do_correct = false;
+                rec.skipped = true;
+            }
         }
     }
 
     if (do_correct) {
-        double* loc = loc_.reserve((size_t)std::max(left.n, right.n) + 8);
-        center_along_batch_vector(stream_, red_ws_, left.data.p, left.n, d_, overall, lrows, nLs, loc,
-                                  loc + std::max(left.n, right.n));  // R/fastMNN.R:496-497
-        center_along_batch_vector(stream_, red_ws_, right.data.p, right.n, d_, overall, rrows, nRs, loc,
-                                  loc + std::max(left.n, right.n));
-        perbatch_var(left, off_l + 1);  // "new" variances (R/fastMNN.R:500-501)
-        perbatch_var(right, off_r + 1);
+        // R/fastMNN.R:496-501: centre both sides along the batch vector; the "new" variances come out of the same pass
+        row_pass(left, {vid}, true, mu_l);
+        row_pass(right, {vid}, true, mu_r);
+        rec.new_slot = left.stat_slot;
+        rec.new_slot.insert(rec.new_slot.end(), right.stat_slot.begin(), right.stat_slot.end());
 
         // R/fastMNN.R:505-507: re-average on the centred data, then the tricube-smoothed correction of the right batch
         average_correction(stream_, left.data.p, lrows, right.data.p, rrows, d_, second_u_.p, mo.U, partR_.p,
@@ -345,10 +452,14 @@ void Engine::merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p,
         double* distT = distT_.reserve((size_t)per * safe_k);
         knn(right.data.p, srows, mo.U, right.data.p, nullptr, right.n, safe_k, idxT, distT);
         tricube_apply(stream_, right.data.p, right.n, d_, averaged, idxT, distT, safe_k, p.ndist);
+        right.stat_slot.assign(right.origin.size(), -1);  // the corrected cells moved
         ++n_extras_;
     } else {
-        perbatch_var(left, off_l + 1);
-        perbatch_var(right, off_r + 1);
+        // skipped: the "new" variances are those of the (orthogonalised) data as it stands (R/fastMNN.R:500-501)
+        ensure_stats(left);
+        ensure_stats(right);
+        rec.new_slot = left.stat_slot;
+        rec.new_slot.insert(rec.new_slot.end(), right.stat_slot.begin(), right.stat_slot.end());
     }
 
     // UPDATE (R/fastMNN.R:520-525): rbind, combine restrict, concatenate origin / extras
@@ -363,6 +474,8 @@ void Engine::merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p,
                            hipMemcpyDeviceToDevice, stream_));
     m.origin = left.origin;
     m.origin.insert(m.origin.end(), right.origin.begin(), right.origin.end());
+    m.stat_slot = left.stat_slot;
+    m.stat_slot.insert(m.stat_slot.end(), right.stat_slot.begin(), right.stat_slot.end());
     m.extras = left.extras;
     m.extras.insert(m.extras.end(), right.extras.begin(), right.extras.end());
     if (do_correct) m.extras.push_back(vid);
@@ -382,8 +495,8 @@ void Engine::merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p,
             hipLaunchKernelGGL(iota_offset, dim3(cdiv(nRs, 256)), dim3(256), 0, stream_, mr + nLs, nRs, left.n);
         BMX_LAUNCH_CHECK();
     }
-    // the copies above read left/right data: the caller frees those nodes only after the stream has drained them
-    BMX_HIP(hipStreamSynchronize(stream_));
+    // the copies above read left / right data: the caller releases those nodes into this engine's block cache, whose
+    // next user is ordered behind the copies by the stream
 }
 
 void Engine::run(const bmx_params_t& p, const int32_t* tree, int tree_len) {
@@ -396,19 +509,17 @@ void Engine::run(const bmx_params_t& p, const int32_t* tree, int tree_len) {
     merges_.clear();
     merges_.resize(nmerges);
     n_extras_ = 0;
+    xchg_calls_ = xchg_bytes_ = 0;
     knn_ws_.events_used = 0;
     vecs_.reserve((size_t)(2 * B_ + 8) * d_);
-    // variance scalars: every merge records (old, new) for at most B segments
-    {
-        int off = 8;  // slot 0 doubles as the exact-path counter
-        for (int m = 0; m < nmerges; ++m) {
-            merges_[m].scal_off = off;
-            off += 2 * B_;
-        }
-        scal_.reserve(off);
-        BMX_HIP(hipMemsetAsync(scal_.p, 0, (size_t)off * sizeof(double), stream_));
-        scal_host_.assign(off, 0.0);
-    }
+    // statistics slots (column means [d] + total variance) and batch.size scalars: a merge takes at most one per
+    // segment before and after its centring, plus one
+    slot_cap_ = (2 * B_ + 2) * B_ + 8;
+    n_slots_ = 0;
+    scal_.reserve(slot_cap_);
+    means_pool_.reserve((size_t)slot_cap_ * d_);
+    BMX_HIP(hipMemsetAsync(scal_.p, 0, (size_t)slot_cap_ * sizeof(double), stream_));
+    scal_host_.assign(slot_cap_, 0.0);
     knn_ws_.exact_total = knn_ws_.tier2_total = 0;
 
     // leaves: row-major working copies of the resident inputs
@@ -569,12 +680,14 @@ void Engine::download(double* corrected, int32_t* batch, int32_t* merge_left, in
         if (merge_right)
             for (int j = 0; j < B_; ++j)
                 merge_right[(size_t)m * B_ + j] = j < (int)rec.right_set.size() ? rec.right_set[j] : 0;
-        if (batch_size) batch_size[m] = rec.batch_size_na ? std::numeric_limits<double>::quiet_NaN() : rec.batch_size;
+        if (batch_size)
+            batch_size[m] = rec.batch_size_na || rec.bs_slot < 0 ? std::numeric_limits<double>::quiet_NaN()
+                                                                  : scal_host_[rec.bs_slot];
         if (skipped) skipped[m] = rec.skipped ? 1 : 0;
         if (lost_var) {
             for (int b = 0; b < B_; ++b) lost_var[(size_t)b * nmerges + m] = 0.0;  // 1 - var.kept, var.kept starts at 1
             for (size_t s = 0; s < rec.var_batches.size(); ++s) {
-                const double oldv = scal_host_[rec.scal_off + 2 * s], newv = scal_host_[rec.scal_off + 2 * s + 1];
+                const double oldv = scal_host_[rec.old_slot[s]], newv = scal_host_[rec.new_slot[s]];
                 lost_var[(size_t)(rec.var_batches[s] - 1) * nmerges + m] = 1.0 - newv / oldv;
             }
         }

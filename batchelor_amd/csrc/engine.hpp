@@ -22,6 +22,7 @@ struct Node {
     DevBuf<int32_t> restrict_rows;  // 0-based, in the caller's order (any order, no cell twice)
     int n_restrict = 0;
     std::vector<Segment> origin;  // MNN_treenode@origin as run lengths
+    std::vector<int> stat_slot;   // per segment: slot of its current column means / total variance, -1 = stale
     std::vector<int> extras;      // ids of batch vectors in the engine's pool (MNN_treenode@extras)
 };
 
@@ -38,8 +39,9 @@ struct MergeRecord {
     double batch_size = 0.0;
     bool batch_size_na = true;
     bool skipped = false;
-    int scal_off = 0;  // offset of this merge's variance scalars in the device scalar buffer
-    std::vector<int> var_batches;  // batch id of each (old, new) scalar pair, left segments first
+    int bs_slot = -1;              // slot of batch.size in the device scalar buffer
+    std::vector<int> var_batches;  // per segment (left segments first): batch id, ...
+    std::vector<int> old_slot, new_slot;  // ... slots of its total variance before / after the merge's centring
 };
 
 void bmx_shard_range_impl(int64_t n, int rank, int world, int64_t* begin, int64_t* end);
@@ -49,6 +51,11 @@ class Engine {
     explicit Engine(int device);
     ~Engine();
     void set_shard(int rank, int world, bmx_allgather_fn fn, void* ctx);
+    // production exchange: an RCCL communicator owned by the engine, all-gathers in place on the engine's stream
+    void init_rccl(int rank, int world, const void* unique_id);
+    // exchange statistics since the last run() started
+    int64_t exchange_calls() const { return xchg_calls_; }
+    int64_t exchange_bytes() const { return xchg_bytes_; }
     void upload(int nbatches, int d, const double* const* data, const int32_t* nrows,
                 const int32_t* const* restrict_idx, const int32_t* n_restrict);
     void run(const bmx_params_t& p, const int32_t* tree, int tree_len);
@@ -90,11 +97,17 @@ class Engine {
     DevBuf<int32_t> idxLR_, idxRL_, cntL_, offL_, partR_, cntR_, flagR_, offR_, second_u_, second_rows_, idxT_;
     DevBuf<int32_t> flagL_, offSel_, lsel_, qsel_;
     DevBuf<unsigned long long> maskL_;
-    DevBuf<double> distT_, averaged_, loc_, vecs_, scal_;
+    DevBuf<double> distT_, averaged_, loc_, vecs_, scal_, means_pool_;
+    int n_slots_ = 0, slot_cap_ = 0;
 
   private:
     void merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p, std::unique_ptr<Node>& merged);
-    void perbatch_var(const Node& node, int scal_off);
+    // statistics (column means + total variance) of the segments whose slot is stale
+    void ensure_stats(Node& node);
+    // one pass over the node: centre along the given batch vectors (may be none), optionally with fresh statistics
+    // mu_known: the node's restrict-row column mean when the caller already has it (it is invariant under centring)
+    void row_pass(Node& node, const std::vector<int>& vec_ids, bool with_stats, const double* mu_known = nullptr);
+    void node_mean(const Node& node, double* mu);  // column mean over the restrict rows (all rows without restrict)
     void orthogonalize(Node& node, const std::vector<int>& extras);
     int count_mnn_pairs(const Node& left, const Node& right, const bmx_params_t& p);
     std::unique_ptr<Node> clone_node(const Node& src);
@@ -105,6 +118,8 @@ class Engine {
     int rank_ = 0, world_ = 1;
     bmx_allgather_fn gather_fn_ = nullptr;
     void* gather_ctx_ = nullptr;
+    void* comm_ = nullptr;  // ncclComm_t
+    int64_t xchg_calls_ = 0, xchg_bytes_ = 0;
     int64_t fallbacks_ = 0;
     int snap_merge_ = -1;
     DevBuf<double> snap_l_, snap_r_;

@@ -70,6 +70,48 @@ class TorchExchange:
         torch.cuda.synchronize(self.device)
 
 
+def rccl_library_path():
+    """The RCCL this process already uses: the one next to torch's HIP libraries (one RCCL per process)."""
+    import os
+    import torch
+    cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    return cand if os.path.exists(cand) else "librccl.so"
+
+
+def init_engine_rccl(engine, group=None):
+    """Gives `engine` its own RCCL communicator over the ranks of an initialised torch.distributed group: the
+    all-gathers of the path then run inside the engine, in place on its stream (bmx_engine_init_rccl).  The 128-byte
+    id is made on rank 0 and handed round with broadcast_object_list (any backend).  Collective."""
+    import torch.distributed as dist
+    lib = _lib.lib()
+    import torch
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    # loading RCCL is local and can fail on one rank only: agree on it before the collective set-up, so that either
+    # every rank goes on or every rank raises (and the caller falls back together)
+    err = None
+    try:
+        _lib.check(lib.bmx_rccl_load(rccl_library_path().encode()))
+    except Exception as exc:  # noqa: BLE001
+        err = exc
+    if world > 1:
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else "cpu"
+        flag = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        if int(flag.item()) and err is None:
+            err = RuntimeError("RCCL could not be loaded on another rank")
+    if err is not None:
+        raise err
+    buf = ctypes.create_string_buffer(128)
+    if rank == 0:
+        _lib.check(lib.bmx_rccl_unique_id(buf, 128))
+    box = [buf.raw]
+    if world > 1:
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    uid = ctypes.create_string_buffer(box[0], 128)
+    _lib.check(lib.bmx_engine_init_rccl(engine._h, int(rank), int(world), uid, 128))
+    return rank, world
+
+
 def sharded_knn_reference(knn_fn, X, Q, k, exchange_tensor_fn, rank, world):
     """Host-side statement of the sharded search: rank-local kNN on its query slice, then the in-place all-gather of
     the padded per-rank slices.  `knn_fn(X, Qslice, k) -> (idx, dist)`.  Used by the CPU (gloo) tests."""

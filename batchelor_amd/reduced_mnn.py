@@ -125,6 +125,11 @@ class MnnEngine:
             raise err
         _lib.check(rc)
 
+    def exchange_stats(self):
+        calls, nbytes = ctypes.c_int64(0), ctypes.c_int64(0)
+        _lib.check(_lib.lib().bmx_engine_exchange_stats(self._h, ctypes.byref(calls), ctypes.byref(nbytes)))
+        return {"calls": calls.value, "bytes": nbytes.value}
+
     def set_profiling(self, on=True):
         _lib.check(_lib.lib().bmx_engine_set_profiling(self._h, 1 if on else 0))
 

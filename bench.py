@@ -162,8 +162,19 @@ def main():
     n_cells = int(sum(sizes))
 
     eng = bx.MnnEngine(local_rank)
+    exchange = "none"
     if world > 1:
-        eng.set_shard(rank, world, TorchExchange(local_rank))
+        # production: RCCL inside the engine (in place, on its stream); if the communicator cannot be made, the
+        # torch.distributed all-gather through the callback
+        from batchelor_amd.dist import init_engine_rccl
+        try:
+            init_engine_rccl(eng)
+            exchange = "rccl in engine"
+        except Exception as exc:  # noqa: BLE001
+            if rank == 0:
+                print(f"bench.py: engine-owned RCCL unavailable ({exc}); using torch.distributed", file=sys.stderr)
+            eng.set_shard(rank, world, TorchExchange(local_rank))
+            exchange = "torch.distributed all_gather_into_tensor"
     eng.upload(batches)  # inputs resident in HBM from here on
 
     def barrier():

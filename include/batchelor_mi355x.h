@@ -103,6 +103,16 @@ int32_t bmx_engine_create(int32_t device, bmx_engine_t** out);
 void bmx_engine_destroy(bmx_engine_t* e);
 /* Every kNN search is split by query rows over `world` ranks and completed with `fn`; all ranks hold all batches. */
 int32_t bmx_engine_set_shard(bmx_engine_t* e, int32_t rank, int32_t world, bmx_allgather_fn fn, void* ctx);
+/* Production exchange: RCCL called from inside the engine, in place on the engine's stream (no host round trip, no
+ * staging copy).  bmx_rccl_load resolves the RCCL entry points from `librccl_path` (the RCCL the process already
+ * uses -- one RCCL per process; NULL searches the global scope); rank 0 makes the 128-byte id with
+ * bmx_rccl_unique_id and the host side hands it to every rank (MPI, torch.distributed, a file: not this library's
+ * business); bmx_engine_init_rccl is collective over the ranks and replaces any callback set with set_shard. */
+int32_t bmx_rccl_load(const char* librccl_path);
+int32_t bmx_rccl_unique_id(void* id_out, int32_t bytes);
+int32_t bmx_engine_init_rccl(bmx_engine_t* e, int32_t rank, int32_t world, const void* unique_id, int32_t bytes);
+/* All-gathers issued and bytes received by this rank since the last bmx_engine_run started. */
+int32_t bmx_engine_exchange_stats(bmx_engine_t* e, int64_t* calls, int64_t* bytes);
 /* Copies the batches to HBM.  data[b]: nrows[b] x d column-major; restrict_idx[b]: 1-based, any order, no cell twice,
  * n_restrict[b] entries, or NULL / n_restrict[b] < 0 for "all cells" (R/checkInputs.R:96-120 normalises them). */
 int32_t bmx_engine_upload(bmx_engine_t* e, int32_t nbatches, int32_t d, const double* const* data,

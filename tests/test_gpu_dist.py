@@ -66,3 +66,41 @@ print("nccl-ok")
     env = dict(os.environ, BMX_ROOT=ROOT, BMX_PORT=str(port))
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "nccl-ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_engine_owned_rccl_communicator_world_size_one():
+    """The production exchange: RCCL called from inside the engine, in place on its stream.  One GPU on the test box, so
+    the communicator has one rank; BMX_EXCHANGE_ALWAYS makes that rank go through ncclAllGather for every list anyway.
+    The result must be the plain engine's, bit for bit, and the gathers must have happened."""
+    code = r'''
+import os, sys
+sys.path.insert(0, os.environ["BMX_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["BMX_PORT"], rank=0, world_size=1)
+import batchelor_amd as bx
+from batchelor_amd.dist import init_engine_rccl
+from tests.conftest import synth_batches
+B = synth_batches(13, [3001, 2500, 1777], 50)
+ref = bx.reducedMNN(*B)
+eng = bx.MnnEngine(0)
+assert init_engine_rccl(eng) == (0, 1)
+eng.upload(B)
+eng.run()
+got = eng.download()
+st = eng.exchange_stats()
+assert st["calls"] == 2 * (2 + 2), st      # per merge: two index gathers + tricube index and distance gathers
+assert np.array_equal(got.corrected, ref.corrected)
+for (a, b), (c, d) in zip(got.merge_info.pairs, ref.merge_info.pairs):
+    assert np.array_equal(a, c) and np.array_equal(b, d)
+eng.close()
+dist.destroy_process_group()
+print("rccl-engine-ok")
+'''
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, BMX_ROOT=ROOT, BMX_PORT=str(port), BMX_EXCHANGE_ALWAYS="1", PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "rccl-engine-ok" in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
