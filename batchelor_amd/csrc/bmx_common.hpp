@@ -208,8 +208,12 @@ bool bf16_launch(hipStream_t stream, KnnWorkspace& ws, int NS, int KS, const Bf1
 // ties by lowest position).  X/Q are row-major [*, d]; ref_rows / q_rows (0-based, may be null = identity) select
 // nr / nq rows.  idx_out [nq][k] receives 0-based POSITIONS in the reference list; dist_out [nq][k] Euclidean
 // distances (may be null).  Only rows [q_begin, q_end) of the outputs are written.
+// seed_d2 (nullable, [nq] f32): per query an upper bound of the squared distance beyond which the caller has no use
+// for neighbours.  The search then starts from that threshold instead of a sampled one and a row may come back with
+// fewer than k neighbours, padded with -1: exactly the references within the bound, or the k nearest if there are
+// more than k of them.
 void knn_device(hipStream_t stream, KnnWorkspace& ws, const double* X, const int32_t* ref_rows, int nr,
                 const double* Q, const int32_t* q_rows, int nq, int d, int k, int32_t* idx_out, double* dist_out,
-                int q_begin, int q_end);
+                int q_begin, int q_end, const float* seed_d2 = nullptr);
 
 }  // namespace bmx

@@ -32,6 +32,11 @@ void emit_pairs(hipStream_t stream, const int32_t* idxLR, int nL, int k2, const 
 // off[r] = position of a listed row in sel, off[n_rows] = their number), sel = the listed rows, ascending.
 void select_listed_rows(hipStream_t stream, ScanWorkspace& ws, const int32_t* idx, int64_t n_entries, int n_rows,
                         int32_t* flag, int32_t* off, int32_t* sel);
+// seed[c] (c < nsel) = the largest squared distance (rounded up to f32) at which a right cell lists the c-th selected
+// left cell: idxRL / distRL [n_entries] = the right cells' neighbour lists with their Euclidean distances, lpos2c maps
+// a listed left cell to its row among the selected ones.  No mutual partner of that left cell lies farther.
+void seed_thresholds(hipStream_t stream, const int32_t* idxRL, const double* distRL, int64_t n_entries,
+                     const int32_t* lpos2c, int nsel, float* seed);
 // out[i] = rows[sel[i]]
 void compose_row_list(hipStream_t stream, const int32_t* sel, int n, const int32_t* rows, int32_t* out);
 // second_u = ascending positions r with cntR[r] > 0 (offR = exclusive scan of the 0/1 flags, computed here).

@@ -175,11 +175,11 @@ void Engine::upload(int nbatches, int d, const double* const* data, const int32_
 }
 
 void Engine::knn(const double* X, const int32_t* ref_rows, int nr, const double* Q, const int32_t* q_rows, int nq,
-                 int k, int32_t* idx, double* dist) {
+                 int k, int32_t* idx, double* dist, const float* seed_d2) {
     // query rows are split over ranks; the padded per-rank slices are contiguous, so the all-gather is in place
     int64_t b = 0, e = nq;
     bmx_shard_range_impl(nq, rank_, world_, &b, &e);
-    knn_device(stream_, knn_ws_, X, ref_rows, nr, Q, q_rows, nq, d_, k, idx, dist, (int)b, (int)e);
+    knn_device(stream_, knn_ws_, X, ref_rows, nr, Q, q_rows, nq, d_, k, idx, dist, (int)b, (int)e, seed_d2);
     {
         const int64_t per = (nq + world_ - 1) / world_;
         exchange(idx, per * k * (int64_t)sizeof(int32_t));
@@ -199,8 +199,9 @@ Engine::MnnOut Engine::find_mnn(const Node& left, const Node& right, int k, doub
     if (o.k1 < 1 || o.k2 < 1) throw Error(BMX_ERR_ARG, "'k' must be positive");
     const int64_t perR = (nR + world_ - 1) / world_ * (int64_t)world_;
     int32_t* idxRL = idxRL_.reserve((size_t)perR * o.k1);
-    // 1. every right cell's neighbours in LEFT
-    knn(left.data.p, lrows, nL, right.data.p, rrows, nR, o.k1, idxRL, nullptr);
+    // 1. every right cell's neighbours in LEFT, with their distances
+    double* distRL = distRL_.reserve((size_t)perR * o.k1);
+    knn(left.data.p, lrows, nL, right.data.p, rrows, nR, o.k1, idxRL, distRL);
     // 2. a pair needs its left cell in some right cell's list, so only those left cells are searched in RIGHT (with a
     //    growing merged reference most left cells are in nobody's list).  The result is the same set of pairs.
     int32_t* flagL = flagL_.reserve(nL);
@@ -220,7 +221,12 @@ Engine::MnnOut Engine::find_mnn(const Node& left, const Node& right, int k, doub
     }
     const int64_t perL = (nsel + world_ - 1) / world_ * (int64_t)world_;
     int32_t* idxLR = idxLR_.reserve((size_t)std::max<int64_t>(1, perL) * o.k2);
-    knn(right.data.p, rrows, nR, left.data.p, qsel, nsel, o.k2, idxLR, nullptr);
+    // A right cell r can only pair with a left cell l if it lists l, at a distance search 1 has just measured: the
+    // largest such distance bounds how far search 2 has to look for l -- a tight starting threshold for free (no
+    // sample pass, and few candidates beyond the ones that matter).  Rows may come back short, padded with -1.
+    float* seed = seedL_.reserve((size_t)std::max<int64_t>(1, perL));
+    seed_thresholds(stream_, idxRL, distRL, (int64_t)nR * o.k1, offSel, nsel, seed);
+    knn(right.data.p, rrows, nR, left.data.p, qsel, nsel, o.k2, idxLR, nullptr, seed);
     int32_t* cntL = cntL_.reserve(std::max(1, nsel));
     int32_t* offL = offL_.reserve((size_t)nsel + 1);
     int32_t* partR = partR_.reserve((size_t)nR * o.k1);

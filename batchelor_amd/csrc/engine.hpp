@@ -75,7 +75,7 @@ class Engine {
 
     // single primitives (also used by the host-pointer parity entry points)
     void knn(const double* X, const int32_t* ref_rows, int nr, const double* Q, const int32_t* q_rows, int nq, int k,
-             int32_t* idx, double* dist);
+             int32_t* idx, double* dist, const float* seed_d2 = nullptr);
     struct MnnOut {
         int64_t P = 0;
         int U = 0;
@@ -97,7 +97,8 @@ class Engine {
     DevBuf<int32_t> idxLR_, idxRL_, cntL_, offL_, partR_, cntR_, flagR_, offR_, second_u_, second_rows_, idxT_;
     DevBuf<int32_t> flagL_, offSel_, lsel_, qsel_;
     DevBuf<unsigned long long> maskL_;
-    DevBuf<double> distT_, averaged_, loc_, vecs_, scal_, means_pool_;
+    DevBuf<double> distT_, distRL_, averaged_, loc_, vecs_, scal_, means_pool_;
+    DevBuf<float> seedL_;
     int n_slots_ = 0, slot_cap_ = 0;
 
   private:

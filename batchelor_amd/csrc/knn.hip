@@ -83,10 +83,26 @@ __device__ __forceinline__ double exact_d2(const double* __restrict__ a, const d
         typedef double d2 __attribute__((ext_vector_type(2)));
         const d2* a2 = reinterpret_cast<const d2*>(a);
         const d2* b2 = reinterpret_cast<const d2*>(b);
+        // eight 16-byte pieces of the (randomly placed) row b in flight at a time; the sum itself stays strictly left
+        // to right (compiled with -ffp-contract=off: the reference's sum, bit for bit)
+        for (; c + 16 <= d; c += 16) {
+            d2 y[8], x[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) y[i] = b2[(c >> 1) + i];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] = a2[(c >> 1) + i];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const double t0 = x[i][0] - y[i][0];
+                s += t0 * t0;
+                const double t1 = x[i][1] - y[i][1];
+                s += t1 * t1;
+            }
+        }
         for (; c < d; c += 2) {
             const d2 x = a2[c >> 1], y = b2[c >> 1];
             const double t0 = x[0] - y[0];
-            s += t0 * t0;  // compiled with -ffp-contract=off: the reference's left-to-right sum, bit for bit
+            s += t0 * t0;
             const double t1 = x[1] - y[1];
             s += t1 * t1;
         }
@@ -124,6 +140,36 @@ __device__ __forceinline__ double pass_scale(double max_n2) {  // same arithmeti
     return ldexp(1.0, e - 1);
 }
 
+// error bound of a candidate pass for one query (unscaled units): f32 rounding of the centred coordinates +
+// accumulation over eps_k terms, the low-order products the pass drops (eps_split |q||r|), and fp16 inputs below the
+// normal range taken as flushed to zero (eps_den, scaled units)
+__device__ __forceinline__ double pass_eps(double qn, double rm, double s, double eps_k, double eps_qr, double eps_split,
+                                           double eps_den) {
+    const double u = 5.9604644775390625e-8;  // 2^-24
+    return 1.5 * u * (2.0 * (qn + rm) * (qn + rm) + (eps_k + 1.0) * (rm * rm + eps_qr * qn * rm)) +
+           eps_split * qn * rm + eps_den * ((2.0 * qn + rm) * s + 1.0) / (s * s);
+}
+
+// seeded search: the starting threshold of query q in the pass's own units.  A reference within seed_d2[q] of the
+// query has an approximate value below (seed - |q~|^2 + eps) s^2, so nothing the caller cares about is filtered out.
+__global__ void seed_tau_kernel(const float* __restrict__ seed_d2, const double* __restrict__ qn2,
+                                const unsigned long long* __restrict__ max_rn2_bits, int nq, int nq_pad, double eps_k,
+                                double eps_qr, double eps_split, double eps_den, int scaled,
+                                uint32_t* __restrict__ tau_g) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq_pad) return;
+    float t = -__builtin_inff();  // padded queries: nothing passes
+    if (q < nq) {
+        const double max_rn2 = __longlong_as_double((long long)*max_rn2_bits);
+        const double s = scaled ? pass_scale(max_rn2) : 1.0;
+        const double eps = pass_eps(sqrt(qn2[q]), sqrt(max_rn2), s, eps_k, eps_qr, eps_split, eps_den);
+        const double x = ((double)seed_d2[q] - qn2[q] + eps) * (s * s);
+        t = (float)(x + fabs(x) * 9.5367431640625e-7 + 1e-30);  // + 2^-20 relative: the f32 rounding cannot land below x
+    }
+    const uint32_t o = f32_orderable(t);
+    tau_g[q] = q < nq ? min(tau_g[q], o) : o;  // the image is order-preserving: min of images = image of the min
+}
+
 __global__ __launch_bounds__(256) void knn_refine(const double* __restrict__ X, const int32_t* __restrict__ ref_rows,
                                                   const double* __restrict__ Q, const int32_t* __restrict__ q_rows,
                                                   int nq, int d, int k, int KS, int nchunks, double eps_k, double eps_qr,
@@ -131,8 +177,9 @@ __global__ __launch_bounds__(256) void knn_refine(const double* __restrict__ X, 
                                                   const int32_t* __restrict__ cand, const float* __restrict__ cand_v,
                                                   const float* __restrict__ tau, const double* __restrict__ qn2,
                                                   const unsigned long long* __restrict__ max_rn2_bits,
-                                                  int32_t* __restrict__ idx_out, double* __restrict__ dist_out,
-                                                  int32_t* __restrict__ flagged, double* __restrict__ flag_bound) {
+                                                  const float* __restrict__ seed_d2, int32_t* __restrict__ idx_out,
+                                                  double* __restrict__ dist_out, int32_t* __restrict__ flagged,
+                                                  double* __restrict__ flag_bound) {
     __shared__ double sd[4][REFINE_MAXM];
     __shared__ int si[4][REFINE_MAXM];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -144,13 +191,7 @@ __global__ __launch_bounds__(256) void knn_refine(const double* __restrict__ X, 
     const double max_rn2 = __longlong_as_double((long long)*max_rn2_bits);
     const double s = scaled ? pass_scale(max_rn2) : 1.0;
     const double s2inv = 1.0 / (s * s);
-    const double qn = sqrt(qn2[q]);
-    const double rm = sqrt(max_rn2);
-    const double u = 5.9604644775390625e-8;  // 2^-24
-    // f32 rounding of the centred coordinates + accumulation over eps_k terms, the low-order products the pass drops
-    // (eps_split |q||r|), and fp16 inputs below the normal range taken as flushed to zero (eps_den, scaled units)
-    const double eps = 1.5 * u * (2.0 * (qn + rm) * (qn + rm) + (eps_k + 1.0) * (rm * rm + eps_qr * qn * rm)) +
-                       eps_split * qn * rm + eps_den * ((2.0 * qn + rm) * s + 1.0) * s2inv;
+    const double eps = pass_eps(sqrt(qn2[q]), sqrt(max_rn2), s, eps_k, eps_qr, eps_split, eps_den);
     // 1. dense list of the valid candidates (ballot prefix)
     int M = 0;
     float* sv = reinterpret_cast<float*>(&sd[w][0]) + REFINE_MAXM;  // upper half of this wave's sd row: approx values
@@ -221,7 +262,12 @@ __global__ __launch_bounds__(256) void knn_refine(const double* __restrict__ X, 
         sd[w][m] = exact_d2(qv, X + (int64_t)(ref_rows ? ref_rows[id] : id) * d, d);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    double kth = M >= k ? 0.0 : __builtin_inf();  // fewer than k candidates: never certified
+    // fewer than k candidates: never certified -- unless the search was seeded, where the row is complete as soon as
+    // nothing within the seed distance can have been rejected: the seed then plays the k-th distance's part
+    const double seed = seed_d2 ? (double)seed_d2[q] : __builtin_inf();
+    double kth = M >= k ? 0.0 : seed;
+    if (seed_d2)
+        for (int m = M + lane; m < k; m += 64) idx_out[(int64_t)q * k + m] = -1;
     for (int m = lane; m < M; m += 64) {
         const double dm = sd[w][m];
         const int im = si[w][m];
@@ -240,6 +286,8 @@ __global__ __launch_bounds__(256) void knn_refine(const double* __restrict__ X, 
         tmin = fminf(tmin, __shfl_xor(tmin, o));
         kth = fmax(kth, __shfl_xor(kth, o));
     }
+    // a seeded row only has to be right up to the seed distance: entries beyond it are of no use to the caller
+    kth = fmin(kth, seed);
     if (lane == 0) {
         const bool proven = kth < (double)tmin * s2inv + qn2[q] - eps;  // tmin = +inf when nothing was ever rejected
         if (!proven) {
@@ -443,7 +491,7 @@ int candidate_tiers(int d, int k, int nr, Tier out[2]) {
 // are listed in `flagged` (count in flagged[0]) with their k-th candidate distance in flag_bound.
 void candidate_pass(hipStream_t stream, KnnWorkspace& ws, const Tier& T, const double* X, const int32_t* ref_rows, int nr,
                     const double* Qs, const int32_t* qrs, int nq, int d, int k, int32_t* io, double* dout,
-                    int32_t* flagged, double* flag_bound) {
+                    int32_t* flagged, double* flag_bound, const float* seed_d2) {
     const int NS = T.NS, KS = T.KS;
     ws.last_variant = T.id == 1 ? 3 : 2;
     const int unit = 256;  // queries per workgroup: 8 consumer waves of 32 (both ring kernels)
@@ -459,6 +507,8 @@ void candidate_pass(hipStream_t stream, KnnWorkspace& ws, const Tier& T, const d
     // more candidates to append and select (the harmonic tail of the running threshold) -- with the fp16 kernel's
     // cheap tiles the balance is at ~16k rows
     const int S_auto = nr >= 65536 && T.id == 1 ? 16384 : 4096;
+    // (a seeded search samples too: the odd query whose seed is loose -- a left cell listed by one far-away right cell --
+    // then starts from the sampled threshold like everybody else; the tighter of the two counts)
     const int S = nr >= 32768 ? (std::getenv("BMX_SAMPLE") ? std::atoi(std::getenv("BMX_SAMPLE")) : S_auto) : 0;
     int C = 1, n_full = 0;
     {
@@ -522,27 +572,6 @@ void candidate_pass(hipStream_t stream, KnnWorkspace& ws, const Tier& T, const d
         bf16_prep(stream, X, ref_rows, nr, nr_pad, d, NS, mean, 0, reinterpret_cast<uint16_t*>(pr), rn2, maxbits, slots);
         bf16_prep(stream, Qs, qrs, nq, nq_pad, d, NS, mean, 1, reinterpret_cast<uint16_t*>(pq), qn2, maxbits, slots);
     }
-    // sample pass: threshold estimation over rows [0, S); full pass: every row, starting from that threshold
-    if (S == 0) {  // no sample: +inf everywhere (0xFF800000 is the orderable image of +inf)
-        hipLaunchKernelGGL(fill_u32, dim3(cdiv(nq_pad, 256)), dim3(256), 0, stream, tau_g, nq_pad, 0xFF800000u);
-        BMX_LAUNCH_CHECK();
-    }
-    Bf16Launch L{reinterpret_cast<const uint16_t*>(pq), reinterpret_cast<const uint16_t*>(pr), nqb, 0, S, 1, S, 0, nchunks,
-                 tau_g, 1, cand, cand_v, tau};
-    auto go = [&](const Bf16Launch& l) {
-        return T.id == 1 ? f16_launch(stream, ws, NS, KS, l) : bf16_launch(stream, ws, NS, KS, l);
-    };
-    bool ok = true;
-    if (S > 0) ok = go(L);
-    L.first_begin = 0;
-    L.range_len = chunk_len;
-    L.nranges = C;
-    L.n_full = C > 1 ? n_full : 0;
-    L.r_limit = nr_pad;
-    L.sample = 0;
-    ok = ok && go(L);
-    if (!ok) throw Error(BMX_ERR_ARG, "kNN: unsupported padded dimension");
-
     double eps_k, eps_qr, eps_split, eps_den;
     if (T.id == 1) {
         eps_k = 16.0 * NS;                                              // f32 accumulation over the K columns
@@ -555,10 +584,36 @@ void candidate_pass(hipStream_t stream, KnnWorkspace& ws, const Tier& T, const d
         eps_split = 1.5 * 3.03 * 2.0 * 1.52587890625e-05;               // dropped ql.rl, qh.r3, q3.rh: 3.03 * 2^-16 * 2|q||r|
         eps_den = 0.0;
     }
+    // sample pass: threshold estimation over rows [0, S); full pass: every row, starting from that threshold
+    if (S == 0) {  // no sample: +inf everywhere (0xFF800000 is the orderable image of +inf)
+        hipLaunchKernelGGL(fill_u32, dim3(cdiv(nq_pad, 256)), dim3(256), 0, stream, tau_g, nq_pad, 0xFF800000u);
+        BMX_LAUNCH_CHECK();
+    }
+    Bf16Launch L{reinterpret_cast<const uint16_t*>(pq), reinterpret_cast<const uint16_t*>(pr), nqb, 0, S, 1, S, 0, nchunks,
+                 tau_g, 1, cand, cand_v, tau};
+    auto go = [&](const Bf16Launch& l) {
+        return T.id == 1 ? f16_launch(stream, ws, NS, KS, l) : bf16_launch(stream, ws, NS, KS, l);
+    };
+    bool ok = true;
+    if (S > 0) ok = go(L);
+    if (seed_d2) {  // tau_g = min(sampled threshold, seed threshold)
+        hipLaunchKernelGGL(seed_tau_kernel, dim3(cdiv(nq_pad, 256)), dim3(256), 0, stream, seed_d2, qn2, maxbits, nq,
+                           nq_pad, eps_k, eps_qr, eps_split, eps_den, T.id == 1 ? 1 : 0, tau_g);
+        BMX_LAUNCH_CHECK();
+    }
+    L.first_begin = 0;
+    L.range_len = chunk_len;
+    L.nranges = C;
+    L.n_full = C > 1 ? n_full : 0;
+    L.r_limit = nr_pad;
+    L.sample = 0;
+    ok = ok && go(L);
+    if (!ok) throw Error(BMX_ERR_ARG, "kNN: unsupported padded dimension");
+
     BMX_HIP(hipMemsetAsync(flagged, 0, sizeof(int32_t), stream));
     hipLaunchKernelGGL(knn_refine, dim3(cdiv(nq, 4)), dim3(256), 0, stream, X, ref_rows, Qs, qrs, nq, d, k, KS, nchunks,
-                       eps_k, eps_qr, eps_split, eps_den, T.id == 1 ? 1 : 0, cand, cand_v, tau, qn2, maxbits, io, dout,
-                       flagged, flag_bound);
+                       eps_k, eps_qr, eps_split, eps_den, T.id == 1 ? 1 : 0, cand, cand_v, tau, qn2, maxbits, seed_d2, io,
+                       dout, flagged, flag_bound);
     BMX_LAUNCH_CHECK();
     if (std::getenv("BMX_DEBUG")) {
         std::vector<int32_t> hc((size_t)nq * nchunks * KS);
@@ -625,14 +680,15 @@ void exact_search(hipStream_t stream, KnnWorkspace& ws, const double* X, const i
 // queries (Qs, qrs)[0, nq) through the tiers tiers[t ...]
 void search_tiers(hipStream_t stream, KnnWorkspace& ws, const Tier* tiers, int ntiers, int t, const double* X,
                   const int32_t* ref_rows, int nr, const double* Qs, const int32_t* qrs, int nq, int d, int k, int32_t* io,
-                  double* dout) {
+                  double* dout, const float* seed_d2 = nullptr) {
     if (t >= ntiers) {
         exact_search(stream, ws, X, ref_rows, nr, Qs, qrs, d, k, io, dout, nullptr, nullptr, nq);
         return;
     }
     int32_t* flagged = ws.flagged_t[t].reserve((size_t)nq + 1);
     double* bound = ws.flag_bound_t[t].reserve((size_t)nq + 1);
-    candidate_pass(stream, ws, tiers[t], X, ref_rows, nr, Qs, qrs, nq, d, k, io, dout, flagged, bound);
+    // (what a seeded pass cannot settle goes on unseeded: the full k nearest serve the caller just as well)
+    candidate_pass(stream, ws, tiers[t], X, ref_rows, nr, Qs, qrs, nq, d, k, io, dout, flagged, bound, seed_d2);
     // the number of uncertified queries decides what is launched next, so it is read back (one small synchronisation)
     const int count = read_count(stream, flagged);
     if (count == 0) return;
@@ -660,7 +716,7 @@ void search_tiers(hipStream_t stream, KnnWorkspace& ws, const Tier* tiers, int n
 
 void knn_device(hipStream_t stream, KnnWorkspace& ws, const double* X, const int32_t* ref_rows, int nr,
                 const double* Q, const int32_t* q_rows, int nq_total, int d, int k, int32_t* idx_out,
-                double* dist_out, int q_begin, int q_end) {
+                double* dist_out, int q_begin, int q_end, const float* seed_d2) {
     (void)nq_total;
     const int nq = q_end - q_begin;
     if (nq <= 0 || k <= 0) return;
@@ -679,7 +735,8 @@ void knn_device(hipStream_t stream, KnnWorkspace& ws, const double* X, const int
     const int ntiers = ws.force_exact ? 0 : candidate_tiers(d, k, nr, tiers);
     ws.last_exact = 0;
     ws.last_flagged_tier[0] = ws.last_flagged_tier[1] = 0;
-    search_tiers(stream, ws, tiers, ntiers, 0, X, ref_rows, nr, Qs, qrs, nq, d, k, io, dout);
+    search_tiers(stream, ws, tiers, ntiers, 0, X, ref_rows, nr, Qs, qrs, nq, d, k, io, dout,
+                 seed_d2 ? seed_d2 + q_begin : nullptr);
     if (ntiers > 0) ws.exact_total += ws.last_exact;
     if (ntiers > 0) ws.tier2_total += ws.last_flagged_tier[0] * (ntiers > 1 ? 1 : 0);
 }

@@ -43,8 +43,20 @@ constexpr int NCONS = 8;   // consumer waves (32 queries each): two per SIMD
 constexpr int NPROD = 4;   // producer waves: one per SIMD
 constexpr int NQ = NCONS * 32;
 constexpr int QCAP = 64;   // spill records per consumer wave (one group of one tile can fill all 64)
-constexpr int QSOFT = 32;  // ... but the queue is worked off as soon as it holds this many: short, frequent stalls
-constexpr int HEAD = 8;    // a list is compacted ahead of time once fewer than HEAD slots are free
+#ifndef BMX_QSOFT
+#define BMX_QSOFT 24
+#endif
+#ifndef BMX_HEAD
+#define BMX_HEAD 4
+#endif
+#ifndef BMX_NPIV
+#define BMX_NPIV 4
+#endif
+#ifndef BMX_PSLEEP
+#define BMX_PSLEEP 1
+#endif
+constexpr int QSOFT = BMX_QSOFT;  // ... but the queue is worked off as soon as it holds this many: short, frequent stalls
+constexpr int HEAD = BMX_HEAD;    // a list is compacted ahead of time once fewer than HEAD slots are free
 
 __device__ __forceinline__ uint16_t f32_to_f16_bits(float f) {
     const _Float16 h = (_Float16)f;  // v_cvt_f16_f32: round to nearest even, overflow to infinity
@@ -192,8 +204,11 @@ __host__ __device__ constexpr int ring_slots_for(int NS, int LCAP) {
     return n > 8 ? 8 : n;
 }
 // list capacity: as long as the ring keeps at least four slots, else as short as a useful pending part allows
+#ifndef BMX_LCAP_MAX
+#define BMX_LCAP_MAX 56
+#endif
 __host__ __device__ constexpr int list_cap(int NS, int KS) {
-    for (int c = 64; c >= KS + 16; c -= 8)
+    for (int c = BMX_LCAP_MAX; c >= KS + 16; c -= 8)
         if (ring_slots_for(NS, c) >= 4) return c;
     return KS + 16 <= 64 ? KS + 16 : 64;
 }
@@ -244,19 +259,32 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
     }
     const int ntiles = (r_end - r_begin) >> 5;
     const int out_chunk = out_chunk0 + rng;
+    // Every workgroup sweeps its range once, but from a different starting tile (wrapping round): workgroups that are
+    // launched together then read different stretches of the reference image at any one time.  All of them reading
+    // the same 4 KB at the same moment serialises on the few L2 channels that hold it -- measured: with the starts
+    // aligned, the very same loop took 1.45x as long once nothing desynchronised the workgroups.
+#ifdef BMX_EXP_NOSTAGGER
+    const int t_off = 0;
+#else
+    const int t_off = ntiles > 0 ? (int)(((long long)(qblock & 255) * ntiles) >> 8) : 0;
+#endif
     if (tid < NSLOT * (1 + NCONS)) ready[tid] = 0;  // ready[] and done[] are contiguous
     if (tid < NQ) cnt[tid] = 0;
     __syncthreads();
 
     if (wave >= NCONS) {
         // ------------------------------------------------------------------ producer (as in knn_bf16.hip)
+#ifdef BMX_EXP_PPRIO
+        __builtin_amdgcn_s_setprio(BMX_EXP_PPRIO);
+#endif
         const int p = wave - NCONS;
         f32x4 ra[NS], rb[NS], rc[NS];
         const f32x4* src = reinterpret_cast<const f32x4*>(PrF) + ((int64_t)(r_begin >> 5) * NS) * 64 + lane;
         f32x4* ring_l = reinterpret_cast<f32x4*>(ring) + lane;
         auto load = [&](f32x4(&r)[NS], int t) {
+            const int at = t + t_off - (t + t_off >= ntiles ? ntiles : 0);  // position t of the sweep = tile `at`
 #pragma unroll
-            for (int s = 0; s < NS; ++s) r[s] = src[((int64_t)t * NS + s) * 64];
+            for (int s = 0; s < NS; ++s) r[s] = src[((int64_t)at * NS + s) * 64];
         };
         // tile t goes to slot t % NSLOT once every consumer has read the tile staged there NSLOT tiles earlier;
         // done[slot][c] = number of the last tile consumer c has read from the slot, plus one
@@ -266,7 +294,7 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
             for (;;) {
                 const int v = lane < NCONS ? lds_load_volatile(&done[slot * NCONS + lane]) : need;
                 if (__builtin_amdgcn_ballot_w64(v < need) == 0) break;
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(BMX_PSLEEP);
             }
         };
         auto publish = [&](const f32x4(&r)[NS], int t) {
@@ -357,8 +385,8 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
         int pl = 0, kept = 0x7FFFFFFF;
         uint32_t pk = 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int p = ((2 * i + 1) * n) >> 4;  // < n
+        for (int i = 0; i < BMX_NPIV; ++i) {
+            const int p = ((2 * i + 1) * n) / (2 * BMX_NPIV);  // < n
             const uint32_t k_i = (uint32_t)__builtin_amdgcn_readlane((int)key, p);
             const unsigned long long m_i = __builtin_amdgcn_ballot_w64(key < k_i);
             const int c_i = __builtin_popcountll(m_i);
@@ -573,7 +601,13 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
             }
             asm volatile("" ::"v"(best[KS / 2 - 1]));  // keep it in this block
         } else {
+#if defined(BMX_EXP_NOFILTER)
+            any = 0;  // timing experiment: no filter, no events (results are garbage)
+#elif defined(BMX_EXP_NOEVENT)
+            any = __builtin_amdgcn_ballot_w64(mn < -3.0e38f);  // timing experiment: filter runs, nothing passes
+#else
             any = __builtin_amdgcn_ballot_w64(mn < tau);
+#endif
             asm volatile("" ::"s"(any), "v"(g[0]), "v"(g[1]), "v"(g[2]), "v"(g[3]));  // keep the filter in this block
         }
 #pragma unroll
@@ -588,7 +622,8 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
         const unsigned long long dbg_e0 = STAMP();
 #endif
         // ---- spill the groups with survivors of tile t - 1
-        const uint32_t tagbase = ((uint32_t)(t - 1) << 8) | (uint32_t)lane;
+        const int at = t - 1 + t_off - (t - 1 + t_off >= ntiles ? ntiles : 0);  // the tile at position t - 1 of the sweep
+        const uint32_t tagbase = ((uint32_t)at << 8) | (uint32_t)lane;
         auto spill = [&](const int u, const unsigned long long m) {
             if (g[u] < tau) {  // the lanes of m
                 const int slot = qcount + mbcnt64(m);
@@ -646,7 +681,9 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
     for (int e = 0; e < 16; ++e) accA[e] = accB[e] = __builtin_inff();  // "previous tile" of step 0: nothing passes
     // at equal priority the second-dispatched half of the consumers (waves 4..7, one per SIMD) loses every contested
     // issue slot to its older partner: it gets the higher static priority (MI355X_MICROARCH.md, two waves per SIMD)
+#ifndef BMX_EXP_NOCPRIO
     if (wave >= NCONS / 2) __builtin_amdgcn_s_setprio(1);
+#endif
     if (ntiles > 0) {
         spin_until_staged(0);
         __atomic_signal_fence(__ATOMIC_SEQ_CST);

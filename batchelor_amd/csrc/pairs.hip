@@ -79,8 +79,8 @@ __global__ void mutual_left(const int32_t* __restrict__ idxLR, int nL, int k2, c
     int c = 0;
     unsigned long long m = 0;  // bit j: neighbour j is mutual (kept for emit_pairs when k2 <= 64)
     for (int j = 0; j < k2; ++j) {
-        const int32_t r = idxLR[(int64_t)c0 * k2 + j];
-        const bool hit = row_contains(idxRL + (int64_t)r * k1, k1, l);
+        const int32_t r = idxLR[(int64_t)c0 * k2 + j];  // -1: the (seeded) search found fewer than k2 cells in reach
+        const bool hit = r >= 0 && row_contains(idxRL + (int64_t)r * k1, k1, l);
         c += hit ? 1 : 0;
         if (hit && j < 64) m |= 1ull << j;
     }
@@ -123,7 +123,7 @@ __global__ void emit_pairs_kernel(const int32_t* __restrict__ idxLR, int nL, int
     const unsigned long long m = maskL ? maskL[c] : 0;
     for (int j = 0; j < k2; ++j) {
         const int32_t r = idxLR[(int64_t)c * k2 + j];
-        if (maskL ? ((m >> j) & 1ull) != 0 : row_contains(idxRL + (int64_t)r * k1, k1, l)) {
+        if (maskL ? ((m >> j) & 1ull) != 0 : (r >= 0 && row_contains(idxRL + (int64_t)r * k1, k1, l))) {
             first[o] = lid;
             second[o] = (rrows ? rrows[r] : r) + 1;
             ++o;
@@ -139,6 +139,18 @@ __global__ void flag_positive(const int32_t* __restrict__ cnt, int n, int32_t* _
 __global__ void mark_listed(const int32_t* __restrict__ idx, int64_t n, int32_t* __restrict__ flag) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) flag[idx[i]] = 1;  // same value from every writer: no atomics needed
+}
+
+// seed[c] = max over the right cells r that list left cell l (c = row of l among the selected left cells) of
+// d(r, l)^2, rounded up to f32: every right cell that can be a mutual partner of l lies within it
+__global__ void seed_from_lists(const int32_t* __restrict__ idxRL, const double* __restrict__ distRL, int64_t n,
+                                const int32_t* __restrict__ lpos2c, uint32_t* __restrict__ seed_bits) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double dd = distRL[i] * distRL[i] * (1.0 + 1e-15);  // sqrt, then squared again: never below the true value
+    float f = (float)dd;
+    if ((double)f < dd) f = __uint_as_float(__float_as_uint(f) + 1u);  // dd >= 0: the next float up
+    atomicMax(seed_bits + lpos2c[idxRL[i]], __float_as_uint(f));       // non-negative floats order like their bits
 }
 
 __global__ void compose_rows(const int32_t* __restrict__ sel, int n, const int32_t* __restrict__ rows,
@@ -203,6 +215,17 @@ void select_listed_rows(hipStream_t stream, ScanWorkspace& ws, const int32_t* id
     exclusive_scan_i32(stream, ws, flag, off, n_rows);
     hipLaunchKernelGGL(scatter_positions, dim3(cdiv(n_rows, 256)), dim3(256), 0, stream, flag, off, n_rows, sel);
     BMX_LAUNCH_CHECK();
+}
+
+void seed_thresholds(hipStream_t stream, const int32_t* idxRL, const double* distRL, int64_t n_entries,
+                     const int32_t* lpos2c, int nsel, float* seed) {
+    if (nsel <= 0) return;
+    BMX_HIP(hipMemsetAsync(seed, 0, (size_t)nsel * sizeof(float), stream));
+    if (n_entries > 0) {
+        hipLaunchKernelGGL(seed_from_lists, dim3(cdiv(n_entries, 256)), dim3(256), 0, stream, idxRL, distRL, n_entries,
+                           lpos2c, reinterpret_cast<uint32_t*>(seed));
+        BMX_LAUNCH_CHECK();
+    }
 }
 
 void compose_row_list(hipStream_t stream, const int32_t* sel, int n, const int32_t* rows, int32_t* out) {

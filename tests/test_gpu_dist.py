@@ -33,7 +33,7 @@ def test_two_rank_engine_equals_single_rank(tmp_path):
             assert np.array_equal(got[f"pl{m}"], ref.merge_info.pairs[m][0])
             assert np.array_equal(got[f"pr{m}"], ref.merge_info.pairs[m][1])
         assert np.array_equal(got["lost_var"], ref.merge_info.lost_var)
-        assert int(got["calls"]) == 2 * (2 + 2)   # per merge: two index gathers + tricube index and distance gathers
+        assert int(got["calls"]) == 2 * (3 + 2)   # per merge: index + distance + index gathers, tricube index + distance
 
 
 def test_nccl_exchange_aliases_raw_device_pointer():
@@ -89,7 +89,7 @@ eng.upload(B)
 eng.run()
 got = eng.download()
 st = eng.exchange_stats()
-assert st["calls"] == 2 * (2 + 2), st      # per merge: two index gathers + tricube index and distance gathers
+assert st["calls"] == 2 * (3 + 2), st      # per merge: index + distance + index gathers, tricube index + distance
 assert np.array_equal(got.corrected, ref.corrected)
 for (a, b), (c, d) in zip(got.merge_info.pairs, ref.merge_info.pairs):
     assert np.array_equal(a, c) and np.array_equal(b, d)
