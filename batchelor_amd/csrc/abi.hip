@@ -536,6 +536,19 @@ int32_t bmx_engine_snapshot(bmx_engine_t* e, double* left_rm, double* right_rm, 
     return guarded([&] { e->impl->snapshot(left_rm, right_rm, n_left, n_right); });
 }
 
+int32_t bmx_engine_profile_detail(bmx_engine_t* e, double* out10) {
+    return guarded([&] { e->impl->profile_detail(out10); });
+}
+
+int32_t bmx_engine_knn_kernel(bmx_engine_t* e, char* buf, int32_t n) {
+    return guarded([&] {
+        if (!buf || n < 1) throw bmx::Error(BMX_ERR_ARG, "no buffer");
+        const std::string& k = e->impl->knn_ws_.last_kernel;
+        std::strncpy(buf, k.c_str(), (size_t)n - 1);
+        buf[n - 1] = 0;
+    });
+}
+
 int32_t bmx_engine_knn_variant(bmx_engine_t* e) { return e && e->impl ? e->impl->knn_ws_.last_variant : -1; }
 
 int32_t bmx_fast_mnn(int32_t nbatches, int32_t d, const double* const* data, const int32_t* nrows,

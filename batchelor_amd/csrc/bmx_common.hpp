@@ -167,8 +167,12 @@ struct KnnWorkspace {
     int last_variant = -1;  // candidate pass of the last search's first tier: 3 = fp16 ring, 2 = split-bf16 ring
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    std::vector<int> event_tag;  // per used pair: 0 = sample pass, 1 = fp16 full pass, 2 = split-bf16 full pass, 3 = streaming section
     size_t events_used = 0;
-    std::pair<hipEvent_t, hipEvent_t> next_events() {
+    std::string last_kernel;     // name of the last full-pass candidate kernel, as rocprofv3 prints it
+    std::pair<hipEvent_t, hipEvent_t> next_events(int tag = 1) {
+        if (event_tag.size() <= events_used) event_tag.resize(events_used + 1);
+        event_tag[events_used] = tag;
         if (events_used == events.size()) {
             hipEvent_t a, b;
             BMX_HIP(hipEventCreate(&a));

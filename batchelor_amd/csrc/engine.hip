@@ -364,6 +364,7 @@ void Engine::merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p,
     for (const Segment& s : left.origin) rec.var_batches.push_back(s.batch);
     for (const Segment& s : right.origin) rec.var_batches.push_back(s.batch);
 
+    std::unique_ptr<Section> sec = std::make_unique<Section>(this);  // streaming section 1: statistics, orthogonalisation
     // "old" variances (R/fastMNN.R:467-468): a segment untouched since its last statistics keeps them (the left
     // node's segments carry the "new" variances of the merge that made it)
     ensure_stats(left);
@@ -388,8 +389,10 @@ void Engine::merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p,
         BMX_HIP(hipMemcpyAsync(snap_r_.reserve((size_t)right.n * d_), right.data.p,
                                (size_t)right.n * d_ * sizeof(double), hipMemcpyDeviceToDevice, stream_));
     }
+    sec.reset();
     const MnnOut mo = find_mnn(left, right, p.k, p.prop_k);  // R/fastMNN.R:476-477
     if (mo.P == 0) throw Error(BMX_ERR_NO_PAIRS, "no mutual nearest neighbours found between batches");
+    sec = std::make_unique<Section>(this);  // streaming section 2: pairs, averaging, centring + statistics
     const int nLs = left.has_restrict ? left.n_restrict : left.n;
     const int nRs = right.has_restrict ? right.n_restrict : right.n;
     const int32_t* lrows = left.has_restrict ? left.restrict_rows.p : nullptr;
@@ -456,7 +459,9 @@ void Engine::merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p,
         const int64_t per = (right.n + world_ - 1) / world_ * (int64_t)world_;
         int32_t* idxT = idxT_.reserve((size_t)per * safe_k);
         double* distT = distT_.reserve((size_t)per * safe_k);
+        sec.reset();
         knn(right.data.p, srows, mo.U, right.data.p, nullptr, right.n, safe_k, idxT, distT);
+        sec = std::make_unique<Section>(this);  // streaming section 3: tricube apply, rbind
         tricube_apply(stream_, right.data.p, right.n, d_, averaged, idxT, distT, safe_k, p.ndist);
         right.stat_slot.assign(right.origin.size(), -1);  // the corrected cells moved
         ++n_extras_;
@@ -770,6 +775,32 @@ void Engine::snapshot(double* left_rm, double* right_rm, int64_t* nl, int64_t* n
 void Engine::merge_stats(int merge, int64_t* out6) const {
     if (merge < 0 || merge >= (int)merges_.size()) throw Error(BMX_ERR_ARG, "merge index out of range");
     for (int i = 0; i < 6; ++i) out6[i] = merges_[merge].stats[i];
+}
+
+Engine::Section::Section(Engine* eng) : e(eng) {
+    if (e->knn_ws_.profile) {
+        ev = e->knn_ws_.next_events(3);
+        (void)hipEventRecord(ev.first, e->stream_);
+    }
+}
+Engine::Section::~Section() {
+    if (ev.second) (void)hipEventRecord(ev.second, e->stream_);
+}
+
+void Engine::profile_detail(double* out10) {
+    for (int i = 0; i < 10; ++i) out10[i] = 0.0;
+    for (size_t i = 0; i < knn_ws_.events_used; ++i) {
+        float t = 0.f;
+        BMX_HIP(hipEventElapsedTime(&t, knn_ws_.events[i].first, knn_ws_.events[i].second));
+        switch (knn_ws_.event_tag[i]) {
+            case 1: out10[0] += t; out10[1] += 1; break;
+            case 2: out10[2] += t; out10[3] += 1; break;
+            case 0: out10[4] += t; out10[5] += 1; break;
+            default: out10[6] += t; break;
+        }
+    }
+    out10[7] = (double)fallbacks_;
+    out10[8] = (double)knn_ws_.tier2_total;
 }
 
 void Engine::profile(double* topk_ms, int64_t* launches, int64_t* fallbacks) {

@@ -69,6 +69,10 @@ class Engine {
     void set_snapshot(int merge) { snap_merge_ = merge; }
     void snapshot(double* left_rm, double* right_rm, int64_t* nl, int64_t* nr);
     void profile(double* topk_ms, int64_t* launches, int64_t* fallbacks);
+    // out[0..9]: full-pass ms / launches of the fp16 kernel, of the split-bf16 kernel, sample-pass ms / launches,
+    // streaming-section ms (everything of the merges that is not a kNN search), queries that took the exact path,
+    // queries handed from tier 1 to tier 2, all since the last run() started (profiling on)
+    void profile_detail(double* out10);
     int nbatches() const { return B_; }
     int64_t total_cells() const { return N_; }
     hipStream_t stream() const { return stream_; }
@@ -122,6 +126,12 @@ class Engine {
     void* comm_ = nullptr;  // ncclComm_t
     int64_t xchg_calls_ = 0, xchg_bytes_ = 0;
     int64_t fallbacks_ = 0;
+    struct Section {  // a streaming section bracketed by events while profiling
+        Engine* e;
+        std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+        explicit Section(Engine* eng);
+        ~Section();
+    };
     int snap_merge_ = -1;
     DevBuf<double> snap_l_, snap_r_;
     int64_t snap_nl_ = 0, snap_nr_ = 0;

@@ -611,7 +611,7 @@ void launch(hipStream_t stream, KnnWorkspace& ws, const Bf16Launch& L) {
     ensure_dynamic_lds(reinterpret_cast<const void*>(&knn_topk_bf16<NS, KS, NCONS, NPROD, PLN, true>), lds);
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     if (ws.profile) {
-        ev = ws.next_events();
+        ev = ws.next_events(L.sample ? 0 : 2);
         BMX_HIP(hipEventRecord(ev.first, stream));
     }
     const int items = L.n_full + (L.nqb - L.n_full) * L.nranges;

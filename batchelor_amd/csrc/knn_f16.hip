@@ -32,6 +32,7 @@
 #include "knn_select.hpp"
 
 #include <cmath>
+#include <string>
 
 namespace bmx {
 namespace {
@@ -764,9 +765,12 @@ void launch(hipStream_t stream, KnnWorkspace& ws, const Bf16Launch& L) {
     ensure_dynamic_lds(reinterpret_cast<const void*>(&knn_topk_f16<NS, KS, LCAP, true>), lds);
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     if (ws.profile) {
-        ev = ws.next_events();
+        ev = ws.next_events(L.sample ? 0 : 1);
         BMX_HIP(hipEventRecord(ev.first, stream));
     }
+    if (!L.sample)
+        ws.last_kernel = "knn_topk_f16<" + std::to_string(NS) + ", " + std::to_string(KS) + ", " + std::to_string(LCAP) +
+                         ", false>";
     const int items = L.n_full + (L.nqb - L.n_full) * L.nranges;
     if (L.sample)
         hipLaunchKernelGGL((knn_topk_f16<NS, KS, LCAP, true>), dim3(items), dim3((NCONS + NPROD) * 64), lds, stream,

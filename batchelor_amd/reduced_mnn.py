@@ -152,6 +152,15 @@ class MnnEngine:
         _lib.check(_lib.lib().bmx_engine_snapshot(self._h, _lib.f64p(left), _lib.f64p(right), None, None))
         return left, right
 
+    def profile_detail(self):
+        a = np.zeros(10, dtype=np.float64)
+        _lib.check(_lib.lib().bmx_engine_profile_detail(self._h, _lib.f64p(a)))
+        buf = ctypes.create_string_buffer(128)
+        _lib.check(_lib.lib().bmx_engine_knn_kernel(self._h, buf, 128))
+        return {"f16_ms": a[0], "f16_launches": int(a[1]), "bf16_ms": a[2], "bf16_launches": int(a[3]),
+                "sample_ms": a[4], "sample_launches": int(a[5]), "streaming_ms": a[6],
+                "exact_fallbacks": int(a[7]), "tier2_queries": int(a[8]), "kernel": buf.value.decode()}
+
     def merge_stats(self):
         out = []
         for m in range(self.nbatches - 1):

@@ -14,9 +14,10 @@ m-th new batch is orthogonalised against m-1 earlier batch vectors).  `--workloa
 With N > 1 the same job is split by kNN query rows over the ranks (strong scaling) and the per-rank neighbour lists
 are all-gathered with RCCL; every rank ends with the full result.
 
-Rank 0 prints ONE JSON line with the contract fields plus `roofline` (dominant kernel knn_topk_mfma: algorithmic
-FLOPs / HIP-event time vs the f32-input MFMA peak) and, at N = 1, `cpu_baseline` (the CPU oracle timed on a bounded
-sample of the same workload on this box's host cores).
+Rank 0 prints ONE JSON line with the contract fields plus `roofline` (dominant kernel knn_topk_f16: algorithmic
+FLOPs / HIP-event time of its launches vs the dense fp16 MFMA peak), `streaming` (the HBM-bound rest of the merges
+against the HBM peak), `value_host_to_host` (upload, run, download and pairs included) and, at N = 1, `cpu_baseline`
+(two CPU statements of the dominant step timed on a bounded sample of the same workload on this box's host cores).
 """
 import argparse
 import json
@@ -74,17 +75,20 @@ def synth_batches(config, sizes, d, shift=1.0):
     return out
 
 
-def measured_traffic(workload, variant):
+def measured_traffic(workload, kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/): FETCH_SIZE and
     WRITE_SIZE collected in separate --pmc runs of this very command, corrected as MI355X_MICROARCH.md prescribes
     for gfx950 (FETCH_SIZE x 2).  PMC counters cannot be read from inside the timed process, so the number is the
-    last committed measurement for the same workload and kernel; None when there is none."""
-    path = os.path.join(ROOT, "profiles", f"r01_traffic_{workload}_bf16.json")
+    last committed measurement -- and it is only reported when it was taken on the very kernel (template arguments
+    included) this run has just launched; otherwise None plus the reason."""
+    path = os.path.join(ROOT, "profiles", f"r02_traffic_{workload}.json")
     try:
         rec = json.load(open(path))
     except (OSError, ValueError):
-        return None
-    return rec["bytes_per_launch"] if rec.get("variant") == variant and rec.get("workload") == workload else None
+        return None, f"no committed PMC measurement for {workload}"
+    if rec.get("workload") != workload or not str(rec.get("kernel", "")).startswith(kernel):
+        return None, f"committed PMC measurement is for {rec.get('kernel')!r}, this run launched {kernel!r}"
+    return rec["bytes_per_launch"], None
 
 
 def algorithmic_flops(stats, d):
@@ -93,40 +97,75 @@ def algorithmic_flops(stats, d):
     return sum(2.0 * d * (m["nL"] * m["nR"] + m["nR_all"] * m["U"]) for m in stats)
 
 
-def cpu_baseline(batches, stats, d, k):
-    """Times the CPU oracle (oracle/, "port" of the reference algorithm; the reference R/Rcpp path itself cannot run
-    on this box) on a bounded sample: the three exact searches of the merge with 2048 sampled query rows each
-    against the FULL reference sets, all host cores; extrapolated by pair evaluations to the whole job."""
-    from oracle import fastmnn_oracle as orc
+def streaming_bytes(stats, d, k):
+    """B_merge = 8 d [(nL + nR)(1 + 2 + 1) + 2 nR E + 4 P + 2 nR] + 12 nR k -- variances before and
+    after, the centring pass (read + write), orthogonalisation of the right batch against E earlier batch vectors, the
+    two gathers of the two averaging passes, the tricube apply (read + write) and its index / distance lists."""
+    tot = 0.0
+    for e, m in enumerate(stats):
+        n_l, n_r = m["nL_all"], m["nR_all"]
+        tot += 8.0 * d * ((n_l + n_r) * 4 + 2 * n_r * e + 4 * m["P"] + 2 * n_r) + 12.0 * n_r * k
+    return tot
+
+
+def cpu_baselines(batches, stats, d, k):
+    """The reference R/Rcpp path cannot run on this box (no R), so two CPU statements of its dominant step -- the
+    exact kNN searches, > 98 % of the CPU time -- are timed on a bounded sample of the same workload and extrapolated by
+    pair evaluations to the whole job (oracle/cpu_baselines.py):
+      A  one thread, pruned exact search in the manner of KmknnParam() / SerialParam(), fastMNN()'s defaults;
+      B  all host cores, blocked brute force on the host BLAS;
+      C  all host cores, the oracle's OpenMP brute force (no BLAS).
+    Returns (main, variants): main = the faster one in the contract's cpu_baseline form."""
+    from oracle import cpu_baselines as cb
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     L, R = batches[0], batches[1]
     rng = np.random.default_rng(0)
-    U = max(k, int(stats[0]["U"]))
-    sub = R[rng.choice(R.shape[0], min(U, R.shape[0]), replace=False)]
-
-    def timed(ns):
-        ql = L[rng.choice(L.shape[0], min(ns, L.shape[0]), replace=False)]
-        qr = R[rng.choice(R.shape[0], min(ns, R.shape[0]), replace=False)]
-        t0 = time.perf_counter()
-        orc.query_knn(R, ql, k, nthreads=cores)
-        orc.query_knn(L, qr, k, nthreads=cores)
-        orc.query_knn(sub, qr, k, nthreads=cores)
-        dt = time.perf_counter() - t0
-        return ql, qr, dt, ql.shape[0] * R.shape[0] + qr.shape[0] * L.shape[0] + qr.shape[0] * sub.shape[0]
-
-    # calibrate with a small sample, then size the timed sample for ~15 s of CPU work (bounded by the full job)
-    _, _, dt0, ev0 = timed(max(1024, 8 * cores))
-    ns = int(min(L.shape[0], max(2048, 8 * cores) * max(1.0, 15.0 / max(dt0, 1e-3))))
-    ql, qr, dt, sampled = timed(ns)
-    rate = sampled / dt
-    total = sum(2.0 * m["nL"] * m["nR"] + m["nR_all"] * m["U"] for m in stats)  # two searches per block on the CPU
+    total_pairs = sum(2.0 * m["nL"] * m["nR"] + m["nR_all"] * m["U"] for m in stats)  # two searches per block on a CPU
     n_cells = sum(b.shape[0] for b in batches)
-    return {
-        "value": n_cells / (total / rate), "unit": "cells/s", "cores": cores, "kind": "port",
-        "sample": (f"oracle exact FP64 brute-force kNN (OpenMP, {cores} threads): {ql.shape[0]} sampled query rows x "
-                   f"full reference set for each of the 3 searches of the merge, {dt:.1f} s; extrapolated by pair "
-                   f"evaluations ({rate:.3g}/s) to the whole job (kNN is >98% of the CPU time)"),
-    }
+    out = {}
+    # A: build on one batch (the k-means cost scales with the cells, like the search), a few hundred queries
+    t0 = time.perf_counter()
+    nq_a = 256
+    qa = R[rng.choice(R.shape[0], nq_a, replace=False)]
+    _, _, st = cb.kmknn_knn(L, qa, k, iters=3)
+    rate_a = nq_a * L.shape[0] / st["query_s"]
+    build_total = st["build_s"] * sum((m["nL"] + m["nR"]) for m in stats) / L.shape[0]  # an index per side per merge
+    out["A"] = {"value": n_cells / (total_pairs / rate_a + build_total), "unit": "cells/s", "cores": 1, "kind": "port",
+                "sample": (f"KMKNN-style pruned exact search (oracle/kmknn_baseline.c), 1 thread: index over "
+                           f"{L.shape[0]} cells in {st['build_s']:.1f} s, {nq_a} queries in {st['query_s']:.2f} s, "
+                           f"{100 * st['visited']:.1f}% of the reference visited per query ({rate_a:.3g} pair "
+                           f"evaluations/s); extrapolated by pair evaluations to the whole job, "
+                           f"{time.perf_counter() - t0:.0f} s of CPU time spent")}
+    # B: BLAS brute force, sized for ~10 s
+    t0 = time.perf_counter()
+    nq_b = 2048
+    cb.blas_knn(L, R[:nq_b], k)
+    dt0 = time.perf_counter() - t0
+    nq_b = int(min(R.shape[0], max(2048, 2048 * 8.0 / max(dt0, 1e-3))))
+    t0 = time.perf_counter()
+    cb.blas_knn(L, R[:nq_b], k)
+    dt = time.perf_counter() - t0
+    rate_b = nq_b * L.shape[0] / dt
+    out["B"] = {"value": n_cells / (total_pairs / rate_b), "unit": "cells/s", "cores": cores, "kind": "port",
+                "sample": (f"blocked brute force on the host BLAS (numpy, FP64 DGEMM + exact re-evaluation of the kept), "
+                           f"{cores} host threads available: {nq_b} queries x {L.shape[0]} reference cells in {dt:.1f} s "
+                           f"({rate_b:.3g} pair evaluations/s); extrapolated by pair evaluations to the whole job")}
+    # C: the oracle's own OpenMP brute force (FP64, no BLAS), all cores -- round 1's baseline, kept for continuity
+    from oracle import fastmnn_oracle as orc
+    t0 = time.perf_counter()
+    orc.query_knn(L, R[:4096], k, nthreads=cores)
+    dt0 = time.perf_counter() - t0
+    nq_c = int(min(R.shape[0], max(4096, 4096 * 8.0 / max(dt0, 1e-3))))
+    t0 = time.perf_counter()
+    orc.query_knn(L, R[:nq_c], k, nthreads=cores)
+    dt = time.perf_counter() - t0
+    rate_c = nq_c * L.shape[0] / dt
+    out["C"] = {"value": n_cells / (total_pairs / rate_c), "unit": "cells/s", "cores": cores, "kind": "port",
+                "sample": (f"oracle exact FP64 brute force (oracle/mnn_oracle.c, OpenMP, {cores} threads): {nq_c} queries x "
+                           f"{L.shape[0]} reference cells in {dt:.1f} s ({rate_c:.3g} pair evaluations/s); extrapolated "
+                           f"by pair evaluations to the whole job")}
+    main = dict(max(out.values(), key=lambda r: r["value"]))
+    return main, out
 
 
 def main():
@@ -136,6 +175,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-to-host", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -190,12 +230,16 @@ def main():
     eng.set_profiling(True)
     barrier()
     t0 = time.perf_counter()
-    topk_ms, topk_launches = 0.0, 0
+    acc = None
     for _ in range(args.steps):
         eng.run(k=k, merge_tree=tree)  # returns after the engine's stream has drained
-        p = eng.profile()
-        topk_ms += p["topk_ms"]
-        topk_launches += p["topk_launches"]
+        p = eng.profile_detail()
+        if acc is None:
+            acc = dict(p)
+        else:
+            for key, v in p.items():
+                if isinstance(v, (int, float)):
+                    acc[key] += v
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -204,12 +248,34 @@ def main():
         elapsed = float(t.item())
 
     stats = eng.merge_stats()
-    prof = eng.profile()
-    fallbacks = prof["exact_fallbacks"]
-    kern = KERNELS.get(prof["variant"], KERNELS[3])
+    variant = eng.profile()["variant"]
+    kern = KERNELS.get(variant, KERNELS[3])
+    dom = "f16" if variant == 3 else "bf16"
+    dom_ms, dom_launches = acc[dom + "_ms"], acc[dom + "_launches"]
+    xst = eng.exchange_stats() if world > 1 else {"calls": 0, "bytes": 0}
+
+    # host to host: column-major host inputs -> host outputs, upload, run, download and pairs included
+    h2h = None
+    if world == 1 and not args.no_host_to_host:
+        eng.set_profiling(False)
+        reps = []
+        for _ in range(2):
+            t1 = time.perf_counter()
+            e2 = bx.MnnEngine(local_rank)
+            e2.upload(batches)
+            e2.run(k=k, merge_tree=tree)
+            res = e2.download(with_pairs=True)
+            e2.close()
+            reps.append(time.perf_counter() - t1)
+            del res
+        h2h = min(reps)
+
     if rank == 0:
         flops = algorithmic_flops(stats, d) / world  # this rank's share of the query rows
-        achieved = flops * args.steps / (topk_ms * 1e-3) / 1e12 if topk_ms > 0 else 0.0
+        achieved = flops * args.steps / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        traffic, why = measured_traffic(args.workload, acc["kernel"]) if world == 1 else (None, "multi-GPU run")
+        sbytes = streaming_bytes(stats, d, k)
+        stream_s = acc["streaming_ms"] * 1e-3 / args.steps
         line = {
             "metric": "cells/sec corrected (reducedMNN engine, 50 PCs)",
             "value": n_cells * args.steps / elapsed,
@@ -228,21 +294,37 @@ def main():
                                    f"cells x {d} PCs, k={k}, "
                                    f"merge.order={'1..' + str(len(sizes)) if tree is None else 'balanced tree'}, "
                                    "inputs resident in HBM",
-                       "parallelism": "kNN query rows sharded over ranks, RCCL all-gather of neighbour lists"
+                       "parallelism": f"kNN query rows sharded over ranks, all-gather of neighbour lists: {exchange}"
                                       if world > 1 else "single GPU",
-                       "mnn_pairs": [m["P"] for m in stats], "exact_fallback_queries": fallbacks},
+                       "mnn_pairs": [m["P"] for m in stats], "exact_fallback_queries": acc["exact_fallbacks"],
+                       "second_tier_queries": acc["tier2_queries"]},
             "roofline": {
-                "bound": "mfma", "kernel": kern["kernel"], "achieved": achieved, "peak": kern["peak"],
+                "bound": "mfma", "kernel": acc["kernel"], "achieved": achieved, "peak": kern["peak"],
                 "unit": "TFLOP/s", "frac": achieved / kern["peak"],
-                "traffic": measured_traffic(args.workload, prof["variant"]) if world == 1 else None,
-                "launches_per_step": topk_launches / max(1, args.steps),
-                "avg_launch_ms": topk_ms / max(1, topk_launches),
+                "traffic": traffic, "traffic_note": why,
+                "launches_per_step": dom_launches / max(1, args.steps),
+                "avg_launch_ms": dom_ms / max(1, dom_launches),
                 "algorithmic_flops_per_step": flops,
+                "other_candidate_passes_ms_per_step": {"sample": acc["sample_ms"] / args.steps,
+                                                       "second_tier": (acc["bf16_ms"] if dom == "f16" else 0.0) / args.steps},
             },
+            # the HBM-bound rest of a merge (SURVEY.md 8d, K3-K6 + the apply half of K7): algorithmic bytes over the
+            # HIP-event time of the merges' streaming sections, against the 8 TB/s HBM peak
+            "streaming": {"bound": "hbm", "algorithmic_bytes_per_step": sbytes, "ms_per_step": 1e3 * stream_s,
+                          "achieved": sbytes / stream_s / 1e9 if stream_s > 0 else 0.0, "peak": 8000.0, "unit": "GB/s",
+                          "frac": sbytes / stream_s / 8e12 if stream_s > 0 else 0.0},
+            "per_rank": {"candidate_pass_ms_per_step": (dom_ms + acc["sample_ms"] + acc["bf16_ms" if dom == "f16" else "f16_ms"])
+                                                       / args.steps,
+                         "streaming_ms_per_step": 1e3 * stream_s,
+                         "exchange_calls_per_step": xst["calls"], "exchange_bytes_per_step": xst["bytes"]},
         }
+        if h2h is not None:
+            line["value_host_to_host"] = n_cells / h2h
+            line["host_to_host_ms"] = 1e3 * h2h
         if world == 1 and not args.no_cpu_baseline:
             try:
-                line["cpu_baseline"] = cpu_baseline(batches, stats, d, k)
+                line["cpu_baseline"], line["cpu_baseline_variants"] = cpu_baselines(batches, stats, d, k)
+                line["host_cores"] = os.cpu_count()
             except Exception as exc:  # the baseline must never take the GPU number down with it
                 line["cpu_baseline"] = {"value": None, "unit": "cells/s", "cores": os.cpu_count(), "kind": "port",
                                         "sample": f"failed: {exc}"}

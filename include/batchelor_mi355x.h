@@ -141,9 +141,17 @@ int32_t bmx_engine_profile(bmx_engine_t* e, double* topk_ms, int64_t* topk_launc
  * matrices to read the sizes first. */
 int32_t bmx_engine_set_snapshot(bmx_engine_t* e, int32_t merge);
 int32_t bmx_engine_snapshot(bmx_engine_t* e, double* left_rm, double* right_rm, int64_t* n_left, int64_t* n_right);
+/* Per kernel class (profiling on, since the last run started): out[0], out[1] = milliseconds and launches of the fp16
+ * full pass, out[2], out[3] of the split-bf16 full pass, out[4], out[5] of the sample passes, out[6] = milliseconds of
+ * the merges' streaming sections (everything that is not a kNN search), out[7] = queries that took the exact FP64
+ * path, out[8] = queries the first tier handed to the second. */
+int32_t bmx_engine_profile_detail(bmx_engine_t* e, double* out10);
+/* Name of the full-pass candidate kernel the engine launched last, as rocprofv3 prints it (template arguments
+ * included): lets a benchmark check that a stored counter measurement belongs to the kernel it has just timed. */
+int32_t bmx_engine_knn_kernel(bmx_engine_t* e, char* buf, int32_t n);
 /* Candidate-pass kernel used by the engine's last MFMA-path search: 2 = knn_topk_bf16 (split-bf16 MFMA, LDS ring),
- * 1 = knn_topk_w1 (f32 MFMA, wave per workgroup), 0 = knn_topk_mfma (f32 MFMA, LDS staging), -1 = none yet.
- * The environment variable BMX_TOPK_VARIANT selects it for A/B runs. */
+ * 3 = knn_topk_f16 (single fp16 product, LDS ring), -1 = none yet.  The environment variable BMX_KNN_TIER restricts the
+ * search to one tier for A/B runs. */
 int32_t bmx_engine_knn_variant(bmx_engine_t* e);
 
 /* One-shot convenience (what the R shim calls): create + upload + run + download + pairs stay queryable on *out_engine

@@ -435,3 +435,17 @@ def test_single_object_with_batch_factor(oracle):
     ref = oracle.reduced_mnn(*B)
     np.testing.assert_allclose(ref.corrected[shuffle], out.corrected, rtol=1e-9, atol=1e-12)  # expect_equal upstream
     assert np.array_equal(ref.batch[shuffle], out.batch)
+
+
+def test_cpu_baselines_are_exact(oracle):
+    """bench.py's two CPU baselines (oracle/cpu_baselines.py: KMKNN-style pruned search, BLAS brute force) give the
+    brute-force oracle's neighbours: what is timed there is the same exact search."""
+    from oracle import cpu_baselines as cb
+    X, Q = synth_batches(2, [3000, 200], 20)
+    oi, od = oracle.query_knn(X, Q, 12)
+    ia, da, st = cb.kmknn_knn(X, Q, 12)
+    assert np.array_equal(ia, oi) and np.array_equal(da, od)
+    assert 0.0 < st["visited"] <= 1.0
+    ib, db = cb.blas_knn(X, Q, 12)
+    assert np.array_equal(ib, oi)
+    np.testing.assert_allclose(db, od, rtol=1e-12)
