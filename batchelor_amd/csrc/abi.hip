@@ -401,7 +401,9 @@ int32_t bmx_adjust_shift_variance(const double* data1, int32_t g1, int32_t n1, c
         const int32_t* q1 = upload(dr1, restrict1, (size_t)nr1, s);
         const int32_t* q2 = upload(dr2, restrict2, (size_t)nr2, s);
         double* po = dO.reserve(n2);
-        double* pw = dW.reserve(std::max<size_t>(1, (size_t)std::min(n2, 1024) * 2 * nr1));
+        int asv_blocks = 1, asv_npad = 1, asv_exact = 1;
+        double* pw = dW.reserve(std::max<size_t>(1, bmx::adjust_shift_variance_scratch(n2, nr1, nr2, &asv_blocks, &asv_npad,
+                                                                                      &asv_exact)));
         bmx::adjust_shift_variance_device(s, p1, g, n1, p2, n2, pv, sigma2, q1, nr1, q2, nr2, po, pw);
         BMX_HIP(hipMemcpyAsync(out, po, (size_t)n2 * sizeof(double), hipMemcpyDeviceToHost, s));
         BMX_HIP(hipStreamSynchronize(s));

@@ -95,6 +95,8 @@ void cosnorm_project_device(hipStream_t stream, const double* x, int G, int n, c
 // ---- legacy natives (legacy.hip) -------------------------------------------------------------------
 void smooth_gaussian_kernel_device(hipStream_t stream, const double* averaged, int g, int U, const int32_t* index,
                                    const double* mat, int gd, int n, double sigma2, double* out, double* ws_density);
+// doubles of scratch adjust_shift_variance_device needs (and the launch shape it will use)
+size_t adjust_shift_variance_scratch(int n2, int nr1, int nr2, int* blocks, int* npad, int* exact);
 void adjust_shift_variance_device(hipStream_t stream, const double* data1, int g, int n1, const double* data2, int n2,
                                   const double* vect, double sigma2, const int32_t* restrict1, int nr1,
                                   const int32_t* restrict2, int nr2, double* out, double* ws_pairs);

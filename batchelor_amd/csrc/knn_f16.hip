@@ -260,14 +260,13 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
     }
     const int ntiles = (r_end - r_begin) >> 5;
     const int out_chunk = out_chunk0 + rng;
-    // Every workgroup sweeps its range once, but from a different starting tile (wrapping round): workgroups that are
-    // launched together then read different stretches of the reference image at any one time.  All of them reading
-    // the same 4 KB at the same moment serialises on the few L2 channels that hold it -- measured: with the starts
-    // aligned, the very same loop took 1.45x as long once nothing desynchronised the workgroups.
-#ifdef BMX_EXP_NOSTAGGER
-    const int t_off = 0;
-#else
+    // BMX_STAGGER (experiment, off): every workgroup starts its sweep at a different tile and wraps round.  Measured:
+    // no change in time, but 4x the L2 misses (the workgroups of an XCD no longer share the stretch they stream), so
+    // the sweeps stay aligned.
+#ifdef BMX_STAGGER
     const int t_off = ntiles > 0 ? (int)(((long long)(qblock & 255) * ntiles) >> 8) : 0;
+#else
+    const int t_off = 0;
 #endif
     if (tid < NSLOT * (1 + NCONS)) ready[tid] = 0;  // ready[] and done[] are contiguous
     if (tid < NQ) cnt[tid] = 0;

@@ -204,10 +204,15 @@ int orc_find_mutual_nns(const int32_t* left, int32_t nL, int32_t k2, const int32
     return ORC_OK;
 }
 
-/* R::logspace_add (Rmath): log(exp(lx) + exp(ly)) */
-static inline double logspace_add(double lx, double ly) {
-    return (lx > ly ? lx : ly) + log1p(exp(-fabs(lx - ly)));
-}
+/* R::logspace_add (Rmath): log(exp(lx) + exp(ly)) = max + log1p(exp(-|lx - ly|)).  Rmath calls the platform's exp and
+ * log1p; their last bit is not defined across math libraries, and adjust_shift_variance's quantile walk amplifies a
+ * last-bit difference into a different cell.  So the sum is taken with the bit-reproducible exp / log1p of
+ * portable_math.h (a few ulp from libm; tests/test_oracle_kat.py compares the two), which the HIP side repeats. */
+#include "portable_math.h"
+static inline double logspace_add(double lx, double ly) { return bmx_pm_logspace_add(lx, ly); }
+/* the same with the platform's libm, for the comparison test */
+double orc_logspace_add_libm(double lx, double ly) { return (lx > ly ? lx : ly) + log1p(exp(-fabs(lx - ly))); }
+double orc_logspace_add(double lx, double ly) { return bmx_pm_logspace_add(lx, ly); }
 
 /* ------------------------------------------------------------------------------------------------
  * smooth_gaussian_kernel -- follows src/smooth_gaussian_kernel.cpp:11-118.
