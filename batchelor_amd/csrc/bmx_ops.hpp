@@ -80,6 +80,11 @@ void average_correction(hipStream_t stream, const double* L, const int32_t* lrow
 void tricube_apply(hipStream_t stream, double* X, int n, int d, const double* averaged, const int32_t* idx,
                    const double* dist, int k, double ndist);
 
+// correction [n][d] = .compute_tricube_average alone (no add): the per-cell correction vectors var.adj rescales
+void tricube_vectors(hipStream_t stream, int n, int d, const double* averaged, const int32_t* idx, const double* dist,
+                     int k, double ndist, double* correction);
+// X[i] += pmax(scaling[i], 1) * correction[i]   (R/mnnCorrect.R:479-480, :345)
+void add_scaled_rows(hipStream_t stream, double* X, int n, int d, const double* correction, const double* scaling);
 // layout helpers
 void transpose_cm_to_rm(hipStream_t stream, const double* cm, int n, int d, double* rm);  // [n x d] col-major -> row-major
 void transpose_rm_to_cm(hipStream_t stream, const double* rm, int n, int d, double* cm, int ld_cm, int row_off);
@@ -99,6 +104,7 @@ void smooth_gaussian_kernel_device(hipStream_t stream, const double* averaged, i
 size_t adjust_shift_variance_scratch(int n2, int nr1, int nr2, int* blocks, int* npad, int* exact);
 void adjust_shift_variance_device(hipStream_t stream, const double* data1, int g, int n1, const double* data2, int n2,
                                   const double* vect, double sigma2, const int32_t* restrict1, int nr1,
-                                  const int32_t* restrict2, int nr2, double* out, double* ws_pairs);
+                                  const int32_t* restrict2, int nr2, double* out, double* ws_pairs,
+                                  int vect_row_major = 0);
 
 }  // namespace bmx

@@ -97,6 +97,7 @@ __global__ __launch_bounds__(256) void average_correction_kernel(
 }
 
 // one wave per row: tricube weights from the k ascending distances, then the weighted sum of correction vectors
+template <bool IN_PLACE>
 __global__ __launch_bounds__(256) void tricube_apply_kernel(double* __restrict__ X, int n, int d,
                                                             const double* __restrict__ averaged,
                                                             const int32_t* __restrict__ idx,
@@ -125,8 +126,17 @@ __global__ __launch_bounds__(256) void tricube_apply_kernel(double* __restrict__
             const double w = (t * t * t) / total;
             acc = acc + averaged[(int64_t)ii[j] * d + c] * w;
         }
-        X[(int64_t)i * d + c] = X[(int64_t)i * d + c] + acc;
+        X[(int64_t)i * d + c] = IN_PLACE ? X[(int64_t)i * d + c] + acc : acc;
     }
+}
+
+__global__ void add_scaled_rows_kernel(double* __restrict__ X, int64_t total, int d, const double* __restrict__ corr,
+                                       const double* __restrict__ scaling) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    double s = scaling[e / d];
+    s = s < 1.0 ? 1.0 : s;  // pmax(scaling, 1): a NaN stays a NaN
+    X[e] = X[e] + s * corr[e];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -378,8 +388,28 @@ void average_correction(hipStream_t stream, const double* L, const int32_t* lrow
 void tricube_apply(hipStream_t stream, double* X, int n, int d, const double* averaged, const int32_t* idx,
                    const double* dist, int k, double ndist) {
     if (n <= 0 || k <= 0) return;  // k == 0: the weighted correction is all zeros (R/utils_tricube.R:22-23)
-    hipLaunchKernelGGL(tricube_apply_kernel, dim3(cdiv(n, 4)), dim3(256), 0, stream, X, n, d, averaged, idx, dist, k,
+    hipLaunchKernelGGL(tricube_apply_kernel<true>, dim3(cdiv(n, 4)), dim3(256), 0, stream, X, n, d, averaged, idx, dist, k,
                        ndist);
+    BMX_LAUNCH_CHECK();
+}
+
+void tricube_vectors(hipStream_t stream, int n, int d, const double* averaged, const int32_t* idx, const double* dist,
+                     int k, double ndist, double* correction) {
+    if (n <= 0) return;
+    if (k <= 0) {
+        BMX_HIP(hipMemsetAsync(correction, 0, (size_t)n * d * sizeof(double), stream));
+        return;
+    }
+    hipLaunchKernelGGL(tricube_apply_kernel<false>, dim3(cdiv(n, 4)), dim3(256), 0, stream, correction, n, d, averaged, idx,
+                       dist, k, ndist);
+    BMX_LAUNCH_CHECK();
+}
+
+void add_scaled_rows(hipStream_t stream, double* X, int n, int d, const double* correction, const double* scaling) {
+    const int64_t total = (int64_t)n * d;
+    if (total <= 0) return;
+    hipLaunchKernelGGL(add_scaled_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, X, total, d,
+                       correction, scaling);
     BMX_LAUNCH_CHECK();
 }
 

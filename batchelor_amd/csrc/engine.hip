@@ -462,7 +462,34 @@ void Engine::merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p,
         sec.reset();
         knn(right.data.p, srows, mo.U, right.data.p, nullptr, right.n, safe_k, idxT, distT);
         sec = std::make_unique<Section>(this);  // streaming section 3: tricube apply, rbind
-        tricube_apply(stream_, right.data.p, right.n, d_, averaged, idxT, distT, safe_k, p.ndist);
+        if (!p.var_adj) {
+            tricube_apply(stream_, right.data.p, right.n, d_, averaged, idxT, distT, safe_k, p.ndist);
+        } else {
+            // mnnCorrect(var.adj=TRUE) on the fastMNN correction (R/mnnCorrect.R:331-342,462-481): every right cell's
+            // correction vector is stretched so that the cell lands on the matching quantile of the left batch
+            double* corr = corr_.reserve((size_t)right.n * d_);
+            tricube_vectors(stream_, right.n, d_, averaged, idxT, distT, safe_k, p.ndist, corr);
+            const int32_t* r1 = lrows;
+            const int32_t* r2 = rrows;
+            if (!r1) {
+                int32_t* io = iota_l_.reserve(left.n);
+                hipLaunchKernelGGL(iota_offset, dim3(cdiv(left.n, 256)), dim3(256), 0, stream_, io, left.n, 0);
+                r1 = io;
+            }
+            if (!r2) {
+                int32_t* io = iota_r_.reserve(right.n);
+                hipLaunchKernelGGL(iota_offset, dim3(cdiv(right.n, 256)), dim3(256), 0, stream_, io, right.n, 0);
+                r2 = io;
+            }
+            BMX_LAUNCH_CHECK();
+            int blocks = 1, npad = 1, exact = 1;
+            double* ws = asv_ws_.reserve(std::max<size_t>(1, adjust_shift_variance_scratch(right.n, nLs, nRs, &blocks, &npad,
+                                                                                           &exact)));
+            double* scaling = asv_scale_.reserve(right.n);
+            adjust_shift_variance_device(stream_, left.data.p, d_, left.n, right.data.p, right.n, corr, p.sigma, r1, nLs, r2,
+                                         nRs, scaling, ws, /* vect_row_major */ 1);
+            add_scaled_rows(stream_, right.data.p, right.n, d_, corr, scaling);
+        }
         right.stat_slot.assign(right.origin.size(), -1);  // the corrected cells moved
         ++n_extras_;
     } else {
@@ -805,13 +832,16 @@ void Engine::profile_detail(double* out10) {
 
 void Engine::profile(double* topk_ms, int64_t* launches, int64_t* fallbacks) {
     double ms = 0.0;
+    int64_t n = 0;
     for (size_t i = 0; i < knn_ws_.events_used; ++i) {
+        if (knn_ws_.event_tag[i] == 3) continue;  // a streaming section, not a candidate-pass launch
         float t = 0.f;
         BMX_HIP(hipEventElapsedTime(&t, knn_ws_.events[i].first, knn_ws_.events[i].second));
         ms += t;
+        ++n;
     }
     if (topk_ms) *topk_ms = ms;
-    if (launches) *launches = (int64_t)knn_ws_.events_used;
+    if (launches) *launches = n;
     if (fallbacks) *fallbacks = fallbacks_;
 }
 

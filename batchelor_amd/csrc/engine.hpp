@@ -103,6 +103,8 @@ class Engine {
     DevBuf<unsigned long long> maskL_;
     DevBuf<double> distT_, distRL_, averaged_, loc_, vecs_, scal_, means_pool_;
     DevBuf<float> seedL_;
+    DevBuf<double> corr_, asv_ws_, asv_scale_;
+    DevBuf<int32_t> iota_l_, iota_r_;
     int n_slots_ = 0, slot_cap_ = 0;
 
   private:

@@ -142,8 +142,8 @@ __device__ __forceinline__ double orderable_f64(unsigned long long o) {
 
 __global__ __launch_bounds__(T) void asv_kernel(const double* __restrict__ data1, int g, int n1,
                                                 const double* __restrict__ data2, int n2,
-                                                const double* __restrict__ vect, double sigma2,
-                                                const int32_t* __restrict__ r1, int nr1,
+                                                const double* __restrict__ vect, int64_t vs_cell, int64_t vs_x,
+                                                double sigma2, const int32_t* __restrict__ r1, int nr1,
                                                 const int32_t* __restrict__ r2, int nr2, double* __restrict__ out,
                                                 double* __restrict__ scratch) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(T) void asv_kernel(const double* __restrict__ data1
     for (int cell = blockIdx.x; cell < n2; cell += gridDim.x) {
         // unit gradient and own projection (adjust_shift_variance.cpp:57-70)
         for (int x = tid; x < g; x += T) {
-            grad[x] = vect[(int64_t)x * n2 + cell];
+            grad[x] = vect[(int64_t)x * vs_x + (int64_t)cell * vs_cell];
             cur[x] = data2[(int64_t)cell * g + x];
         }
         __syncthreads();
@@ -287,8 +287,8 @@ __device__ __forceinline__ bool pair_less(double p0, double w0, double p1, doubl
 }
 
 __global__ __launch_bounds__(T) void asv_exact_kernel(const double* __restrict__ data1, int g, const double* __restrict__ data2,
-                                                      int n2, const double* __restrict__ vect, double sigma2,
-                                                      const int32_t* __restrict__ r1, int nr1,
+                                                      int n2, const double* __restrict__ vect, int64_t vs_cell,
+                                                      int64_t vs_x, double sigma2, const int32_t* __restrict__ r1, int nr1,
                                                       const int32_t* __restrict__ r2, int nr2, int npad,
                                                       double* __restrict__ out, double* __restrict__ scratch) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(T) void asv_exact_kernel(const double* __restrict__
 
     for (int cell = blockIdx.x; cell < n2; cell += gridDim.x) {
         for (int x = tid; x < g; x += T) {
-            grad[x] = vect[(int64_t)x * n2 + cell];
+            grad[x] = vect[(int64_t)x * vs_x + (int64_t)cell * vs_cell];
             cur[x] = data2[(int64_t)cell * g + x];
         }
         __syncthreads();
@@ -441,16 +441,18 @@ size_t adjust_shift_variance_scratch(int n2, int nr1, int nr2, int* blocks, int*
 
 void adjust_shift_variance_device(hipStream_t stream, const double* data1, int g, int n1, const double* data2, int n2,
                                   const double* vect, double sigma2, const int32_t* restrict1, int nr1,
-                                  const int32_t* restrict2, int nr2, double* out, double* ws_pairs) {
+                                  const int32_t* restrict2, int nr2, double* out, double* ws_pairs, int vect_row_major) {
+    // vect is an R matrix [n2 x g] (column-major) at the .Call boundary, row-major [n2][g] inside the engine
+    const int64_t vs_cell = vect_row_major ? g : 1, vs_x = vect_row_major ? 1 : n2;
     if (n2 <= 0) return;
     int blocks = 1, npad = 1, exact = 1;
     (void)adjust_shift_variance_scratch(n2, nr1, nr2, &blocks, &npad, &exact);
     if (exact)
         hipLaunchKernelGGL(asv_exact_kernel, dim3(blocks), dim3(T), (size_t)2 * g * sizeof(double), stream, data1, g, data2,
-                           n2, vect, sigma2, restrict1, nr1, restrict2, nr2, npad, out, ws_pairs);
+                           n2, vect, vs_cell, vs_x, sigma2, restrict1, nr1, restrict2, nr2, npad, out, ws_pairs);
     else
         hipLaunchKernelGGL(asv_kernel, dim3(blocks), dim3(T), (size_t)2 * g * sizeof(double), stream, data1, g, n1, data2,
-                           n2, vect, sigma2, restrict1, nr1, restrict2, nr2, out, ws_pairs);
+                           n2, vect, vs_cell, vs_x, sigma2, restrict1, nr1, restrict2, nr2, out, ws_pairs);
     BMX_LAUNCH_CHECK();
 }
 

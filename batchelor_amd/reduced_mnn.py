@@ -20,7 +20,8 @@ from .merge_tree import encode_postorder, resolve_merge_order
 
 class BmxParams(ctypes.Structure):
     _fields_ = [("k", ctypes.c_int32), ("prop_k", ctypes.c_double), ("ndist", ctypes.c_double),
-                ("min_batch_skip", ctypes.c_double), ("auto_merge", ctypes.c_int32)]
+                ("min_batch_skip", ctypes.c_double), ("auto_merge", ctypes.c_int32), ("var_adj", ctypes.c_int32),
+                ("sigma", ctypes.c_double)]
 
 
 ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64)
@@ -114,9 +115,11 @@ class MnnEngine:
         self._keep = (mats, rlist)
         self.nbatches, self.nrows, self.d = B, nrows.tolist(), d
 
-    def run(self, k=20, prop_k=None, ndist=3.0, min_batch_skip=0.0, merge_tree=None, auto_merge=False):
+    def run(self, k=20, prop_k=None, ndist=3.0, min_batch_skip=0.0, merge_tree=None, auto_merge=False, var_adj=False,
+            sigma=0.1):
         p = BmxParams(int(k), float("nan") if prop_k is None else float(prop_k), float(ndist),
-                      float("nan") if min_batch_skip is None else float(min_batch_skip), 1 if auto_merge else 0)
+                      float("nan") if min_batch_skip is None else float(min_batch_skip), 1 if auto_merge else 0,
+                      1 if var_adj else 0, float(sigma))
         code = encode_postorder(merge_tree if merge_tree is not None
                                 else resolve_merge_order(self.nbatches))
         rc = _lib.lib().bmx_engine_run(self._h, ctypes.byref(p), _lib.i32p(code), int(code.size))
@@ -194,7 +197,8 @@ class MnnEngine:
                          stats=self.merge_stats())
 
 
-def _fast_mnn(batches, k, prop_k, restrict, ndist, merge_order, auto_merge, min_batch_skip, names, device=0):
+def _fast_mnn(batches, k, prop_k, restrict, ndist, merge_order, auto_merge, min_batch_skip, names, device=0,
+              var_adj=False, sigma=0.1):
     """.fast_mnn (R/fastMNN.R:398-429)."""
     if names is not None and len(set(names)) != len(names):
         raise ValueError("names of batches should be unique")  # R/fastMNN.R:422
@@ -203,7 +207,7 @@ def _fast_mnn(batches, k, prop_k, restrict, ndist, merge_order, auto_merge, min_
         eng.upload(batches, restrict)
         tree = None if auto_merge else resolve_merge_order(len(batches), merge_order, names)
         eng.run(k=k, prop_k=prop_k, ndist=ndist, min_batch_skip=min_batch_skip, merge_tree=tree,
-                auto_merge=auto_merge)
+                auto_merge=auto_merge, var_adj=var_adj, sigma=sigma)
         out = eng.download()
     finally:
         eng.close()
@@ -256,7 +260,7 @@ def _reindex_pairings(pairings, new_order):
 
 
 def reducedMNN(*batches, batch=None, k=20, prop_k=None, restrict=None, ndist=3, merge_order=None, auto_merge=False,
-               min_batch_skip=0.0, names=None, device=0) -> MnnResult:
+               min_batch_skip=0.0, names=None, device=0, var_adj=False, sigma=0.1) -> MnnResult:
     """reducedMNN(..., batch=, k=, prop.k=, restrict=, ndist=, merge.order=, auto.merge=, min.batch.skip=)
     (R/reducedMNN.R:61-95).  `names` plays the role of the argument names of `...`."""
     if len(batches) == 1 and isinstance(batches[0], (list, tuple)):
@@ -274,11 +278,11 @@ def reducedMNN(*batches, batch=None, k=20, prop_k=None, restrict=None, ndist=3, 
             raise ValueError("'batch' must be specified if '...' has only one object")  # R/checkInputs.R:128
         div = divideIntoBatches(batches[0], batch, None if restrict is None else restrict[0])
         out = _fast_mnn(div["batches"], k, prop_k, div["restricted"], ndist, merge_order, auto_merge, min_batch_skip,
-                        [str(l) for l in div["levels"]], device)
+                        [str(l) for l in div["levels"]], device, var_adj, sigma)
         reo = div["reorder"]
         out.corrected = out.corrected[reo - 1]
         out.batch = out.batch[reo - 1]
         out.merge_info.pairs = _reindex_pairings(out.merge_info.pairs, reo)
         return out
     return _fast_mnn([np.asarray(b, dtype=np.float64) for b in batches], k, prop_k, restrict, ndist, merge_order,
-                     auto_merge, min_batch_skip, names, device)
+                     auto_merge, min_batch_skip, names, device, var_adj, sigma)

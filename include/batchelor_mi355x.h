@@ -91,6 +91,10 @@ typedef struct {
     double ndist;          /* ndist = 3 */
     double min_batch_skip; /* NaN = NA_real_: batch.size not computed, nothing skipped (R/fastMNN.R:484) */
     int32_t auto_merge;    /* non-zero: R/MNN_tree.R:154-226 instead of the predefined tree */
+    int32_t var_adj;       /* non-zero: rescale every cell's correction vector as mnnCorrect(var.adj=TRUE) does --
+                              pmax(adjust_shift_variance(left, right, correction, sigma), 1) * correction
+                              (R/mnnCorrect.R:331-342,462-481).  fastMNN() has no such switch: 0 is its behaviour */
+    double sigma;          /* bandwidth handed to adjust_shift_variance as `sigma2` (R/mnnCorrect.R:477), 0.1 */
 } bmx_params_t;
 
 /* Multi-GPU exchange: called by the engine when `buf` (a DEVICE buffer of world * bytes_per_rank bytes whose slice

@@ -226,12 +226,23 @@ def compute_tricube_average(vals, indices, distances, bandwidth=None, ndist=3):
     return out
 
 
-def tricube_weighted_correction(curdata, correction, in_mnn, k=20, ndist=3, nthreads=0):
-    """R/fastMNN.R:599-608."""
+def tricube_weighted_correction(curdata, correction, in_mnn, k=20, ndist=3, nthreads=0, var_adj=None):
+    """R/fastMNN.R:599-608.  var_adj = (refdata, sigma, restrict1, restrict2) additionally rescales every cell's
+    correction vector as mnnCorrect(var.adj=TRUE) does (R/mnnCorrect.R:331-342, .adjust_shift_variance :462-481:
+    pmax(scaling, 1) * correction) -- BASELINE.json configs[4]; fastMNN() itself has no such switch."""
     cur_uniq = curdata[np.asarray(in_mnn) - 1]
     safe_k = min(k, cur_uniq.shape[0])
     idx, dist = query_knn(cur_uniq, curdata, safe_k, nthreads)
-    return curdata + compute_tricube_average(correction, idx, dist, ndist=ndist)
+    corr = compute_tricube_average(correction, idx, dist, ndist=ndist)
+    if var_adj is not None:
+        refdata, sigma, r1, r2 = var_adj
+        r1 = np.arange(refdata.shape[0]) if r1 is None else np.asarray(r1) - 1
+        r2 = np.arange(curdata.shape[0]) if r2 is None else np.asarray(r2) - 1
+        scaling = adjust_shift_variance(refdata.T, curdata.T, corr, sigma, r1, r2)
+        with np.errstate(invalid="ignore"):
+            scaling = np.where(scaling < 1, 1.0, scaling)  # pmax(scaling, 1): NaN stays NaN
+        corr = scaling[:, None] * corr
+    return curdata + corr
 
 
 def combine_restrict(left_data, left_restrict, right_data, right_restrict):
@@ -457,7 +468,7 @@ class FastMnnResult:
 
 
 def fast_mnn(batches: Sequence[np.ndarray], k=20, prop_k=None, restrict=None, ndist=3, merge_order=None,
-             auto_merge=False, min_batch_skip=0.0, names=None, nthreads=0) -> FastMnnResult:
+             auto_merge=False, min_batch_skip=0.0, names=None, nthreads=0, var_adj=False, sigma=0.1) -> FastMnnResult:
     """R/fastMNN.R:398-562 (.fast_mnn + .fast_mnn_core).  `min_batch_skip=None` is R's NA."""
     batches = [np.ascontiguousarray(b, dtype=np.float64) for b in batches]
     nbatches = len(batches)
@@ -516,7 +527,9 @@ def fast_mnn(batches: Sequence[np.ndarray], k=20, prop_k=None, restrict=None, nd
             re_avg, re_second = average_correction(left_data, first, right_data, second)  # :505-507
             right_data = tricube_weighted_correction(right_data, re_avg, re_second,
                                                      k=choose_k(k, prop_k, right_data.shape[0]), ndist=ndist,
-                                                     nthreads=nthreads)
+                                                     nthreads=nthreads,
+                                                     var_adj=(left_data, sigma, left.restrict, right.restrict)
+                                                     if var_adj else None)
         else:
             to_add = []
             left_new = compute_perbatch_var(left_data, left.index, left.origin)
@@ -587,17 +600,18 @@ def divide_into_batches(x, batch, restrict=None):
 
 
 def reduced_mnn(*batches, batch=None, k=20, prop_k=None, restrict=None, ndist=3, merge_order=None, auto_merge=False,
-                min_batch_skip=0.0, names=None, nthreads=0) -> FastMnnResult:
+                min_batch_skip=0.0, names=None, nthreads=0, var_adj=False, sigma=0.1) -> FastMnnResult:
     """R/reducedMNN.R:61-95."""
     if len(batches) == 1:
         r0 = None if restrict is None else restrict[0]
         divided, levels, reorder, restricted = divide_into_batches(np.asarray(batches[0], dtype=np.float64), batch, r0)
         out = fast_mnn(divided, k=k, prop_k=prop_k, restrict=restricted, ndist=ndist, merge_order=merge_order,
-                       auto_merge=auto_merge, min_batch_skip=min_batch_skip, names=[str(l) for l in levels],
+                       auto_merge=auto_merge, min_batch_skip=min_batch_skip, names=[str(l) for l in levels], var_adj=var_adj, sigma=sigma,
                        nthreads=nthreads)
         out.corrected = out.corrected[reorder - 1]
         out.batch = out.batch[reorder - 1]
         out.merge_info.pairs = reindex_pairings(out.merge_info.pairs, reorder)
         return out
     return fast_mnn(list(batches), k=k, prop_k=prop_k, restrict=restrict, ndist=ndist, merge_order=merge_order,
-                    auto_merge=auto_merge, min_batch_skip=min_batch_skip, names=names, nthreads=nthreads)
+                    auto_merge=auto_merge, min_batch_skip=min_batch_skip, names=names, nthreads=nthreads,
+                    var_adj=var_adj, sigma=sigma)
