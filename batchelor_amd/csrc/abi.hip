@@ -450,6 +450,36 @@ int32_t bmx_cosnorm_project(const double* x, int32_t G, int32_t n, const double*
     });
 }
 
+/* ---------------------------------------------------------------- device PCA ------------------------------------ */
+struct bmx_pca {
+    bmx::Pca* impl = nullptr;
+    ~bmx_pca() { bmx::pca_destroy(impl); }
+};
+
+int32_t bmx_pca_create(int32_t device, int32_t G, bmx_pca_t** out) {
+    return guarded([&] {
+        if (!out) throw bmx::Error(BMX_ERR_ARG, "null output pointer");
+        if (G < 1) throw bmx::Error(BMX_ERR_ARG, "the PCA needs at least one gene");
+        auto h = std::make_unique<bmx_pca>();
+        h->impl = bmx::pca_create(device, G);
+        *out = h.release();
+    });
+}
+
+void bmx_pca_destroy(bmx_pca_t* p) { delete p; }
+
+int32_t bmx_pca_add_batch(bmx_pca_t* p, const double* x, int64_t n, double weight, int32_t cos_norm) {
+    return guarded([&] { bmx::pca_add_batch(p->impl, x, n, weight, cos_norm); });
+}
+
+int32_t bmx_pca_fit(bmx_pca_t* p, int32_t d, int32_t iters, double* centers, double* rotation, double* sdev) {
+    return guarded([&] { bmx::pca_fit(p->impl, d, iters, centers, rotation, sdev); });
+}
+
+int32_t bmx_pca_project(bmx_pca_t* p, int32_t batch, double* out) {
+    return guarded([&] { bmx::pca_project(p->impl, batch, out); });
+}
+
 /* ---------------------------------------------------------------- engine ---------------------------------------- */
 
 int32_t bmx_engine_create(int32_t device, bmx_engine_t** out) {

@@ -97,6 +97,14 @@ void apply_cosine_norm_device(hipStream_t stream, const double* x, int G, int n,
 void cosnorm_project_device(hipStream_t stream, const double* x, int G, int n, const double* u, int d,
                             const double* centers, int cos_norm, double* out, double* l2_out, double* cu_scratch);
 
+// ---- multiBatchPCA on the device (pca.hip) -----------------------------------------------------------------------
+class Pca;
+Pca* pca_create(int device, int G);
+void pca_destroy(Pca* p);
+void pca_add_batch(Pca* p, const double* x_host, int64_t n, double weight, int cos_norm);
+void pca_fit(Pca* p, int d, int iters, double* centers, double* rotation, double* sdev);
+void pca_project(Pca* p, int batch, double* out_host);
+
 // ---- legacy natives (legacy.hip) -------------------------------------------------------------------
 void smooth_gaussian_kernel_device(hipStream_t stream, const double* averaged, int g, int U, const int32_t* index,
                                    const double* mat, int gd, int n, double sigma2, double* out, double* ws_density);

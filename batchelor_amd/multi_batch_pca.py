@@ -1,5 +1,5 @@
-"""Host-side multiBatchPCA (BASELINE.json north_star: "multiBatchPCA stays on the reference CPU path") and the
-device cosineNorm / projection steps on either side of it.
+"""multiBatchPCA on the device (default) or on the host (BASELINE.json north_star: "multiBatchPCA stays on the
+reference CPU path"; kept as `multiBatchPCA_host`), and the device cosineNorm / projection steps on either side of it.
 
 multiBatchPCA follows R/multiBatchPCA.R:211-322: grand mean of the batch means (weighted), each centred batch scaled
 by 1/sqrt(n_b / w_b), left singular vectors u of the scaled genes x cells matrix, projection of the UNSCALED centred
@@ -63,7 +63,81 @@ def _weight_vector(ncells, weights):
     return w
 
 
-def multiBatchPCA(*batches, d=50, weights=None, l2=None, block=65536):
+class DevicePCA:
+    """bmx_pca_t: the batches (genes x cells) stay in HBM; fit() = multiBatchPCA (R/multiBatchPCA.R:211-322) by blocked
+    subspace iteration on the FP64 matrix cores; project(b) = crossprod(cosineNorm(x_b) - centers, rotation)."""
+
+    def __init__(self, n_genes, device=0):
+        _lib.require_gpu()
+        self._h = ctypes.c_void_p()
+        lib = _lib.lib()
+        lib.bmx_pca_destroy.argtypes = [ctypes.c_void_p]
+        lib.bmx_pca_destroy.restype = None
+        _lib.check(lib.bmx_pca_create(int(device), int(n_genes), ctypes.byref(self._h)))
+        self.G = int(n_genes)
+        self.ncells = []
+        self.d = 0
+
+    def add_batch(self, x, weight=1.0, cos_norm=False):
+        x = _lib.as_f(x)
+        if x.ndim != 2 or x.shape[0] != self.G:
+            raise ValueError("number of rows is not the same across batches")
+        _lib.check(_lib.lib().bmx_pca_add_batch(self._h, _lib.f64p(x), ctypes.c_int64(x.shape[1]),
+                                                ctypes.c_double(float(weight)), 1 if cos_norm else 0))
+        self.ncells.append(int(x.shape[1]))
+
+    def fit(self, d=50, iters=15):
+        centers = np.zeros(self.G)
+        rotation = np.zeros((self.G, d), order="F")
+        sdev = np.zeros(d)
+        _lib.check(_lib.lib().bmx_pca_fit(self._h, int(d), int(iters), _lib.f64p(centers), _lib.f64p(rotation),
+                                          _lib.f64p(sdev)))
+        self.d = int(d)
+        return {"rotation": np.ascontiguousarray(rotation), "centers": centers, "d": sdev}
+
+    def project(self, b):
+        out = np.zeros((self.ncells[b], self.d), order="F")
+        _lib.check(_lib.lib().bmx_pca_project(self._h, int(b), _lib.f64p(out)))
+        return np.ascontiguousarray(out)
+
+    def close(self):
+        if self._h:
+            _lib.lib().bmx_pca_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def multiBatchPCA(*batches, d=50, weights=None, cos_norm=False, iters=15, device=0, return_pcs=True):
+    """multiBatchPCA(..., d=, weights=) on the device (R/multiBatchPCA.R:140-258).  Batches are genes x cells; with
+    cos_norm the cosine normalisation of fastMNN (R/fastMNN.R:348-351) is applied on the fly.
+    Returns {"rotation", "centers", "d", "weights"} plus "pcs": the list of cells x d projections."""
+    if len(batches) == 1 and isinstance(batches[0], (list, tuple)):
+        batches = tuple(batches[0])
+    if len(batches) == 0:
+        raise ValueError("at least one batch must be specified")
+    G = np.asarray(batches[0]).shape[0]
+    if any(np.asarray(m).ndim != 2 or np.asarray(m).shape[0] != G for m in batches):
+        raise ValueError("number of rows is not the same across batches")
+    w = _weight_vector([np.asarray(m).shape[1] for m in batches], weights)
+    pca = DevicePCA(G, device)
+    try:
+        for m, wi in zip(batches, w):
+            pca.add_batch(m, weight=wi, cos_norm=cos_norm)
+        out = pca.fit(d=d, iters=iters)
+        out["weights"] = w
+        if return_pcs:
+            out["pcs"] = [pca.project(b) for b in range(len(batches))]
+    finally:
+        pca.close()
+    return out
+
+
+def multiBatchPCA_host(*batches, d=50, weights=None, l2=None, block=65536):
     """Host PCA across batches (genes x cells each).  `l2` (optional list of per-cell norms) applies the cosine
     normalisation on the fly, so the normalised matrices are never materialised.
 

@@ -197,6 +197,25 @@ int32_t bmx_cosine_norm(const double* x, int32_t G, int32_t n, double* l2, doubl
 int32_t bmx_cosnorm_project(const double* x, int32_t G, int32_t n, const double* rotation, int32_t d,
                             const double* centers, int32_t cos_norm, double* out);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * multiBatchPCA on the device (R/multiBatchPCA.R:211-322; called from fastMNN() at R/fastMNN.R:353-354).  The batches
+ * (genes x cells, column-major, as the reference has them) are uploaded once and stay in HBM; neither the scaled
+ * genes x N matrix nor the genes x genes Gram matrix is formed: the top subspace is found by blocked subspace
+ * iteration on the FP64 matrix cores with the centring and the cosine normalisation folded in.
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct bmx_pca bmx_pca_t;
+int32_t bmx_pca_create(int32_t device, int32_t n_genes, bmx_pca_t** out);
+void bmx_pca_destroy(bmx_pca_t* p);
+/* x: n_genes x n column-major (host).  weight: the batch's weight w_b (1 = R's default: every batch counts the same
+ * whatever its size, R/multiBatchPCA.R:299-334).  cos_norm != 0: cosineNorm(x) (R/cosineNorm.R:63-82) on the fly. */
+int32_t bmx_pca_add_batch(bmx_pca_t* p, const double* x, int64_t n, double weight, int32_t cos_norm);
+/* d <= 56 components; iters: subspace iterations (15 is plenty for data with a spectral gap).  centers [n_genes],
+ * rotation [n_genes x d] column-major (columns defined up to sign, as any SVD's), sdev [d] singular values of the
+ * scaled matrix; any may be NULL. */
+int32_t bmx_pca_fit(bmx_pca_t* p, int32_t d, int32_t iters, double* centers, double* rotation, double* sdev);
+/* crossprod(cosineNorm(x_b) - centers, rotation) (R/multiBatchPCA.R:236-239): out [n_b x d] column-major. */
+int32_t bmx_pca_project(bmx_pca_t* p, int32_t batch, double* out);
+
 #ifdef __cplusplus
 }
 #endif
