@@ -366,7 +366,7 @@ int32_t bmx_smooth_gaussian_kernel(const double* averaged, int32_t g, int32_t U,
         const double* pm = upload(dM, mat, (size_t)gd * n, s);
         const int32_t* pi = upload(dI, index, (size_t)U, s);
         double* po = dO.reserve((size_t)g * n);
-        double* pd = dD.reserve(std::max(1, U));
+        double* pd = dD.reserve((size_t)n + (size_t)std::max(1, U));  // squared norms + densities
         bmx::smooth_gaussian_kernel_device(s, pa, g, U, pi, pm, gd, n, sigma2, po, pd);
         BMX_HIP(hipMemcpyAsync(out, po, (size_t)g * n * sizeof(double), hipMemcpyDeviceToHost, s));
         BMX_HIP(hipStreamSynchronize(s));

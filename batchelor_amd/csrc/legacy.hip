@@ -50,82 +50,177 @@ __device__ __forceinline__ double block_sum(double v, double* sm) {
     return r;
 }
 
-// density[i] = log sum_j exp(-|x_idx[i] - x_idx[j]|^2 / sigma2)     (smooth_gaussian_kernel.cpp:56-65)
-__global__ __launch_bounds__(T) void sgk_density(const double* __restrict__ mat, int gd, const int32_t* __restrict__ index,
-                                                 int U, double sigma2, double* __restrict__ density) {
-    __shared__ double sm[T];
-    const int i = blockIdx.x;
-    const double* ci = mat + (int64_t)index[i] * gd;
-    double mx = -__builtin_inf();
-    for (int j = threadIdx.x; j < U; j += T) {
-        const double* cj = mat + (int64_t)index[j] * gd;
-        double s = 0.0;
-        for (int x = 0; x < gd; ++x) {
-            const double t = ci[x] - cj[x];
-            s += t * t;
-        }
-        mx = fmax(mx, s / -sigma2);
-    }
-    mx = block_max(mx, sm);
-    double acc = 0.0;
-    for (int j = threadIdx.x; j < U; j += T) {
-        const double* cj = mat + (int64_t)index[j] * gd;
-        double s = 0.0;
-        for (int x = 0; x < gd; ++x) {
-            const double t = ci[x] - cj[x];
-            s += t * t;
-        }
-        acc += exp(s / -sigma2 - mx);
-    }
-    acc = block_sum(acc, sm);
-    if (threadIdx.x == 0) density[i] = mx + log(acc);
+// ---------------------------------------------------------------------------------------------------
+// smooth_gaussian_kernel (src/smooth_gaussian_kernel.cpp:11-118) as ONE streaming kernel per output tile, in the
+// manner of a flash-attention forward pass:
+//     out[:, c] = sum_i averaged[:, i] p_ic / sum_i p_ic,   p_ic = exp(-|m_i - x_c|^2 / sigma2 - density_i)
+// with m_i = mat[:, index_i] the MNN-involved cells.  A workgroup owns 64 cells x 128 genes of `out`, walks the MNN
+// cells in tiles of 64 and keeps a running maximum / sum per cell (online softmax), so every (MNN cell, cell)
+// distance is formed once per gene tile and no weight ever touches memory.
+// Both products run on the FP64 matrix cores (v_mfma_f64_16x16x4_f64):
+//   scores  S[i][c] = m_i . x_c over the distance genes (A = MNN tile, B = cell tile; |m|^2 + |x|^2 - 2 S after);
+//   output  out[c][g] += P[c][i] averaged[i][g] -- the score accumulator IS this product's A operand: register reg of
+//           row tile t at lane l holds i = 16 t + 4 reg + (l >> 4), exactly k-step 4 t + reg's element (l >> 4), and its
+//           column c = l & 15 is the row the A operand wants, so P goes from the first product into the second without
+//           leaving the registers.
+// density_i = log sum_j exp(-|m_i - m_j|^2 / sigma2) is the same kernel without the second product (its log-sum-exp
+// per "cell" over the MNN cells, the cells being the MNN cells themselves).
+// ---------------------------------------------------------------------------------------------------
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+__global__ void fill_nan(double* __restrict__ p, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = __builtin_nan("");
 }
 
-// out[:, c] = sum_i averaged[:, i] * softmax_i(logw_i[c] - density_i)      (smooth_gaussian_kernel.cpp:70-115)
-// grid (cells, gene blocks of T): every gene block re-derives the weights of its cell
-constexpr int SGK_CHUNK = 1024;
-__global__ __launch_bounds__(T) void sgk_apply(const double* __restrict__ averaged, int g, int U,
-                                               const int32_t* __restrict__ index, const double* __restrict__ mat, int gd,
-                                               int n, double sigma2, const double* __restrict__ density,
-                                               double* __restrict__ out) {
-    __shared__ double sm[T];
-    __shared__ double lm[SGK_CHUNK];
-    const int c = blockIdx.x;
-    const int x = blockIdx.y * T + threadIdx.x;
-    const double* cc = mat + (int64_t)c * gd;
-    double M = -__builtin_inf(), Tsum = 0.0, acc = 0.0;
-    for (int i0 = 0; i0 < U; i0 += SGK_CHUNK) {
-        const int m = min(SGK_CHUNK, U - i0);
-        double cmx = -__builtin_inf();
-        for (int i = threadIdx.x; i < m; i += T) {
-            const double* ci = mat + (int64_t)index[i0 + i] * gd;
-            double s = 0.0;
-            for (int t = 0; t < gd; ++t) {
-                const double df = ci[t] - cc[t];
-                s += df * df;
+__global__ void row_norms2(const double* __restrict__ X, int64_t n, int gd, double* __restrict__ out) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= n) return;
+    double s = 0.0;
+    for (int k = lane; k < gd; k += 64) s += X[r * gd + k] * X[r * gd + k];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) out[r] = s;
+}
+
+constexpr int SG_KC = 32;    // distance genes staged per step
+constexpr int SG_GT = 128;   // output genes per workgroup
+
+template <bool APPLY>
+__global__ __launch_bounds__(256) void sgk_flash(const double* __restrict__ X, int gd, const double* __restrict__ xn2,
+                                                 const int32_t* __restrict__ cells, int64_t ncells,
+                                                 const int32_t* __restrict__ index, int U, double inv_s2,
+                                                 const double* __restrict__ dens, const double* __restrict__ Av, int g,
+                                                 double* __restrict__ out, double* __restrict__ lse) {
+    constexpr int P = SG_KC + 2;        // pitch 34: conflict-free fragment reads (see pca.hip)
+    constexpr int PA = SG_GT + 16;      // pitch 144 = 16 mod 32
+    __shared__ double ms[64 * P];
+    __shared__ double xs[64 * P];
+    __shared__ double as_[APPLY ? 64 * PA : 1];
+    __shared__ double mi2[64], di[64], fac[64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t c0 = (int64_t)blockIdx.x * 64;
+    const int g0 = blockIdx.y * SG_GT;
+    const int cl = 16 * w + (lane & 15);  // this lane's column (cell) of the score tile
+    const int64_t cme = c0 + cl;
+    const int64_t crow = cme < ncells ? (cells ? cells[cme] : cme) : -1;
+    const double cn2 = crow >= 0 ? xn2[crow] : 0.0;
+    double m_run = -__builtin_inf(), l_run = 0.0;  // l_run: this lane's share of the column sum
+    d4 acc[APPLY ? SG_GT / 16 : 1];
+#pragma unroll
+    for (int t = 0; t < (APPLY ? SG_GT / 16 : 1); ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
+    const int lr = tid >> 2, seg = (tid & 3) * 8;
+    const int64_t xrow = c0 + lr < ncells ? (cells ? cells[c0 + lr] : c0 + lr) : -1;
+    for (int i0 = 0; i0 < U; i0 += 64) {
+        // ---- scores: S_t[reg] = m_i . x_c, i = i0 + 16 t + 4 reg + (lane >> 4), c = cl
+        d4 S[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) S[t] = d4{0.0, 0.0, 0.0, 0.0};
+        const int64_t mrow = i0 + lr < U ? index[i0 + lr] : -1;
+        if (tid < 64) {
+            const int64_t r = i0 + tid < U ? index[i0 + tid] : -1;
+            mi2[tid] = r >= 0 ? xn2[r] : 0.0;
+            di[tid] = (r >= 0 && dens) ? dens[i0 + tid] : 0.0;
+        }
+        for (int k0 = 0; k0 < gd; k0 += SG_KC) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = k0 + seg + e;
+                ms[lr * P + seg + e] = (mrow >= 0 && k < gd) ? X[mrow * gd + k] : 0.0;
+                xs[lr * P + seg + e] = (xrow >= 0 && k < gd) ? X[xrow * gd + k] : 0.0;
             }
-            const double v = s / -sigma2 - density[i0 + i];
-            lm[i] = v;
-            cmx = fmax(cmx, v);
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < SG_KC / 4; ++kk) {
+                const double b = xs[cl * P + 4 * kk + (lane >> 4)];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const double a = ms[(16 * t + (lane & 15)) * P + 4 * kk + (lane >> 4)];
+                    S[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, S[t], 0, 0, 0);
+                }
+            }
+            __syncthreads();
         }
-        cmx = block_max(cmx, sm);
-        const double newM = fmax(M, cmx);
-        const double scale = M == -__builtin_inf() ? 0.0 : exp(M - newM);
-        double part = 0.0;
-        for (int i = threadIdx.x; i < m; i += T) {
-            const double w = newM == -__builtin_inf() ? 0.0 : exp(lm[i] - newM);
-            lm[i] = w;
-            part += w;
+        if constexpr (APPLY) {
+            // stage the averaged vectors of this MNN tile: as_[i][gene]
+            for (int e = tid; e < 64 * SG_GT; e += 256) {
+                const int ii = e / SG_GT, gg = e - ii * SG_GT;
+                as_[ii * PA + gg] = (i0 + ii < U && g0 + gg < g) ? Av[(int64_t)(i0 + ii) * g + g0 + gg] : 0.0;
+            }
         }
-        part = block_sum(part, sm);  // also orders the lm[] writes before the reads below
-        Tsum = Tsum * scale + part;
-        acc *= scale;
-        if (x < g)
-            for (int i = 0; i < m; ++i) acc += averaged[(int64_t)(i0 + i) * g + x] * lm[i];
-        M = newM;
-        __syncthreads();
+        // ---- log-weights and the online softmax of this lane's column
+        double tmax = -__builtin_inf();
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int ii = 16 * t + 4 * reg + (lane >> 4);
+                const double d2 = mi2[ii] + cn2 - 2.0 * S[t][reg];
+                const double v = i0 + ii < U ? -(d2 > 0.0 ? d2 : 0.0) * inv_s2 - di[ii] : -__builtin_inf();
+                S[t][reg] = v;
+                tmax = fmax(tmax, v);
+            }
+        tmax = fmax(tmax, __shfl_xor(tmax, 16));
+        tmax = fmax(tmax, __shfl_xor(tmax, 32));
+        const double m_new = fmax(m_run, tmax);  // finite: the tile holds at least one MNN cell
+        const double scale = exp(m_run - m_new);  // exp(-inf) = 0 on the first tile
+        double psum = 0.0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const double pv = exp(S[t][reg] - m_new);
+                S[t][reg] = pv;
+                psum += pv;
+            }
+        l_run = l_run * scale + psum;
+        m_run = m_new;
+        if constexpr (APPLY) {
+            if ((lane >> 4) == 0) fac[cl] = scale;
+            __syncthreads();  // fac and as_ visible
+            // the output rows of this lane are the cells 16 w + (lane >> 4) + 4 reg: rescale, then accumulate
+            double f[4];
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) f[reg] = fac[16 * w + (lane >> 4) + 4 * reg];
+#pragma unroll
+            for (int gt = 0; gt < SG_GT / 16; ++gt)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) acc[gt][reg] *= f[reg];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int kk = 4 * t + reg;  // k-step: its element (lane >> 4) is MNN cell 4 kk + (lane >> 4) of the tile
+                    const double a = S[t][reg];
+#pragma unroll
+                    for (int gt = 0; gt < SG_GT / 16; ++gt) {
+                        const double b = as_[(4 * kk + (lane >> 4)) * PA + 16 * gt + (lane & 15)];
+                        acc[gt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[gt], 0, 0, 0);
+                    }
+                }
+        }
+        __syncthreads();  // mi2 / di / as_ / fac are rewritten by the next tile
     }
-    if (x < g) out[(int64_t)c * g + x] = acc / Tsum;
+    // column sum over the four lanes that share a column
+    double l_tot = l_run + __shfl_xor(l_run, 16);
+    l_tot += __shfl_xor(l_tot, 32);
+    if constexpr (APPLY) {
+        if ((lane >> 4) == 0) fac[cl] = 1.0 / l_tot;
+        __syncthreads();
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int64_t c = c0 + 16 * w + (lane >> 4) + 4 * reg;
+            if (c >= ncells) continue;
+            const double inv = fac[16 * w + (lane >> 4) + 4 * reg];
+#pragma unroll
+            for (int gt = 0; gt < SG_GT / 16; ++gt) {
+                const int gg = g0 + 16 * gt + (lane & 15);
+                if (gg < g) out[c * g + gg] = acc[gt][reg] * inv;
+            }
+        }
+    } else {
+        if ((lane >> 4) == 0 && cme < ncells) lse[cme] = m_run + log(l_tot);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -415,15 +510,23 @@ __global__ __launch_bounds__(T) void asv_exact_kernel(const double* __restrict__
 
 }  // namespace
 
+// ws: n + U doubles (squared norms of every cell over the distance genes, densities of the MNN cells)
 void smooth_gaussian_kernel_device(hipStream_t stream, const double* averaged, int g, int U, const int32_t* index,
-                                   const double* mat, int gd, int n, double sigma2, double* out, double* ws_density) {
+                                   const double* mat, int gd, int n, double sigma2, double* out, double* ws) {
     if (n <= 0 || g <= 0) return;
-    if (U > 0) {
-        hipLaunchKernelGGL(sgk_density, dim3(U), dim3(T), 0, stream, mat, gd, index, U, sigma2, ws_density);
+    if (U <= 0) {  // no MNN cell: 0 / 0 everywhere, as the reference's final division gives
+        hipLaunchKernelGGL(fill_nan, dim3((unsigned)cdiv((int64_t)n * g, 256)), dim3(256), 0, stream, out, (int64_t)n * g);
         BMX_LAUNCH_CHECK();
+        return;
     }
-    hipLaunchKernelGGL(sgk_apply, dim3(n, cdiv(g, T)), dim3(T), 0, stream, averaged, g, U, index, mat, gd, n, sigma2,
-                       ws_density, out);
+    double* xn2 = ws;
+    double* dens = ws + n;
+    hipLaunchKernelGGL(row_norms2, dim3((unsigned)cdiv(n, 4)), dim3(256), 0, stream, mat, (int64_t)n, gd, xn2);
+    // densities: the log-sum-exp of every MNN cell over the MNN cells (:56-65)
+    hipLaunchKernelGGL(sgk_flash<false>, dim3((unsigned)cdiv(U, 64), 1), dim3(256), 0, stream, mat, gd, xn2, index,
+                       (int64_t)U, index, U, 1.0 / sigma2, nullptr, nullptr, 0, nullptr, dens);
+    hipLaunchKernelGGL(sgk_flash<true>, dim3((unsigned)cdiv(n, 64), (unsigned)cdiv(g, SG_GT)), dim3(256), 0, stream, mat, gd,
+                       xn2, nullptr, (int64_t)n, index, U, 1.0 / sigma2, dens, averaged, g, out, nullptr);
     BMX_LAUNCH_CHECK();
 }
 

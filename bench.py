@@ -224,12 +224,52 @@ def run_config4(args):
     print(json.dumps(line), flush=True)
 
 
+def run_sgk(args):
+    """smooth_gaussian_kernel (K8) at n = 1e5 cells, U = 1e4 MNN cells, 50 dimensions, through the .Call-level entry
+    (host matrices in and out); a sample of cells is checked against the dense specification of
+    tests/testthat/test-mnn-correct.R:36-65 computed by numpy."""
+    import torch
+    torch.cuda.set_device(0)
+    from batchelor_amd import natives as nat
+    n, U, gd = 100000, 10000, 50
+    rng = np.random.Generator(np.random.PCG64(20250314 + 8000))
+    mat = rng.standard_normal((gd, n)) / np.sqrt(1.0 + np.arange(gd) / 5.0)[:, None]
+    index = np.sort(rng.choice(n, U, replace=False))
+    averaged = rng.standard_normal((gd, U)) * 0.1
+    s2 = 1.0
+    nat.smooth_gaussian_kernel(averaged, index, mat, s2)
+    t0 = time.perf_counter()
+    out = nat.smooth_gaussian_kernel(averaged, index, mat, s2)
+    dt = time.perf_counter() - t0
+    cells = rng.choice(n, 64, replace=False)
+    m = mat[:, index]
+    d_mm = ((m[:, :, None] - m[:, None, :]) ** 2).sum(axis=0) if U <= 2000 else None
+    # dense REF on the sample (chunked over MNN cells to bound memory)
+    dens = np.zeros(U)
+    for i0 in range(0, U, 500):
+        dd = ((m[:, i0:i0 + 500, None] - m[:, None, :]) ** 2).sum(axis=0)
+        dens[i0:i0 + 500] = np.log(np.exp(-dd / s2).sum(axis=1))
+    dc = ((m[:, :, None] - mat[:, None, cells]) ** 2).sum(axis=0)          # U x 64
+    lw = -dc / s2 - dens[:, None]
+    w = np.exp(lw - lw.max(axis=0))
+    ref = (averaged @ w) / w.sum(axis=0)
+    err = float(np.abs(out[:, cells] - ref).max() / np.abs(ref).max())
+    flops = 2.0 * gd * U * (n + U) + 2.0 * gd * U * n
+    print(json.dumps({"metric": "cells/sec smoothed (smooth_gaussian_kernel, .Call level, host in / host out)",
+                      "value": n / dt, "unit": "cells/s", "n_gpus": 1, "steps": 1, "warmup": 1, "ms_per_step": 1e3 * dt,
+                      "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64 MFMA",
+                      "data": "synthetic", "config": {"workload": f"sgk: n={n} cells, U={U} MNN cells, {gd} dims, sigma2={s2}",
+                                                      "max_rel_err_vs_dense_spec_on_64_cells": err},
+                      "algorithmic_flops": flops}), flush=True)
+    assert err < 1e-9, err
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS) + ["config4"])
+    ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS) + ["config4", "sgk"])
     ap.add_argument("--cells", type=int, default=25000, help="config4: cells per batch")
     ap.add_argument("--pca-iters", type=int, default=15, help="config4: subspace iterations")
     ap.add_argument("--var-adj", action="store_true", help="config5: mnnCorrect-style variance adjustment in the merges")
@@ -239,6 +279,8 @@ def main():
 
     if args.workload == "config4":
         return run_config4(args)
+    if args.workload == "sgk":
+        return run_sgk(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -87,6 +87,20 @@ def test_smooth_gaussian_kernel(oracle, nat, case):
     np.testing.assert_allclose(out, ref, rtol=1e-9, atol=1e-15)
 
 
+def test_smooth_gaussian_kernel_many_tiles(oracle, nat):
+    # several cell tiles, MNN tiles and gene tiles of the streaming kernel, ragged edges everywhere; different gene sets
+    # for the distances (40) and the output (300), as mnnCorrect(subset.row=) has them
+    rng = np.random.default_rng(10007)
+    n, U, gd, g = 1500, 333, 40, 300
+    mat = rng.standard_normal((gd, n)) * 0.3
+    index = rng.permutation(n)[:U]
+    averaged = rng.standard_normal((g, U))
+    for s2 in (0.5, 0.05):
+        out = nat.smooth_gaussian_kernel(averaged, index, mat, s2)
+        ref = oracle.smooth_gaussian_kernel(averaged, index, mat, s2)
+        np.testing.assert_allclose(out, ref, rtol=1e-9, atol=1e-13)
+
+
 def test_smooth_gaussian_kernel_errors(nat):
     with pytest.raises(RuntimeError, match="'index' must have length equal to number of rows in 'averaged'"):
         nat.smooth_gaussian_kernel(np.zeros((3, 4)), np.zeros(3, int), np.zeros((3, 5)), 1.0)
