@@ -503,7 +503,18 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
         qcount = 0;
         // lists about to fill are cut back now, so that the appends of the next drain rarely find one full
         const int c = lane < 32 ? lds_load_volatile(&mycnt[lane]) : 0;
+#ifdef BMX_EXP_ONECOMPACT
+        // one list per drain ahead of time (the fullest first would need a reduction: the first found will do), the rest
+        // only when they are really full
         unsigned long long need = __builtin_amdgcn_ballot_w64(c > LCAP - HEAD);
+        const unsigned long long crit = __builtin_amdgcn_ballot_w64(c > LCAP - 2);
+        if (need) {
+            const int first = __builtin_ctzll(crit ? crit : need);
+            need = crit | (1ull << first);
+        }
+#else
+        unsigned long long need = __builtin_amdgcn_ballot_w64(c > LCAP - HEAD);
+#endif
         while (need) {
             const int jj = __builtin_ctzll(need);
             need &= need - 1;

@@ -9,8 +9,8 @@
 // cells of the reference's own test data -- so a form that sums in any other order picks a different CELL there, not a
 // rounded value.  asv_exact_kernel therefore repeats the reference's order of operations literally (distances in
 // parallel, then the sequential logspace_add chains in restrict order, a lexicographic sort of (projection, weight),
-// the sequential walk), with the bit-reproducible exp / log1p of portable_math.hpp: bit for bit the CPU oracle's
-// result.  Its sequential chains cost O(cells x (nr1 + nr2)) dependent steps, fine up to ~1e5 restricted cells;
+// the sequential walk), with the bit-reproducible exp / log1p of portable_math.hpp: bit for bit what a CPU
+// following the same order of operations with the same arithmetic gets (the tests' checker does).  Its sequential chains cost O(cells x (nr1 + nr2)) dependent steps, fine up to ~1e5 restricted cells;
 // beyond that asv_kernel (parallel sums + sort-free weighted-quantile bisection) takes over and agrees except on those
 // ill-conditioned cells (tests/testthat/test-mnn-correct.R:141,396-399 acknowledge the effect upstream).
 #include "bmx_ops.hpp"

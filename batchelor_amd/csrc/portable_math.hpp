@@ -1,5 +1,5 @@
-// Bit-reproducible exp / log1p / logspace_add for the adjust_shift_variance quantile walk (product copy; the CPU oracle
-// carries its own copy of the same arithmetic in oracle/portable_math.h).
+// Bit-reproducible exp / log1p / logspace_add for the adjust_shift_variance quantile walk (the product's copy; the
+// tests' CPU checker carries its own copy of the same arithmetic).
 #pragma once
 #include <hip/hip_runtime.h>
 #define BMX_PM_FN __host__ __device__ __forceinline__

@@ -110,21 +110,3 @@ def init_engine_rccl(engine, group=None):
     uid = ctypes.create_string_buffer(box[0], 128)
     _lib.check(lib.bmx_engine_init_rccl(engine._h, int(rank), int(world), uid, 128))
     return rank, world
-
-
-def sharded_knn_reference(knn_fn, X, Q, k, exchange_tensor_fn, rank, world):
-    """Host-side statement of the sharded search: rank-local kNN on its query slice, then the in-place all-gather of
-    the padded per-rank slices.  `knn_fn(X, Qslice, k) -> (idx, dist)`.  Used by the CPU (gloo) tests."""
-    import torch
-    nq = Q.shape[0]
-    per = (nq + world - 1) // world
-    b, e = shard_range(nq, rank, world)
-    idx = np.zeros((per * world, k), dtype=np.int32)
-    dist = np.zeros((per * world, k), dtype=np.float64)
-    if e > b:
-        i, dd = knn_fn(X, Q[b:e], k)
-        idx[b:e], dist[b:e] = i, dd
-    for arr in (idx, dist):
-        t = torch.from_numpy(arr.reshape(-1).view(np.uint8))
-        exchange_tensor_fn(t, per * k * arr.itemsize)
-    return idx[:nq], dist[:nq]

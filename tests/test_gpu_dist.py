@@ -12,7 +12,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_rank_engine_equals_single_rank(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_n_rank_engine_equals_single_rank(tmp_path, world):
     import batchelor_amd as bx
     from tests.conftest import synth_batches
     s = socket.socket()
@@ -20,13 +21,13 @@ def test_two_rank_engine_equals_single_rank(tmp_path):
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, PYTHONPATH=ROOT)
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_gpu_shard_worker.py"), str(r), "2",
-                               str(port), str(tmp_path)], env=env) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_gpu_shard_worker.py"), str(r), str(world),
+                               str(port), str(tmp_path)], env=env) for r in range(world)]
     for p in procs:
-        assert p.wait(timeout=600) == 0
+        assert p.wait(timeout=900) == 0
     B = synth_batches(13, [3001, 2500, 1777], 50)
     ref = bx.reducedMNN(*B)
-    for r in range(2):
+    for r in range(world):
         got = np.load(tmp_path / f"rank{r}.npz")
         assert np.array_equal(got["corrected"], ref.corrected)
         for m in range(2):
