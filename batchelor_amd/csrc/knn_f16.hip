@@ -288,7 +288,7 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
         };
         // tile t goes to slot t % NSLOT once every consumer has read the tile staged there NSLOT tiles earlier;
         // done[slot][c] = number of the last tile consumer c has read from the slot, plus one
-        auto wait_free = [&](int t, int slot) {
+        auto wait_free = [&](int t, int slot) __attribute__((always_inline)) {
             if (t < NSLOT) return;
             const int need = t - NSLOT + 1;
             for (;;) {
@@ -360,6 +360,8 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
     const unsigned long long dbg_t0 = STAMP();
 #endif
 
+    // (every lambda of this kernel is force-inlined: left to its own devices the compiler turned `compact` and `drain`
+    // into real calls once they grew -- their captures then live in scratch and every LDS atomic becomes a flat one.)
     // ---- compaction of query jj's list (jj wave-uniform): cut it back to about KS entries, tighten the threshold.
     // The cut need not sit exactly at rank KS: any entry with at least KS - 1 smaller ones is a valid new threshold
     // (everything above it is dropped, at least KS stay).  Eight entries from fixed, evenly spread places of the
@@ -367,7 +369,7 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
     // dependent chain of quickselect rounds -- and the one that keeps the fewest, at least KS, wins: on average KS + 3
     // stay.  Only when none qualifies (all eight below rank KS: ~1 %) or the best would free too little does the exact
     // quickselect run.
-    auto compact = [&](const int jj, const bool exact = false) {
+    auto compact = [&](const int jj, const bool exact = false) __attribute__((always_inline)) {
         const int n_raw = __builtin_amdgcn_readfirstlane(lds_load_volatile(&mycnt[jj]));
         const int n = n_raw < LCAP ? n_raw : LCAP;
         if (n <= KS) return;
@@ -441,7 +443,7 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
     // of the first half and one of the second (two independent chains of LDS read -> threshold of the owning lane by
     // ds_bpermute -> LDS atomic slot -> store, issued together).  The wave holds the ring up while it is here, so it
     // runs at the highest issue priority.
-    auto drain = [&]() {
+    auto drain = [&]() __attribute__((always_inline)) {
 #ifdef BMX_STAMPS
         const unsigned long long d0 = STAMP();
         ++dbg_ndrain;
@@ -534,7 +536,7 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
     uint32_t tau_fetch = 0xFFFFFFFFu;
     int seen = 0;
     int slot_n = 0;  // slot of the tile to read next
-    auto spin_until_staged = [&](int tile) {
+    auto spin_until_staged = [&](int tile) __attribute__((always_inline)) {
         if (__builtin_amdgcn_readfirstlane(seen) < tile + 1) {
 #ifdef BMX_STAMPS
             const unsigned long long s0 = STAMP();
@@ -553,7 +555,7 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
 #pragma unroll
         for (int s = 0; s < NS; ++s) a[s] = tp[s * 64];
     };
-    auto hand_back = [&](int tile) {
+    auto hand_back = [&](int tile) __attribute__((always_inline)) {
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         {
             // lane 0 stores the done word: EXEC is all ones here (uniform control flow), so it is narrowed and restored
@@ -635,7 +637,7 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
         // ---- spill the groups with survivors of tile t - 1
         const int at = t - 1 + t_off - (t - 1 + t_off >= ntiles ? ntiles : 0);  // the tile at position t - 1 of the sweep
         const uint32_t tagbase = ((uint32_t)at << 8) | (uint32_t)lane;
-        auto spill = [&](const int u, const unsigned long long m) {
+        auto spill = [&](const int u, const unsigned long long m) __attribute__((always_inline)) {
             if (g[u] < tau) {  // the lanes of m
                 const int slot = qcount + mbcnt64(m);
                 f32x4 rec;
