@@ -509,7 +509,7 @@ void candidate_pass(hipStream_t stream, KnnWorkspace& ws, const Tier& T, const d
     const int S_auto = nr >= 65536 && T.id == 1 ? 16384 : 4096;
     // (a seeded search samples too: the odd query whose seed is loose -- a left cell listed by one far-away right cell --
     // then starts from the sampled threshold like everybody else; the tighter of the two counts)
-    const int S = nr >= 32768 ? (std::getenv("BMX_SAMPLE") ? std::atoi(std::getenv("BMX_SAMPLE")) : S_auto) : 0;
+    const int S = nr >= 32768 ? (int)round_up(std::getenv("BMX_SAMPLE") ? std::atoi(std::getenv("BMX_SAMPLE")) : S_auto, 64) : 0;
     int C = 1, n_full = 0;
     {
         const int a = nqb / 256, b = nqb % 256;
@@ -531,7 +531,8 @@ void candidate_pass(hipStream_t stream, KnnWorkspace& ws, const Tier& T, const d
         C = std::max(1, std::min(MAX_CHUNKS - 1, std::atoi(std::getenv("BMX_FORCE_C"))));
         n_full = 0;
     }
-    const int chunk_len = (int)round_up(cdiv(nr, C), 32);
+    const int rmul = T.id == 1 ? 64 : 32;  // the fp16 ring hands two tiles over at a time
+    const int chunk_len = (int)round_up(cdiv(nr, C), rmul);
     C = std::max(1, cdiv(nr, chunk_len));
     const int nr_pad = chunk_len * C;
     const int nchunks = C;

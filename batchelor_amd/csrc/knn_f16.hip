@@ -199,18 +199,19 @@ __global__ __launch_bounds__(256) void knn_prep_f16(const double* __restrict__ X
 // LDS budget: ring of reference tiles | per-query lists | per-wave spill queues | list counters | hand-over words
 // ---------------------------------------------------------------------------------------------------
 __host__ __device__ constexpr int lds_fixed_bytes() { return NCONS * QCAP * 20 + NQ * 4 + 512; }
+// A ring slot holds TWO reference tiles (64 rows): the consumers wait, hand back and poll once per two tiles.
 __host__ __device__ constexpr int ring_slots_for(int NS, int LCAP) {
     const int rest = 160 * 1024 - lds_fixed_bytes() - NQ * LCAP * 8;
-    const int n = rest / (NS * 1024);
-    return n > 8 ? 8 : n;
+    const int n = rest / (2 * NS * 1024);
+    return n > 4 ? 4 : n;
 }
-// list capacity: as long as the ring keeps at least four slots, else as short as a useful pending part allows
+// list capacity: as long as the ring keeps at least two slots (four tiles), else as short as a useful pending part allows
 #ifndef BMX_LCAP_MAX
 #define BMX_LCAP_MAX 56
 #endif
 __host__ __device__ constexpr int list_cap(int NS, int KS) {
     for (int c = BMX_LCAP_MAX; c >= KS + 16; c -= 8)
-        if (ring_slots_for(NS, c) >= 4) return c;
+        if (ring_slots_for(NS, c) >= 2) return c;
     return KS + 16 <= 64 ? KS + 16 : 64;
 }
 
@@ -232,13 +233,14 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
     int n_full, int nranges, int out_chunk0, int out_nchunks, uint32_t* __restrict__ tau_g, int32_t* __restrict__ cand,
     float* __restrict__ cand_v, float* __restrict__ tau_out) {
     constexpr int TILE_BYTES = NS * 1024;
+    constexpr int SLOT_BYTES = 2 * TILE_BYTES;
     constexpr int NSLOT = ring_slots_for(NS, LCAP);
     static_assert(NSLOT >= 2, "LDS ring");
     static_assert(LCAP <= 64 && LCAP > KS, "one list entry per lane during compaction");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* ring = smem;                                                                           // [NSLOT][TILE_BYTES]
-    unsigned long long* lists = reinterpret_cast<unsigned long long*>(smem + NSLOT * TILE_BYTES);  // [NQ][LCAP]
+    char* ring = smem;                                                                           // [NSLOT][2][TILE_BYTES]
+    unsigned long long* lists = reinterpret_cast<unsigned long long*>(smem + NSLOT * SLOT_BYTES);  // [NQ][LCAP]
     float* qvals = reinterpret_cast<float*>(lists + NQ * LCAP);                                   // [NCONS][QCAP][4]
     uint32_t* qtags = reinterpret_cast<uint32_t*>(qvals + NCONS * QCAP * 4);                      // [NCONS][QCAP]
     int* cnt = reinterpret_cast<int*>(qtags + NCONS * QCAP);                                      // [NQ]
@@ -258,16 +260,9 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
         r_begin = first_begin + rng * range_len;
         r_end = min(r_limit, r_begin + range_len);
     }
-    const int ntiles = (r_end - r_begin) >> 5;
+    const int ntiles = (r_end - r_begin) >> 5;  // even: ranges are multiples of 64 rows
+    const int nslots = ntiles >> 1;
     const int out_chunk = out_chunk0 + rng;
-    // BMX_STAGGER (experiment, off): every workgroup starts its sweep at a different tile and wraps round.  Measured:
-    // no change in time, but 4x the L2 misses (the workgroups of an XCD no longer share the stretch they stream), so
-    // the sweeps stay aligned.
-#ifdef BMX_STAGGER
-    const int t_off = ntiles > 0 ? (int)(((long long)(qblock & 255) * ntiles) >> 8) : 0;
-#else
-    const int t_off = 0;
-#endif
     if (tid < NSLOT * (1 + NCONS)) ready[tid] = 0;  // ready[] and done[] are contiguous
     if (tid < NQ) cnt[tid] = 0;
     __syncthreads();
@@ -278,58 +273,55 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
         __builtin_amdgcn_s_setprio(BMX_EXP_PPRIO);
 #endif
         const int p = wave - NCONS;
-        f32x4 ra[NS], rb[NS], rc[NS];
+        f32x4 ra[2 * NS], rb[2 * NS];
         const f32x4* src = reinterpret_cast<const f32x4*>(PrF) + ((int64_t)(r_begin >> 5) * NS) * 64 + lane;
         f32x4* ring_l = reinterpret_cast<f32x4*>(ring) + lane;
-        auto load = [&](f32x4(&r)[NS], int t) {
-            const int at = t + t_off - (t + t_off >= ntiles ? ntiles : 0);  // position t of the sweep = tile `at`
+        auto load = [&](f32x4(&r)[2 * NS], int sl) {  // both tiles of slot sl: 2 NS contiguous 1 KiB pieces
 #pragma unroll
-            for (int s = 0; s < NS; ++s) r[s] = src[((int64_t)at * NS + s) * 64];
+            for (int s = 0; s < 2 * NS; ++s) r[s] = src[((int64_t)sl * 2 * NS + s) * 64];
         };
-        // tile t goes to slot t % NSLOT once every consumer has read the tile staged there NSLOT tiles earlier;
-        // done[slot][c] = number of the last tile consumer c has read from the slot, plus one
-        auto wait_free = [&](int t, int slot) __attribute__((always_inline)) {
-            if (t < NSLOT) return;
-            const int need = t - NSLOT + 1;
+        // slot sl goes to ring position sl % NSLOT once every consumer has read the slot staged there NSLOT slots earlier;
+        // done[pos][c] = number of the last slot consumer c has read from the position, plus one
+        auto wait_free = [&](int sl, int pos) __attribute__((always_inline)) {
+            if (sl < NSLOT) return;
+            const int need = sl - NSLOT + 1;
             for (;;) {
-                const int v = lane < NCONS ? lds_load_volatile(&done[slot * NCONS + lane]) : need;
+                const int v = lane < NCONS ? lds_load_volatile(&done[pos * NCONS + lane]) : need;
                 if (__builtin_amdgcn_ballot_w64(v < need) == 0) break;
                 __builtin_amdgcn_s_sleep(BMX_PSLEEP);
             }
         };
-        auto publish = [&](const f32x4(&r)[NS], int t) {
-            const int slot = t % NSLOT;
-            wait_free(t, slot);
+        auto publish = [&](const f32x4(&r)[2 * NS], int sl) {
+            const int pos = sl % NSLOT;
+            wait_free(sl, pos);
             __atomic_signal_fence(__ATOMIC_SEQ_CST);
-            f32x4* dst = ring_l + slot * (TILE_BYTES / 16);
+            f32x4* dst = ring_l + pos * (SLOT_BYTES / 16);
 #pragma unroll
-            for (int s = 0; s < NS; ++s) dst[s * 64] = r[s];
+            for (int s = 0; s < 2 * NS; ++s) dst[s * 64] = r[s];
             __atomic_signal_fence(__ATOMIC_SEQ_CST);
-            // same wave, in-order LDS queue: the flag lands after the tile
-            if (lane == 0) __hip_atomic_store(&ready[slot], t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // same wave, in-order LDS queue: the flag lands after the tiles
+            if (lane == 0) __hip_atomic_store(&ready[pos], sl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         };
-        int t = p;
-        if (t < ntiles) load(ra, t);
-        if (t + NPROD < ntiles) load(rb, t + NPROD);
-        for (; t < ntiles; t += 3 * NPROD) {
-            if (t + 2 * NPROD < ntiles) load(rc, t + 2 * NPROD);
-            publish(ra, t);
-            if (t + NPROD < ntiles) {
-                if (t + 3 * NPROD < ntiles) load(ra, t + 3 * NPROD);
-                publish(rb, t + NPROD);
-            }
-            if (t + 2 * NPROD < ntiles) {
-                if (t + 4 * NPROD < ntiles) load(rb, t + 4 * NPROD);
-                publish(rc, t + 2 * NPROD);
+        // two register sets: the loads of slot sl + 4 are in flight while slot sl is handed over (16 tiles in flight
+        // per workgroup)
+        int sl = p;
+        if (sl < nslots) load(ra, sl);
+        if (sl + NPROD < nslots) load(rb, sl + NPROD);
+        for (; sl < nslots; sl += 2 * NPROD) {
+            publish(ra, sl);
+            if (sl + 2 * NPROD < nslots) load(ra, sl + 2 * NPROD);
+            if (sl + NPROD < nslots) {
+                publish(rb, sl + NPROD);
+                if (sl + 3 * NPROD < nslots) load(rb, sl + 3 * NPROD);
             }
         }
-        // two empty tiles past the end: the consumers' loop runs one tile longer than the data and always
-        // prefetches "tile t + 1"
-        for (int e = ntiles; e < ntiles + 2; ++e) {
-            if (ntiles > 0 && e % NPROD == p) {
-                const int slot = e % NSLOT;
-                wait_free(e, slot);
-                if (lane == 0) __hip_atomic_store(&ready[slot], e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // two empty slots past the end: the consumers' loop runs one step longer than the data and always refills from
+        // "slot sl + 1"
+        for (int e = nslots; e < nslots + 2; ++e) {
+            if (nslots > 0 && e % NPROD == p) {
+                const int pos = e % NSLOT;
+                wait_free(e, pos);
+                if (lane == 0) __hip_atomic_store(&ready[pos], e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
         return;
@@ -531,65 +523,64 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
 #endif
     };
 
-    // Tile hand-over: as in knn_bf16.hip (tile t + 1 is read into the fragment registers while tile t computes,
-    // its ready word was polled a tile earlier, the done word is queued behind the fragment reads).
+    // Hand-over, once per slot (two tiles).  While the tiles of slot sl compute, their fragment registers are refilled
+    // from slot sl + 1 (each register right after the MFMA that consumed it); the ready word of slot sl + 1 is checked
+    // before the first refill (it was polled a slot earlier: no LDS round trip in steady state), and after the last
+    // refill the wave stores "read up to sl + 1" in its done word -- queued behind the reads in the wave's in-order LDS
+    // queue, so the producers cannot overwrite them early -- and polls the ready word of slot sl + 2.
     uint32_t tau_fetch = 0xFFFFFFFFu;
     int seen = 0;
-    int slot_n = 0;  // slot of the tile to read next
-    auto spin_until_staged = [&](int tile) __attribute__((always_inline)) {
-        if (__builtin_amdgcn_readfirstlane(seen) < tile + 1) {
+    int pos_n = 0;  // ring position of the slot to read next
+    auto spin_until_staged = [&](int slot) __attribute__((always_inline)) {
+        if (__builtin_amdgcn_readfirstlane(seen) < slot + 1) {
 #ifdef BMX_STAMPS
             const unsigned long long s0 = STAMP();
 #endif
             do {
                 __builtin_amdgcn_s_sleep(1);
-                seen = lds_load_volatile(&ready[slot_n]);
-            } while (seen < tile + 1);
+                seen = lds_load_volatile(&ready[pos_n]);
+            } while (seen < slot + 1);
 #ifdef BMX_STAMPS
             dbg_spin += STAMP() - s0;
 #endif
         }
     };
-    auto read_tile = [&](f32x4(&a)[NS]) {
-        const f32x4* tp = reinterpret_cast<const f32x4*>(ring + slot_n * TILE_BYTES) + lane;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) a[s] = tp[s * 64];
-    };
-    auto hand_back = [&](int tile) __attribute__((always_inline)) {
+    auto hand_back = [&](int slot) __attribute__((always_inline)) {
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         {
             // lane 0 stores the done word: EXEC is all ones here (uniform control flow), so it is narrowed and restored
             // with two scalar moves instead of a compare / saveexec / branch sequence
             typedef __attribute__((address_space(3))) int* lds_iptr;
-            const lds_iptr dp = (lds_iptr)&done[slot_n * NCONS + wave];
-            const int val = tile + 1;
+            const lds_iptr dp = (lds_iptr)&done[pos_n * NCONS + wave];
+            const int val = slot + 1;
             asm volatile("s_mov_b64 exec, 1\n\tds_write_b32 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(dp), "v"(val) : "memory");
         }
-        slot_n = slot_n + 1 == NSLOT ? 0 : slot_n + 1;
-        seen = lds_load_volatile(&ready[slot_n]);
+        pos_n = pos_n + 1 == NSLOT ? 0 : pos_n + 1;
+        seen = lds_load_volatile(&ready[pos_n]);
     };
 
-    f32x4 a[NS], b[NS];  // fragment sets of alternate tiles
+    f32x4 a[NS], b[NS];  // fragments of the even / odd tile of the current slot
     uint32_t best[SAMPLE ? KS / 2 : 1];
 #pragma unroll
     for (int i = 0; i < (SAMPLE ? KS / 2 : 1); ++i) best[i] = 0xFF800000u;  // image of +inf
 
-    // One step = the MFMA chain of tile t (fragments in `fa`) into `cur`, with the filter of tile t - 1 (products in
-    // `prev`) issued in its gaps; then the spill of tile t - 1's groups with survivors.  The fragments of tile t + 1
-    // are read into the other register set `fn` BEFORE the chain starts, and the slot is handed back at once: by the
-    // time the next step waits for them (lgkmcnt(0) at its top) they are a whole chain old.
-    auto step = [&](f32x16& cur, const f32x16& prev, const f32x4(&fa)[NS], f32x4(&fn)[NS], const int t) {
-        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the fragments of tile t and the ready word of tile t + 1
-        spin_until_staged(t + 1);
-        __atomic_signal_fence(__ATOMIC_SEQ_CST);
-        read_tile(fn);
-        hand_back(t + 1);
-        __builtin_amdgcn_sched_barrier(0);  // the reads stay in front of the chain
+    // One step = the MFMA chain of tile t (fragments in `f`) into `cur`; in its gaps the refill of each fragment
+    // register with the same half of the NEXT slot and the filter of tile t - 1 (products in `prev`); then the spill of
+    // tile t - 1's groups with survivors.  `half` = which tile of its slot t is.
+    auto step = [&](f32x16& cur, const f32x16& prev, f32x4(&f)[NS], const int t, const int half) {
+        typedef __attribute__((address_space(3))) const char* lds_cptr;
+        typedef __attribute__((address_space(3))) const f32x4* lds_f4ptr;
+        lds_cptr tbase = (lds_cptr)ring + (pos_n * SLOT_BYTES + half * TILE_BYTES + lane * 16);
+        asm volatile("" : "+v"(tbase));     // the address is formed here, ...
+        __builtin_amdgcn_sched_barrier(0);  // ... outside the interleaved block below
+        const lds_f4ptr tp = (lds_f4ptr)tbase;
 #pragma unroll
         for (int e = 0; e < 16; ++e) cur[e] = 0.f;
 #pragma unroll
-        for (int s = 0; s < NS; ++s)
-            cur = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[s]), bq[s], cur, 0, 0, 0);
+        for (int s = 0; s < NS; ++s) {
+            cur = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f[s]), bq[s], cur, 0, 0, 0);
+            f[s] = tp[s * 64];
+        }
         // group minima (4 consecutive references each), then the lane minimum, of the previous tile
         float g[4];
         // every fminf below is half of a three-way minimum: the compiler forms v_min3_f32 from such pairs and, unlike
@@ -626,8 +617,10 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one LDS read
             __builtin_amdgcn_sched_group_barrier(0x002, SAMPLE ? 2 + (KS + 15 + NS - 1) / NS : (12 + NS - 1) / NS, 0);
         }
+        if (half == 1) hand_back(((t - 1) >> 1) + 1);  // both tiles of slot (t - 1) / 2 + 1 have been read
         if constexpr (SAMPLE) return;
         if (any == 0) return;
 #ifdef BMX_STAMPS
@@ -635,8 +628,7 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
         const unsigned long long dbg_e0 = STAMP();
 #endif
         // ---- spill the groups with survivors of tile t - 1
-        const int at = t - 1 + t_off - (t - 1 + t_off >= ntiles ? ntiles : 0);  // the tile at position t - 1 of the sweep
-        const uint32_t tagbase = ((uint32_t)at << 8) | (uint32_t)lane;
+        const uint32_t tagbase = ((uint32_t)(t - 1) << 8) | (uint32_t)lane;
         auto spill = [&](const int u, const unsigned long long m) __attribute__((always_inline)) {
             if (g[u] < tau) {  // the lanes of m
                 const int slot = qcount + mbcnt64(m);
@@ -697,25 +689,35 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
 #ifndef BMX_EXP_NOCPRIO
     if (wave >= NCONS / 2) __builtin_amdgcn_s_setprio(1);
 #endif
-    if (ntiles > 0) {
+    if (nslots > 0) {
         spin_until_staged(0);
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
-        read_tile(a);
+        {
+            const f32x4* tp = reinterpret_cast<const f32x4*>(ring + pos_n * SLOT_BYTES) + lane;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                a[s] = tp[s * 64];
+                b[s] = tp[(NS + s) * 64];
+            }
+        }
         hand_back(0);
         // steps 0 .. ntiles: step t multiplies tile t (step ntiles: an empty tile, product unused) and filters tile
-        // t - 1; two steps per iteration so that the two accumulators alternate statically
-        for (int t2 = 0; t2 <= ntiles; t2 += 2) {
+        // t - 1; one slot = two steps per iteration, so the two accumulators and the two fragment sets alternate statically
+        for (int sl = 0; sl <= nslots; ++sl) {
             if constexpr (!SAMPLE) {
                 // periodic refresh of the shared threshold: the (L1-bypassing) load is issued here and looked at one
                 // iteration later, so nobody waits for the round trip
                 if (shared_tau) {
-                    if ((t2 & 15) == 2) tau = fminf(tau, orderable_f32(tau_fetch));
-                    if ((t2 & 15) == 0)
+                    if ((sl & 7) == 1) tau = fminf(tau, orderable_f32(tau_fetch));
+                    if ((sl & 7) == 0)
                         tau_fetch = __hip_atomic_load(&tau_g[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
-            step(accA, accB, a, b, t2);
-            if (t2 + 1 <= ntiles) step(accB, accA, b, a, t2 + 1);
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the fragments of this slot and the ready word of the next
+            spin_until_staged(sl + 1);
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            step(accA, accB, a, 2 * sl, 0);
+            if (sl < nslots) step(accB, accA, b, 2 * sl + 1, 1);
         }
     }
     __builtin_amdgcn_s_setprio(0);
@@ -771,7 +773,7 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
 template <int NS, int KS>
 void launch(hipStream_t stream, KnnWorkspace& ws, const Bf16Launch& L) {
     constexpr int LCAP = list_cap(NS, KS);
-    constexpr size_t lds = (size_t)ring_slots_for(NS, LCAP) * NS * 1024 + (size_t)NQ * LCAP * 8 + lds_fixed_bytes();
+    constexpr size_t lds = (size_t)ring_slots_for(NS, LCAP) * 2 * NS * 1024 + (size_t)NQ * LCAP * 8 + lds_fixed_bytes();
     static_assert(lds <= 160 * 1024, "LDS budget");
     ensure_dynamic_lds(reinterpret_cast<const void*>(&knn_topk_f16<NS, KS, LCAP, false>), lds);
     ensure_dynamic_lds(reinterpret_cast<const void*>(&knn_topk_f16<NS, KS, LCAP, true>), lds);
