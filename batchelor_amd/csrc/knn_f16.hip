@@ -560,6 +560,7 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
     };
 
     f32x4 a[NS], b[NS];  // fragments of the even / odd tile of the current slot
+    float sample_mn = __builtin_inff();
     uint32_t best[SAMPLE ? KS / 2 : 1];
 #pragma unroll
     for (int i = 0; i < (SAMPLE ? KS / 2 : 1); ++i) best[i] = 0xFF800000u;  // image of +inf
@@ -595,15 +596,21 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
         const float mn = fminf(fminf(fminf(fminf(g[0], g[1]), g[2]), g[3]), tau);
         unsigned long long any = 0;
         if constexpr (SAMPLE) {
-            // sorted insertion of the lane minimum on the order-preserving integer images (see knn_bf16.hip)
-            uint32_t x = f32_orderable(mn);
+            // sorted insertion on the order-preserving integer images (see knn_bf16.hip) of ONE candidate per slot: the
+            // lane's minimum over both tiles of the slot (32 references of one query; still one distinct reference per
+            // candidate, half the insertions)
+            if (half == 0) {
+                sample_mn = mn;
+            } else {
+                uint32_t x = f32_orderable(fminf(fminf(mn, sample_mn), mn));
 #pragma unroll
-            for (int i = 0; i < KS / 2; ++i) {
-                const uint32_t lo = min(best[i], x);
-                x = max(best[i], x);
-                best[i] = lo;
+                for (int i = 0; i < KS / 2; ++i) {
+                    const uint32_t lo = min(best[i], x);
+                    x = max(best[i], x);
+                    best[i] = lo;
+                }
+                asm volatile("" ::"v"(best[KS / 2 - 1]));  // keep it in this block
             }
-            asm volatile("" ::"v"(best[KS / 2 - 1]));  // keep it in this block
         } else {
 #if defined(BMX_EXP_NOFILTER)
             any = 0;  // timing experiment: no filter, no events (results are garbage)
@@ -723,6 +730,15 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
     __builtin_amdgcn_s_setprio(0);
 
     if constexpr (SAMPLE) {
+        {  // the last tile's candidate is still waiting for a partner
+            uint32_t x = f32_orderable(sample_mn);
+#pragma unroll
+            for (int i = 0; i < KS / 2; ++i) {
+                const uint32_t lo = min(best[i], x);
+                x = max(best[i], x);
+                best[i] = lo;
+            }
+        }
         const uint32_t mine = best[KS / 2 - 1], other = __shfl_xor(mine, 32);
         if (h == 0) tau_g[q] = max(mine, other);
         return;
