@@ -561,9 +561,16 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
 
     f32x4 a[NS], b[NS];  // fragments of the even / odd tile of the current slot
     float sample_mn = __builtin_inff();
-    uint32_t best[SAMPLE ? KS / 2 : 1];
+    // SAMPLE: the lane's KS / 2 smallest candidates, ascending.  Insertion of x into a sorted list is one median per
+    // entry, best'[i] = med3(best[i - 1], best[i], x), all of them independent when taken from the top down
+    float best[SAMPLE ? KS / 2 : 1];
 #pragma unroll
-    for (int i = 0; i < (SAMPLE ? KS / 2 : 1); ++i) best[i] = 0xFF800000u;  // image of +inf
+    for (int i = 0; i < (SAMPLE ? KS / 2 : 1); ++i) best[i] = __builtin_inff();
+    auto sample_insert = [&](const float x) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = (SAMPLE ? KS / 2 : 1) - 1; i > 0; --i) best[i] = __builtin_amdgcn_fmed3f(best[i - 1], best[i], x);
+        best[0] = fminf(fminf(best[0], x), x);
+    };
 
     // One step = the MFMA chain of tile t (fragments in `f`) into `cur`; in its gaps the refill of each fragment
     // register with the same half of the NEXT slot and the filter of tile t - 1 (products in `prev`); then the spill of
@@ -602,13 +609,7 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
             if (half == 0) {
                 sample_mn = mn;
             } else {
-                uint32_t x = f32_orderable(fminf(fminf(mn, sample_mn), mn));
-#pragma unroll
-                for (int i = 0; i < KS / 2; ++i) {
-                    const uint32_t lo = min(best[i], x);
-                    x = max(best[i], x);
-                    best[i] = lo;
-                }
+                sample_insert(fminf(fminf(mn, sample_mn), mn));
                 asm volatile("" ::"v"(best[KS / 2 - 1]));  // keep it in this block
             }
         } else {
@@ -625,7 +626,7 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
         for (int s = 0; s < NS; ++s) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one LDS read
-            __builtin_amdgcn_sched_group_barrier(0x002, SAMPLE ? 2 + (KS + 15 + NS - 1) / NS : (12 + NS - 1) / NS, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, SAMPLE ? 3 + (KS / 2 + NS - 1) / NS : (12 + NS - 1) / NS, 0);
         }
         if (half == 1) hand_back(((t - 1) >> 1) + 1);  // both tiles of slot (t - 1) / 2 + 1 have been read
         if constexpr (SAMPLE) return;
@@ -733,17 +734,17 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
     __builtin_amdgcn_s_setprio(0);
 
     if constexpr (SAMPLE) {
-        {  // the last tile's candidate is still waiting for a partner
-            uint32_t x = f32_orderable(sample_mn);
-#pragma unroll
-            for (int i = 0; i < KS / 2; ++i) {
-                const uint32_t lo = min(best[i], x);
-                x = max(best[i], x);
-                best[i] = lo;
-            }
-        }
-        const uint32_t mine = best[KS / 2 - 1], other = __shfl_xor(mine, 32);
+        sample_insert(sample_mn);  // the last tile's candidate was still waiting for a partner
+        const uint32_t mine = f32_orderable(best[KS / 2 - 1]), other = __shfl_xor(mine, 32);
         if (h == 0) tau_g[q] = max(mine, other);
+#ifdef BMX_STAMPS
+        if (lane == 0) {
+            atomicAdd(&bmx_dbg16[0], STAMP() - dbg_t0);
+            atomicAdd(&bmx_dbg16[1], dbg_spin);
+            atomicAdd(&bmx_dbg16[8], (unsigned long long)ntiles);
+            atomicAdd(&bmx_dbg16[9], 1ull);
+        }
+#endif
         return;
     } else {
         drain();
@@ -816,7 +817,8 @@ void launch(hipStream_t stream, KnnWorkspace& ws, const Bf16Launch& L) {
     BMX_LAUNCH_CHECK();
     if (ws.profile) BMX_HIP(hipEventRecord(ev.second, stream));
 #ifdef BMX_STAMPS
-    if (!L.sample) {
+    {
+        if (L.sample) fprintf(stderr, "(sample pass) ");
         unsigned long long hh[48];
         BMX_HIP(hipStreamSynchronize(stream));
         BMX_HIP(hipMemcpyFromSymbol(hh, HIP_SYMBOL(bmx_dbg16), sizeof(hh)));
