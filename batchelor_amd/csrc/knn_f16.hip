@@ -41,11 +41,15 @@ using namespace sel;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int NCONS = 8;   // consumer waves (32 queries each): two per SIMD
-constexpr int NPROD = 4;   // producer waves: one per SIMD
+constexpr int NPROD = 2;   // producer waves
+constexpr int NSERV = 2;   // service waves (each works off the spill queues of NCONS / NSERV consumers)
 constexpr int NQ = NCONS * 32;
 constexpr int QCAP = 64;   // spill records per consumer wave (one group of one tile can fill all 64)
-#ifndef BMX_QSOFT
-#define BMX_QSOFT 24
+#ifndef BMX_DRAIN_MIN
+#define BMX_DRAIN_MIN 16
+#endif
+#ifndef BMX_SPRIO
+#define BMX_SPRIO 1
 #endif
 #ifndef BMX_HEAD
 #define BMX_HEAD 4
@@ -56,7 +60,8 @@ constexpr int QCAP = 64;   // spill records per consumer wave (one group of one 
 #ifndef BMX_PSLEEP
 #define BMX_PSLEEP 1
 #endif
-constexpr int QSOFT = BMX_QSOFT;  // ... but the queue is worked off as soon as it holds this many: short, frequent stalls
+constexpr int EPI_CONS = 20;  // of a consumer's 32 final lists, those it writes out itself (its service wave: the rest)
+constexpr int DRAIN_MIN = BMX_DRAIN_MIN;  // records in a queue before its service wave bothers (unless the consumer waits)
 constexpr int HEAD = BMX_HEAD;    // a list is compacted ahead of time once fewer than HEAD slots are free
 
 __device__ __forceinline__ uint16_t f32_to_f16_bits(float f) {
@@ -196,9 +201,10 @@ __global__ __launch_bounds__(256) void knn_prep_f16(const double* __restrict__ X
 }
 
 // ---------------------------------------------------------------------------------------------------
-// LDS budget: ring of reference tiles | per-query lists | per-wave spill queues | list counters | hand-over words
+// LDS budget: ring of reference tiles | per-query lists | per-wave spill queues | list counters | published
+// thresholds | hand-over words
 // ---------------------------------------------------------------------------------------------------
-__host__ __device__ constexpr int lds_fixed_bytes() { return NCONS * QCAP * 20 + NQ * 4 + 512; }
+__host__ __device__ constexpr int lds_fixed_bytes() { return NCONS * QCAP * 20 + NQ * 4 + NQ * 4 + 512; }
 // A ring slot holds TWO reference tiles (64 rows): the consumers wait, hand back and poll once per two tiles.
 __host__ __device__ constexpr int ring_slots_for(int NS, int LCAP) {
     const int rest = 160 * 1024 - lds_fixed_bytes() - NQ * LCAP * 8;
@@ -228,7 +234,7 @@ __device__ unsigned long long bmx_dbg16[48];
 #endif
 
 template <int NS, int KS, int LCAP, bool SAMPLE>
-__global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
+__global__ __launch_bounds__((NCONS + NPROD + NSERV) * 64) void knn_topk_f16(
     const uint16_t* __restrict__ Pq, const uint16_t* __restrict__ PrF, int first_begin, int range_len, int r_limit,
     int n_full, int nranges, int out_chunk0, int out_nchunks, uint32_t* __restrict__ tau_g, int32_t* __restrict__ cand,
     float* __restrict__ cand_v, float* __restrict__ tau_out) {
@@ -237,6 +243,8 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
     constexpr int NSLOT = ring_slots_for(NS, LCAP);
     static_assert(NSLOT >= 2, "LDS ring");
     static_assert(LCAP <= 64 && LCAP > KS, "one list entry per lane during compaction");
+    static_assert(NCONS % NSERV == 0 && (NCONS / NSERV) % 2 == 0, "a service wave's consumers: whole groups of 64 queries");
+    static_assert((QCAP & (QCAP - 1)) == 0 && QCAP >= 64, "queue positions wrap by masking; one group can hold 64 records");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem;                                                                           // [NSLOT][2][TILE_BYTES]
@@ -244,8 +252,12 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
     float* qvals = reinterpret_cast<float*>(lists + NQ * LCAP);                                   // [NCONS][QCAP][4]
     uint32_t* qtags = reinterpret_cast<uint32_t*>(qvals + NCONS * QCAP * 4);                      // [NCONS][QCAP]
     int* cnt = reinterpret_cast<int*>(qtags + NCONS * QCAP);                                      // [NQ]
-    int* ready = cnt + NQ;                                                                        // [NSLOT]
-    int* done = ready + NSLOT;                                                                    // [NSLOT][NCONS]
+    float* tauL = reinterpret_cast<float*>(cnt + NQ);  // [NQ] thresholds as the service waves last published them
+    int* ready = reinterpret_cast<int*>(tauL + NQ);    // [NSLOT]
+    int* done = ready + NSLOT;                         // [NSLOT][NCONS]
+    int* wrL = done + NSLOT * NCONS;                   // [NCONS] records pushed so far (written by the consumer)
+    int* rdL = wrL + NCONS;                            // [NCONS] records worked off so far (written by its service wave)
+    int* stL = rdL + NCONS;  // [NCONS] consumer state: 0 sweeping, 1 waiting for room in its queue, 2 through
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: branches on it are scalar
@@ -263,11 +275,134 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
     const int ntiles = (r_end - r_begin) >> 5;  // even: ranges are multiples of 64 rows
     const int nslots = ntiles >> 1;
     const int out_chunk = out_chunk0 + rng;
-    if (tid < NSLOT * (1 + NCONS)) ready[tid] = 0;  // ready[] and done[] are contiguous
-    if (tid < NQ) cnt[tid] = 0;
+    if (tid < NSLOT * (1 + NCONS) + 3 * NCONS) ready[tid] = 0;  // ready[], done[], wrL[], rdL[], stL[] are contiguous
+    if (tid < NQ) {
+        cnt[tid] = 0;
+        tauL[tid] = (!SAMPLE && tau_g) ? orderable_f32(tau_g[qblock * NQ + tid]) : __builtin_inff();
+    }
     __syncthreads();
+    const bool shared_tau = !SAMPLE && tau_g != nullptr && nrng > 1;
 
-    if (wave >= NCONS) {
+#ifdef BMX_STAMPS
+    unsigned long long dbg_ncomp = 0, dbg_comp = 0, dbg_rounds = 0;
+#endif
+    // (every lambda of this kernel is force-inlined: left to its own devices the compiler turned `compact` and
+    // `drain` into real calls once they grew -- their captures then live in scratch and every LDS atomic becomes
+    // a flat one.)
+    // ---- compaction of query jj's list (jj wave-uniform) of consumer c: cut it back to about KS entries,
+    // tighten the threshold.  The cut need not sit exactly at rank KS: any entry with at least KS - 1 smaller
+    // ones is a valid new threshold (everything above it is dropped, at least KS stay).  BMX_NPIV entries from
+    // fixed, evenly spread places of the (unordered) list are tried at once -- independent readlane / compare /
+    // popcount chains instead of a dependent chain of quickselect rounds -- and the one that keeps the fewest,
+    // at least KS, wins.  Only when none qualifies or the best would free too little does the exact quickselect
+    // run.
+    auto compact = [&](const int c, const int jj, const bool exact) __attribute__((always_inline)) {
+        unsigned long long* mylists = lists + c * 32 * LCAP;
+        int* mycnt = cnt + c * 32;
+        const int n_raw = __builtin_amdgcn_readfirstlane(lds_load_volatile(&mycnt[jj]));
+        const int n = n_raw < LCAP ? n_raw : LCAP;
+        if (n <= KS) return;
+#ifdef BMX_STAMPS
+        const unsigned long long c0 = STAMP();
+        ++dbg_ncomp;
+#endif
+        const unsigned long long raw = lane < n ? mylists[jj * LCAP + lane] : 0ull;
+        // 31-bit rank key: order-preserving image of the value with its low bits replaced by the lane number
+        // (unique keys; values closer than 2^-17 relative may swap places at the cut, see below)
+        const uint32_t key =
+            lane < n ? (((f32_orderable(__uint_as_float((uint32_t)(raw >> 32))) >> 1) & ~63u) | (uint32_t)lane)
+                     : 0x7FFFFFFFu;
+        unsigned long long M = 0;
+        int pl = 0, kept = 0x7FFFFFFF;
+        uint32_t pk = 0;
+#pragma unroll
+        for (int i = 0; i < BMX_NPIV; ++i) {
+            const int pv = ((2 * i + 1) * n) / (2 * BMX_NPIV);  // < n
+            const uint32_t k_i = (uint32_t)__builtin_amdgcn_readlane((int)key, pv);
+            const unsigned long long m_i = __builtin_amdgcn_ballot_w64(key < k_i);
+            const int c_i = __builtin_popcountll(m_i);
+            if (c_i >= KS - 1 && c_i < kept) {
+                kept = c_i;
+                M = m_i;
+                pl = pv;
+                pk = k_i;
+            }
+        }
+        if (exact ? kept != KS - 1 : kept > KS + 11) {
+            // quickselect for the key with exactly KS - 1 smaller keys; B = lanes that can still be it
+            unsigned long long B = n == 64 ? ~0ull : ((1ull << n) - 1ull);
+            if (kept != 0x7FFFFFFF) B &= M;  // below the best pivot found
+            int it = 0;
+            for (;;) {
+                const int rot = (it * 29 + jj * 7) & 63;  // pivots from changing places
+                ++it;
+                const unsigned long long Br = B >> rot;
+                pl = Br ? rot + __builtin_ctzll(Br) : __builtin_ctzll(B);
+                pk = (uint32_t)__builtin_amdgcn_readlane((int)key, pl);
+                M = __builtin_amdgcn_ballot_w64(key < pk);
+                const int cc = __builtin_popcountll(M);
+                if (cc == KS - 1) break;
+                if (cc > KS - 1)
+                    B &= M;
+                else
+                    B &= ~M & ~(1ull << pl);
+            }
+            kept = KS - 1;
+#ifdef BMX_STAMPS
+            dbg_rounds += it;
+#endif
+        }
+        const unsigned long long keep = M | (1ull << pl);  // kept + 1 lanes, at least KS
+        // the new threshold: the cut key with its lane bits cleared, which is <= the value of everything
+        // dropped, so "rejected => value >= threshold" holds exactly
+        const float newtau = orderable_f32((pk & ~63u) << 1);
+        const int pos = mbcnt64(keep);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // every lane holds its entry before slots are rewritten
+        if ((keep >> lane) & 1ull) mylists[jj * LCAP + pos] = raw;
+        if (lane == 0) mycnt[jj] = kept + 1;
+        if (lane == jj) {
+            const float told = tauL[c * 32 + jj];
+            tauL[c * 32 + jj] = newtau < told ? newtau : told;  // the consumer picks it up at its next slot
+            if (shared_tau) atomicMin(&tau_g[qblock * NQ + c * 32 + jj], f32_orderable(newtau));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#ifdef BMX_STAMPS
+        dbg_comp += STAMP() - c0;
+#endif
+    };
+
+    // ---- final lists [j0, j1) of consumer c out (its queue is empty, nothing appends any more)
+    auto out_lists = [&](const int c, const int j0, const int j1) __attribute__((always_inline)) {
+        unsigned long long* mylists = lists + c * 32 * LCAP;
+        int* mycnt = cnt + c * 32;
+        for (int jj = j0; jj < j1; ++jj) compact(c, jj, true);  // the output holds exactly KS entries per list
+        for (int jj = j0; jj < j1; ++jj) {
+            const int qq = qblock * NQ + c * 32 + jj;
+            const int n = __builtin_amdgcn_readfirstlane(lds_load_volatile(&mycnt[jj]));  // <= KS now
+            // what this range rejected was rejected against thresholds >= the final working threshold (the consumer
+            // filters with a copy of its service wave's threshold, never a tighter one); kept entries at or above it
+            // are as good as rejected (another range holds KS better ones): dropped here
+            const float eff = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane(
+                (int)__float_as_uint(__hip_atomic_load(&tauL[c * 32 + jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))));
+            if (lane < KS) {
+                const unsigned long long e = lane < n ? mylists[jj * LCAP + lane] : 0ull;
+                const float val = __uint_as_float((uint32_t)(e >> 32));
+                const bool keep = lane < n && (val < eff || nrng == 1);
+                const int64_t o = ((int64_t)qq * out_nchunks + out_chunk) * KS + lane;
+                cand[o] = keep ? (int32_t)(uint32_t)e : -1;
+                cand_v[o] = lane < n ? val : __builtin_inff();
+            }
+            if (lane == 0) tau_out[(int64_t)qq * out_nchunks + out_chunk] = eff;
+            if (nrng == 1) {  // a whole-reference item owns every list column of its queries: the others stay empty
+                for (int cc = 1; cc < out_nchunks; ++cc) {
+                    if (lane < KS) cand[((int64_t)qq * out_nchunks + out_chunk + cc) * KS + lane] = -1;
+                    if (lane == 0) tau_out[(int64_t)qq * out_nchunks + out_chunk + cc] = __builtin_inff();
+                }
+            }
+        }
+    };
+
+    if (wave >= NCONS && wave < NCONS + NPROD) {
         // ------------------------------------------------------------------ producer (as in knn_bf16.hip)
 #ifdef BMX_EXP_PPRIO
         __builtin_amdgcn_s_setprio(BMX_EXP_PPRIO);
@@ -302,8 +437,7 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
             // same wave, in-order LDS queue: the flag lands after the tiles
             if (lane == 0) __hip_atomic_store(&ready[pos], sl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         };
-        // two register sets: the loads of slot sl + 4 are in flight while slot sl is handed over (16 tiles in flight
-        // per workgroup)
+        // two register sets: the loads of slot sl + NPROD are in flight while slot sl is handed over
         int sl = p;
         if (sl < nslots) load(ra, sl);
         if (sl + NPROD < nslots) load(rb, sl + NPROD);
@@ -327,11 +461,177 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
         return;
     }
 
+    if (wave >= NCONS + NPROD) {
+        // ------------------------------------------------------------------ service wave: works off the spill queues
+        // of CPS consumer waves while they sweep -- re-test, append to the lists, compact, publish the thresholds --
+        // so that a consumer's own instruction stream holds the filter and the spill only
+        if constexpr (SAMPLE) {
+            return;
+        } else {
+            __builtin_amdgcn_s_setprio(BMX_SPRIO);
+            constexpr int CPS = NCONS / NSERV;
+            const int c0 = (wave - NCONS - NPROD) * CPS;
+#ifdef BMX_STAMPS
+            unsigned long long dbg_drain = 0, dbg_ndrain = 0, dbg_idle = 0;
+            const unsigned long long dbg_t0 = STAMP();
+#endif
+            // ---- one drain pass: up to 32 records (128 values) of consumer c's queue, from position r0.  Every lane
+            // takes one value of a record of the first half and one of the second (two independent chains of LDS read ->
+            // the query's threshold -> LDS atomic slot -> store, issued together).
+            auto drain = [&](const int c, const int r0, const int n) __attribute__((always_inline)) {
+#ifdef BMX_STAMPS
+                const unsigned long long d0 = STAMP();
+                ++dbg_ndrain;
+#endif
+                unsigned long long* mylists = lists + c * 32 * LCAP;
+                int* mycnt = cnt + c * 32;
+                const float* qv = qvals + c * QCAP * 4;
+                const uint32_t* qt = qtags + c * QCAP;
+                const float* mytau = tauL + c * 32;
+                bool pend[2];
+                uint32_t tag[2];
+                float v[2];
+#pragma unroll
+                for (int x = 0; x < 2; ++x) {
+                    const int rec = 16 * x + (lane >> 2);
+                    const int at = (r0 + rec) & (QCAP - 1);
+                    pend[x] = rec < n;
+                    tag[x] = qt[at];
+                    v[x] = qv[(at << 2) + (lane & 3)];
+                }
+                // the records are on their way into registers: their queue positions are free again (the store queues
+                // up behind the reads in this wave's in-order LDS queue)
+                __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                if (lane == 0) __hip_atomic_store(&rdL[c], r0 + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                int jq[2], ref[2];
+#pragma unroll
+                for (int x = 0; x < 2; ++x) {
+                    const int srcl = tag[x] & 63;  // the lane that spilled the record: query srcl & 31, row half srcl >> 5
+                    jq[x] = srcl & 31;
+                    ref[x] = r_begin + ((int)(tag[x] >> 8) << 5) + (int)((tag[x] >> 6) & 3u) * 8 + (srcl >> 5) * 4 +
+                             (lane & 3);
+                }
+                for (;;) {
+                    float tq[2];
+                    int slot[2];
+#pragma unroll
+                    for (int x = 0; x < 2; ++x)
+                        tq[x] = __hip_atomic_load(&mytau[jq[x]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+                    for (int x = 0; x < 2; ++x) {
+                        pend[x] = pend[x] && v[x] < tq[x];
+                        slot[x] = LCAP;
+                        if (pend[x]) slot[x] = atomicAdd(&mycnt[jq[x]], 1);  // ds_add_rtn_u32
+                    }
+#pragma unroll
+                    for (int x = 0; x < 2; ++x)
+                        if (slot[x] < LCAP) {
+                            mylists[jq[x] * LCAP + slot[x]] =
+                                ((unsigned long long)__float_as_uint(v[x]) << 32) | (uint32_t)ref[x];
+                            pend[x] = false;
+                        }
+                    unsigned long long ov0 = __builtin_amdgcn_ballot_w64(pend[0]);
+                    unsigned long long ov1 = __builtin_amdgcn_ballot_w64(pend[1]);
+                    if ((ov0 | ov1) == 0) break;
+                    // full lists: cut them back (the threshold drops), then the lanes left over try again
+                    while (ov0 | ov1) {
+                        const int qq = ov0 ? __builtin_amdgcn_readlane(jq[0], __builtin_ctzll(ov0))
+                                           : __builtin_amdgcn_readlane(jq[1], __builtin_ctzll(ov1));
+                        compact(c, qq, false);
+                        ov0 &= ~__builtin_amdgcn_ballot_w64(jq[0] == qq);
+                        ov1 &= ~__builtin_amdgcn_ballot_w64(jq[1] == qq);
+                    }
+                }
+                // lists about to fill are cut back now, so that the appends of the next pass rarely find one full
+                const int cn = lane < 32 ? lds_load_volatile(&mycnt[lane]) : 0;
+                unsigned long long need = __builtin_amdgcn_ballot_w64(cn > LCAP - HEAD);
+                while (need) {
+                    const int jj = __builtin_ctzll(need);
+                    need &= need - 1;
+                    compact(c, jj, false);
+                }
+#ifdef BMX_STAMPS
+                dbg_drain += STAMP() - d0;
+#endif
+            };
+
+            uint32_t finmask = 0;  // bit s: consumer c0 + s is through and its final lists are out
+            uint32_t tau_fetch[(CPS * 32 + 63) / 64];
+#pragma unroll
+            for (int x = 0; x < (CPS * 32 + 63) / 64; ++x) tau_fetch[x] = 0xFFFFFFFFu;
+            int iter = 0;
+            for (;;) {
+                bool worked = false;
+#pragma nounroll
+                for (int s = 0; s < CPS; ++s) {
+                    if ((finmask >> s) & 1u) continue;
+                    const int c = c0 + s;
+                    // the consumer writes its last record count before the "through" state: read in the opposite order
+                    const int st = __builtin_amdgcn_readfirstlane(lds_load_volatile(&stL[c]));
+                    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                    const int w = __builtin_amdgcn_readfirstlane(lds_load_volatile(&wrL[c]));
+                    const int r = __builtin_amdgcn_readfirstlane(lds_load_volatile(&rdL[c]));  // this wave's own word
+                    const int avail = w - r;
+                    // a short queue is left to grow (a pass costs the same for 1 record as for 32) unless its consumer
+                    // waits for room or is through
+                    if (avail >= DRAIN_MIN || (st != 0 && avail > 0)) {
+                        drain(c, r, avail < 32 ? avail : 32);
+                        worked = true;
+                    } else if (st == 2) {
+                        // nothing will be appended any more: the consumer wave writes the first EPI_CONS final lists out
+                        // itself, this wave the rest
+                        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                        if (lane == 0) __hip_atomic_store(&stL[c], 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        out_lists(c, EPI_CONS, 32);
+                        finmask |= 1u << s;
+                        worked = true;
+                    }
+                }
+                if (finmask == (1u << CPS) - 1u) break;
+                if (shared_tau) {
+                    // thresholds other ranges have reached: the (L1-bypassing) loads are issued in one round of the loop
+                    // and looked at in the next, so nobody waits for the round trip
+                    ++iter;
+#pragma unroll
+                    for (int x = 0; x < (CPS * 32 + 63) / 64; ++x) {
+                        const int qi = c0 * 32 + x * 64 + lane;  // query of the block (CPS * 32 is a multiple of 64)
+                        if ((iter & 15) == 1) {
+                            const float t = orderable_f32(tau_fetch[x]);
+                            if (t < tauL[qi]) tauL[qi] = t;
+                        }
+                        if ((iter & 15) == 0)
+                            tau_fetch[x] = __hip_atomic_load(&tau_g[qblock * NQ + qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                if (!worked) {
+                    __builtin_amdgcn_s_sleep(BMX_PSLEEP);
+#ifdef BMX_STAMPS
+                    ++dbg_idle;
+#endif
+                }
+            }
+#ifdef BMX_STAMPS
+            if (lane == 0) {
+                atomicAdd(&bmx_dbg16[2], dbg_drain);
+                atomicAdd(&bmx_dbg16[3], dbg_ndrain);
+                atomicAdd(&bmx_dbg16[4], dbg_ncomp);
+                atomicAdd(&bmx_dbg16[5], dbg_comp);
+                atomicAdd(&bmx_dbg16[11], dbg_rounds);
+                atomicAdd(&bmx_dbg16[13], STAMP() - dbg_t0);
+                atomicAdd(&bmx_dbg16[14], 1ull);
+                atomicAdd(&bmx_dbg16[15], dbg_idle);
+            }
+#endif
+            return;
+        }
+    }
+
     // ---------------------------------------------------------------------- consumer
     const int j = lane & 31, h = lane >> 5;
     const int q = qblock * NQ + wave * 32 + j;
 
-    float tau = (!SAMPLE && tau_g) ? orderable_f32(tau_g[q]) : __builtin_inff();
+    float tau = tauL[wave * 32 + j];
 
     f16x8 bq[NS];
     {
@@ -340,195 +640,22 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
         for (int s = 0; s < NS; ++s) bq[s] = __builtin_bit_cast(f16x8, src[s]);
     }
 
-    unsigned long long* mylists = lists + wave * 32 * LCAP;  // this wave's 32 lists
-    int* mycnt = cnt + wave * 32;
     float* qv = qvals + wave * QCAP * 4;
     uint32_t* qt = qtags + wave * QCAP;
-    int qcount = 0;  // records in the queue (wave-uniform)
-    const bool shared_tau = !SAMPLE && tau_g != nullptr && nrng > 1;
+    int wr = 0;       // records pushed so far (wave-uniform)
+    int rd_seen = 0;  // what the service wave had worked off when last looked at
 #ifdef BMX_STAMPS
-    unsigned long long dbg_spin = 0, dbg_drain = 0, dbg_ndrain = 0, dbg_ncomp = 0, dbg_evt = 0, dbg_grp = 0, dbg_evc = 0,
-                       dbg_comp = 0, dbg_rounds = 0;
+    unsigned long long dbg_spin = 0, dbg_evt = 0, dbg_grp = 0, dbg_evc = 0, dbg_qwait = 0;
     const unsigned long long dbg_t0 = STAMP();
 #endif
-
-    // (every lambda of this kernel is force-inlined: left to its own devices the compiler turned `compact` and `drain`
-    // into real calls once they grew -- their captures then live in scratch and every LDS atomic becomes a flat one.)
-    // ---- compaction of query jj's list (jj wave-uniform): cut it back to about KS entries, tighten the threshold.
-    // The cut need not sit exactly at rank KS: any entry with at least KS - 1 smaller ones is a valid new threshold
-    // (everything above it is dropped, at least KS stay).  Eight entries from fixed, evenly spread places of the
-    // (unordered) list are tried at once -- eight independent readlane / compare / popcount chains instead of a
-    // dependent chain of quickselect rounds -- and the one that keeps the fewest, at least KS, wins: on average KS + 3
-    // stay.  Only when none qualifies (all eight below rank KS: ~1 %) or the best would free too little does the exact
-    // quickselect run.
-    auto compact = [&](const int jj, const bool exact = false) __attribute__((always_inline)) {
-        const int n_raw = __builtin_amdgcn_readfirstlane(lds_load_volatile(&mycnt[jj]));
-        const int n = n_raw < LCAP ? n_raw : LCAP;
-        if (n <= KS) return;
-#ifdef BMX_STAMPS
-        const unsigned long long c0 = STAMP();
-        ++dbg_ncomp;
-#endif
-        const unsigned long long raw = lane < n ? mylists[jj * LCAP + lane] : 0ull;
-        // 31-bit rank key: order-preserving image of the value with its low bits replaced by the lane number
-        // (unique keys; values closer than 2^-17 relative may swap places at the cut, see below)
-        const uint32_t key =
-            lane < n ? (((f32_orderable(__uint_as_float((uint32_t)(raw >> 32))) >> 1) & ~63u) | (uint32_t)lane)
-                     : 0x7FFFFFFFu;
-        unsigned long long M = 0;
-        int pl = 0, kept = 0x7FFFFFFF;
-        uint32_t pk = 0;
-#pragma unroll
-        for (int i = 0; i < BMX_NPIV; ++i) {
-            const int p = ((2 * i + 1) * n) / (2 * BMX_NPIV);  // < n
-            const uint32_t k_i = (uint32_t)__builtin_amdgcn_readlane((int)key, p);
-            const unsigned long long m_i = __builtin_amdgcn_ballot_w64(key < k_i);
-            const int c_i = __builtin_popcountll(m_i);
-            if (c_i >= KS - 1 && c_i < kept) {
-                kept = c_i;
-                M = m_i;
-                pl = p;
-                pk = k_i;
-            }
-        }
-        if (exact ? kept != KS - 1 : kept > KS + 11) {
-            // quickselect for the key with exactly KS - 1 smaller keys; B = lanes that can still be it
-            unsigned long long B = n == 64 ? ~0ull : ((1ull << n) - 1ull);
-            if (kept != 0x7FFFFFFF) B &= M;  // below the best pivot found
-            int it = 0;
-            for (;;) {
-                const int rot = (it * 29 + jj * 7) & 63;  // pivots from changing places
-                ++it;
-                const unsigned long long Br = B >> rot;
-                pl = Br ? rot + __builtin_ctzll(Br) : __builtin_ctzll(B);
-                pk = (uint32_t)__builtin_amdgcn_readlane((int)key, pl);
-                M = __builtin_amdgcn_ballot_w64(key < pk);
-                const int c = __builtin_popcountll(M);
-                if (c == KS - 1) break;
-                if (c > KS - 1)
-                    B &= M;
-                else
-                    B &= ~M & ~(1ull << pl);
-            }
-            kept = KS - 1;
-#ifdef BMX_STAMPS
-            dbg_rounds += it;
-#endif
-        }
-        const unsigned long long keep = M | (1ull << pl);  // kept + 1 lanes, at least KS
-        // the new threshold: the cut key with its lane bits cleared, which is <= the value of everything dropped,
-        // so "rejected => value >= threshold" holds exactly
-        const float newtau = orderable_f32((pk & ~63u) << 1);
-        const int pos = mbcnt64(keep);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // every lane holds its entry before slots are rewritten
-        if ((keep >> lane) & 1ull) mylists[jj * LCAP + pos] = raw;
-        if (lane == 0) mycnt[jj] = kept + 1;
-        if (lane == jj || lane == jj + 32) tau = newtau < tau ? newtau : tau;
-        if (shared_tau && lane == jj) atomicMin(&tau_g[q], f32_orderable(newtau));  // lane jj's q is query jj's
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#ifdef BMX_STAMPS
-        dbg_comp += STAMP() - c0;
-#endif
-    };
-
-    // ---- drain: work off the spill queue.  32 records = 128 values per pass: every lane takes one value of a record
-    // of the first half and one of the second (two independent chains of LDS read -> threshold of the owning lane by
-    // ds_bpermute -> LDS atomic slot -> store, issued together).  The wave holds the ring up while it is here, so it
-    // runs at the highest issue priority.
-    auto drain = [&]() __attribute__((always_inline)) {
-#ifdef BMX_STAMPS
-        const unsigned long long d0 = STAMP();
-        ++dbg_ndrain;
-#endif
-        __builtin_amdgcn_s_setprio(3);
-        const int n = qcount;
-        for (int base = 0; base < n; base += 32) {
-            bool pend[2];
-            uint32_t tag[2];
-            float v[2];
-#pragma unroll
-            for (int x = 0; x < 2; ++x) {
-                const int rec = base + 16 * x + (lane >> 2);
-                pend[x] = rec < n;
-                tag[x] = qt[pend[x] ? rec : 0];
-                v[x] = qv[((base + 16 * x) << 2) + lane];
-            }
-            int jq[2], srcl[2], ref[2];
-#pragma unroll
-            for (int x = 0; x < 2; ++x) {
-                srcl[x] = tag[x] & 63;  // the lane that spilled the record: query srcl & 31, row half srcl >> 5
-                jq[x] = srcl[x] & 31;
-                ref[x] = r_begin + ((int)(tag[x] >> 8) << 5) + (int)((tag[x] >> 6) & 3u) * 8 + (srcl[x] >> 5) * 4 +
-                         (lane & 3);
-            }
-            for (;;) {
-                float tq[2];
-                int slot[2];
-#pragma unroll
-                for (int x = 0; x < 2; ++x)
-                    tq[x] = __uint_as_float(
-                        (uint32_t)__builtin_amdgcn_ds_bpermute(srcl[x] << 2, (int)__float_as_uint(tau)));
-#pragma unroll
-                for (int x = 0; x < 2; ++x) {
-                    pend[x] = pend[x] && v[x] < tq[x];
-                    slot[x] = LCAP;
-                    if (pend[x]) slot[x] = atomicAdd(&mycnt[jq[x]], 1);  // ds_add_rtn_u32
-                }
-#pragma unroll
-                for (int x = 0; x < 2; ++x)
-                    if (slot[x] < LCAP) {
-                        mylists[jq[x] * LCAP + slot[x]] =
-                            ((unsigned long long)__float_as_uint(v[x]) << 32) | (uint32_t)ref[x];
-                        pend[x] = false;
-                    }
-                unsigned long long ov0 = __builtin_amdgcn_ballot_w64(pend[0]);
-                unsigned long long ov1 = __builtin_amdgcn_ballot_w64(pend[1]);
-                if ((ov0 | ov1) == 0) break;
-                // full lists: cut them back (the threshold drops), then the lanes left over try again
-                while (ov0 | ov1) {
-                    const int qq = ov0 ? __builtin_amdgcn_readlane(jq[0], __builtin_ctzll(ov0))
-                                       : __builtin_amdgcn_readlane(jq[1], __builtin_ctzll(ov1));
-                    compact(qq);
-                    ov0 &= ~__builtin_amdgcn_ballot_w64(jq[0] == qq);
-                    ov1 &= ~__builtin_amdgcn_ballot_w64(jq[1] == qq);
-                }
-            }
-        }
-        qcount = 0;
-        // lists about to fill are cut back now, so that the appends of the next drain rarely find one full
-        const int c = lane < 32 ? lds_load_volatile(&mycnt[lane]) : 0;
-#ifdef BMX_EXP_ONECOMPACT
-        // one list per drain ahead of time (the fullest first would need a reduction: the first found will do), the rest
-        // only when they are really full
-        unsigned long long need = __builtin_amdgcn_ballot_w64(c > LCAP - HEAD);
-        const unsigned long long crit = __builtin_amdgcn_ballot_w64(c > LCAP - 2);
-        if (need) {
-            const int first = __builtin_ctzll(crit ? crit : need);
-            need = crit | (1ull << first);
-        }
-#else
-        unsigned long long need = __builtin_amdgcn_ballot_w64(c > LCAP - HEAD);
-#endif
-        while (need) {
-            const int jj = __builtin_ctzll(need);
-            need &= need - 1;
-            compact(jj);
-        }
-        if (wave >= NCONS / 2)
-            __builtin_amdgcn_s_setprio(1);
-        else
-            __builtin_amdgcn_s_setprio(0);
-#ifdef BMX_STAMPS
-        dbg_drain += STAMP() - d0;
-#endif
-    };
 
     // Hand-over, once per slot (two tiles).  While the tiles of slot sl compute, their fragment registers are refilled
     // from slot sl + 1 (each register right after the MFMA that consumed it); the ready word of slot sl + 1 is checked
     // before the first refill (it was polled a slot earlier: no LDS round trip in steady state), and after the last
     // refill the wave stores "read up to sl + 1" in its done word -- queued behind the reads in the wave's in-order LDS
-    // queue, so the producers cannot overwrite them early -- and polls the ready word of slot sl + 2.
-    uint32_t tau_fetch = 0xFFFFFFFFu;
+    // queue, so the producers cannot overwrite them early -- and polls the ready word of slot sl + 2 and its queries'
+    // thresholds as the service wave has them now.
+    float tau_next = tau;
     int seen = 0;
     int pos_n = 0;  // ring position of the slot to read next
     auto spin_until_staged = [&](int slot) __attribute__((always_inline)) {
@@ -545,18 +672,19 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
 #endif
         }
     };
+    auto lane0_store = [&](int* word, const int val) __attribute__((always_inline)) {
+        // EXEC is all ones here (uniform control flow), so it is narrowed and restored with two scalar moves instead of
+        // a compare / saveexec / branch sequence
+        typedef __attribute__((address_space(3))) int* lds_iptr;
+        const lds_iptr dp = (lds_iptr)word;
+        asm volatile("s_mov_b64 exec, 1\n\tds_write_b32 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(dp), "v"(val) : "memory");
+    };
     auto hand_back = [&](int slot) __attribute__((always_inline)) {
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
-        {
-            // lane 0 stores the done word: EXEC is all ones here (uniform control flow), so it is narrowed and restored
-            // with two scalar moves instead of a compare / saveexec / branch sequence
-            typedef __attribute__((address_space(3))) int* lds_iptr;
-            const lds_iptr dp = (lds_iptr)&done[pos_n * NCONS + wave];
-            const int val = slot + 1;
-            asm volatile("s_mov_b64 exec, 1\n\tds_write_b32 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(dp), "v"(val) : "memory");
-        }
+        lane0_store(&done[pos_n * NCONS + wave], slot + 1);
         pos_n = pos_n + 1 == NSLOT ? 0 : pos_n + 1;
         seen = lds_load_volatile(&ready[pos_n]);
+        if constexpr (!SAMPLE) tau_next = __hip_atomic_load(&tauL[wave * 32 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
 
     f32x4 a[NS], b[NS];  // fragments of the even / odd tile of the current slot
@@ -570,6 +698,26 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
 #pragma unroll
         for (int i = (SAMPLE ? KS / 2 : 1) - 1; i > 0; --i) best[i] = __builtin_amdgcn_fmed3f(best[i - 1], best[i], x);
         best[0] = fminf(fminf(best[0], x), x);
+    };
+
+    // room for `need` (<= QCAP) more records: the service wave's progress is looked at only when the last known state
+    // does not leave enough
+    auto wait_room = [&](const int need) __attribute__((always_inline)) {
+#ifdef BMX_STAMPS
+        const unsigned long long w0 = STAMP();
+#endif
+        rd_seen = __builtin_amdgcn_readfirstlane(lds_load_volatile(&rdL[wave]));
+        if (wr + need - rd_seen > QCAP) {
+            lane0_store(&stL[wave], 1);  // "waiting": the service wave works the queue off whatever its length
+            do {
+                __builtin_amdgcn_s_sleep(1);
+                rd_seen = __builtin_amdgcn_readfirstlane(lds_load_volatile(&rdL[wave]));
+            } while (wr + need - rd_seen > QCAP);
+            lane0_store(&stL[wave], 0);
+        }
+#ifdef BMX_STAMPS
+        dbg_qwait += STAMP() - w0;
+#endif
     };
 
     // One step = the MFMA chain of tile t (fragments in `f`) into `cur`; in its gaps the refill of each fragment
@@ -603,9 +751,8 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
         const float mn = fminf(fminf(fminf(fminf(g[0], g[1]), g[2]), g[3]), tau);
         unsigned long long any = 0;
         if constexpr (SAMPLE) {
-            // sorted insertion on the order-preserving integer images (see knn_bf16.hip) of ONE candidate per slot: the
-            // lane's minimum over both tiles of the slot (32 references of one query; still one distinct reference per
-            // candidate, half the insertions)
+            // sorted insertion of ONE candidate per slot: the lane's minimum over both tiles of the slot (32 references
+            // of one query; still one distinct reference per candidate, half the insertions)
             if (half == 0) {
                 sample_mn = mn;
             } else {
@@ -635,11 +782,12 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
         ++dbg_evt;
         const unsigned long long dbg_e0 = STAMP();
 #endif
-        // ---- spill the groups with survivors of tile t - 1
+        // ---- spill the groups with survivors of tile t - 1: four raw values and a tag per (lane, group) into the
+        // wave's queue; the service wave takes it from there
         const uint32_t tagbase = ((uint32_t)(t - 1) << 8) | (uint32_t)lane;
         auto spill = [&](const int u, const unsigned long long m) __attribute__((always_inline)) {
             if (g[u] < tau) {  // the lanes of m
-                const int slot = qcount + mbcnt64(m);
+                const int slot = (wr + mbcnt64(m)) & (QCAP - 1);
                 f32x4 rec;
                 rec[0] = prev[4 * u];
                 rec[1] = prev[4 * u + 1];
@@ -648,7 +796,7 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
                 *reinterpret_cast<f32x4*>(qv + slot * 4) = rec;
                 qt[slot] = tagbase | ((uint32_t)u << 6);
             }
-            qcount += __builtin_popcountll(m);
+            wr += __builtin_popcountll(m);
 #ifdef BMX_STAMPS
             ++dbg_grp;
 #endif
@@ -660,30 +808,34 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
             m[u] = __builtin_amdgcn_ballot_w64(g[u] < tau);
             tot += __builtin_popcountll(m[u]);
         }
-        if (qcount + tot > QSOFT) {
-            drain();  // may tighten thresholds: the masks are taken again
-            tot = 0;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                m[u] = __builtin_amdgcn_ballot_w64(g[u] < tau);
-                tot += __builtin_popcountll(m[u]);
-            }
+        if (wr + tot - rd_seen > QCAP) {
             if (tot > QCAP) {
-                // the first tiles of a sweep that starts without a threshold: one group (<= 64 records) at a time
+                // the first tiles of a sweep that starts without a threshold: one group (<= 64 records) at a time, each
+                // against the threshold as it stands by then
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
+                    wait_room(QCAP);  // (the queue is empty: everything pushed so far has had its effect on the threshold)
+                    const float tl = __hip_atomic_load(&tauL[wave * 32 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    tau = tl < tau ? tl : tau;
                     const unsigned long long mu = __builtin_amdgcn_ballot_w64(g[u] < tau);
                     if (mu) {
                         spill(u, mu);
-                        drain();
+                        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                        lane0_store(&wrL[wave], wr);
                     }
                 }
+#ifdef BMX_STAMPS
+                dbg_evc += STAMP() - dbg_e0;
+#endif
                 return;
             }
+            wait_room(tot);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
             if (m[u]) spill(u, m[u]);
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        lane0_store(&wrL[wave], wr);  // queued behind the records in the wave's in-order LDS queue
 #ifdef BMX_STAMPS
         dbg_evc += STAMP() - dbg_e0;
 #endif
@@ -697,8 +849,7 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
 #ifndef BMX_EXP_NOCPRIO
     if (wave >= NCONS / 2) __builtin_amdgcn_s_setprio(1);
 #endif
-    // the query fragments have arrived: said here once, so that the waits the compiler places in the loop concern the
-    // threshold refresh alone (it would otherwise keep a vmcnt(0) in front of the MFMAs for these very loads)
+    // the query fragments have arrived: said here once, so that the compiler keeps no vmcnt wait for them in the loop
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     if (nslots > 0) {
         spin_until_staged(0);
@@ -715,16 +866,8 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
         // steps 0 .. ntiles: step t multiplies tile t (step ntiles: an empty tile, product unused) and filters tile
         // t - 1; one slot = two steps per iteration, so the two accumulators and the two fragment sets alternate statically
         for (int sl = 0; sl <= nslots; ++sl) {
-            if constexpr (!SAMPLE) {
-                // periodic refresh of the shared threshold: the (L1-bypassing) load is issued here and looked at one
-                // iteration later, so nobody waits for the round trip
-                if (shared_tau) {
-                    if ((sl & 7) == 1) tau = fminf(tau, orderable_f32(tau_fetch));
-                    if ((sl & 7) == 0)
-                        tau_fetch = __hip_atomic_load(&tau_g[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the fragments of this slot and the ready word of the next
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the fragments of this slot, the ready word of the next, tau
+            if constexpr (!SAMPLE) tau = fminf(fminf(tau, tau_next), tau_next);
             spin_until_staged(sl + 1);
             __atomic_signal_fence(__ATOMIC_SEQ_CST);
             step(accA, accB, a, 2 * sl, 0);
@@ -745,48 +888,25 @@ __global__ __launch_bounds__((NCONS + NPROD) * 64) void knn_topk_f16(
             atomicAdd(&bmx_dbg16[9], 1ull);
         }
 #endif
-        return;
     } else {
-        drain();
-        for (int jj = 0; jj < 32; ++jj) compact(jj, true);  // the output holds exactly KS entries per list
+        // everything is in the queue: once the service wave has worked it off, both write final lists out
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        lane0_store(&stL[wave], 2);
+        while (__builtin_amdgcn_readfirstlane(lds_load_volatile(&stL[wave])) != 3) __builtin_amdgcn_s_sleep(2);
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        out_lists(wave, 0, EPI_CONS);
 #ifdef BMX_STAMPS
         if (lane == 0) {
             atomicAdd(&bmx_dbg16[0], STAMP() - dbg_t0);
             atomicAdd(&bmx_dbg16[1], dbg_spin);
-            atomicAdd(&bmx_dbg16[2], dbg_drain);
-            atomicAdd(&bmx_dbg16[3], dbg_ndrain);
-            atomicAdd(&bmx_dbg16[4], dbg_ncomp);
-            atomicAdd(&bmx_dbg16[5], dbg_comp);
             atomicAdd(&bmx_dbg16[6], dbg_evt);
             atomicAdd(&bmx_dbg16[7], dbg_grp);
             atomicAdd(&bmx_dbg16[8], (unsigned long long)ntiles);
             atomicAdd(&bmx_dbg16[9], 1ull);
             atomicAdd(&bmx_dbg16[10], dbg_evc);
-            atomicAdd(&bmx_dbg16[11], dbg_rounds);
+            atomicAdd(&bmx_dbg16[12], dbg_qwait);
         }
 #endif
-        for (int jj = 0; jj < 32; ++jj) {
-            const int qq = qblock * NQ + wave * 32 + jj;
-            const int n = __builtin_amdgcn_readfirstlane(lds_load_volatile(&mycnt[jj]));  // <= KS now
-            // what this range rejected was rejected against thresholds >= the final working threshold; kept
-            // entries at or above it are as good as rejected (another range holds KS better ones): dropped here
-            const float eff = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(tau), jj));
-            if (lane < KS) {
-                const unsigned long long e = lane < n ? mylists[jj * LCAP + lane] : 0ull;
-                const float val = __uint_as_float((uint32_t)(e >> 32));
-                const bool keep = lane < n && (val < eff || nrng == 1);
-                const int64_t o = ((int64_t)qq * out_nchunks + out_chunk) * KS + lane;
-                cand[o] = keep ? (int32_t)(uint32_t)e : -1;
-                cand_v[o] = lane < n ? val : __builtin_inff();
-            }
-            if (lane == 0) tau_out[(int64_t)qq * out_nchunks + out_chunk] = eff;
-            if (nrng == 1) {  // a whole-reference item owns every list column of its queries: the others stay empty
-                for (int c = 1; c < out_nchunks; ++c) {
-                    if (lane < KS) cand[((int64_t)qq * out_nchunks + out_chunk + c) * KS + lane] = -1;
-                    if (lane == 0) tau_out[(int64_t)qq * out_nchunks + out_chunk + c] = __builtin_inff();
-                }
-            }
-        }
     }
 }
 
@@ -807,11 +927,11 @@ void launch(hipStream_t stream, KnnWorkspace& ws, const Bf16Launch& L) {
                          ", false>";
     const int items = L.n_full + (L.nqb - L.n_full) * L.nranges;
     if (L.sample)
-        hipLaunchKernelGGL((knn_topk_f16<NS, KS, LCAP, true>), dim3(items), dim3((NCONS + NPROD) * 64), lds, stream,
+        hipLaunchKernelGGL((knn_topk_f16<NS, KS, LCAP, true>), dim3(items), dim3((NCONS + NPROD + NSERV) * 64), lds, stream,
                            L.pq, L.pr, L.first_begin, L.range_len, L.r_limit, L.n_full, L.nranges, L.out_chunk0,
                            L.out_nchunks, L.tau_g, L.cand, L.cand_v, L.tau);
     else
-        hipLaunchKernelGGL((knn_topk_f16<NS, KS, LCAP, false>), dim3(items), dim3((NCONS + NPROD) * 64), lds, stream,
+        hipLaunchKernelGGL((knn_topk_f16<NS, KS, LCAP, false>), dim3(items), dim3((NCONS + NPROD + NSERV) * 64), lds, stream,
                            L.pq, L.pr, L.first_begin, L.range_len, L.r_limit, L.n_full, L.nranges, L.out_chunk0,
                            L.out_nchunks, L.tau_g, L.cand, L.cand_v, L.tau);
     BMX_LAUNCH_CHECK();
@@ -823,13 +943,14 @@ void launch(hipStream_t stream, KnnWorkspace& ws, const Bf16Launch& L) {
         BMX_HIP(hipStreamSynchronize(stream));
         BMX_HIP(hipMemcpyFromSymbol(hh, HIP_SYMBOL(bmx_dbg16), sizeof(hh)));
         const double nt = (double)hh[8];
+        const double sw = hh[14] ? (double)hh[14] : 1.0;
         fprintf(stderr,
-                "[stamps f16] waves=%.0f tiles/wave=%.0f cyc/tile=%.0f spin/tile=%.0f drain/tile=%.0f (every %.1f tiles, "
-                "%.0f cyc each) compact/tile=%.0f (every %.1f tiles, %.0f cyc, %.1f rounds each) event tiles=%.3f "
-                "groups/tile=%.3f evpath/tile=%.0f\n",
-                (double)hh[9], nt / hh[9], hh[0] / nt, hh[1] / nt, hh[2] / nt, hh[3] ? nt / hh[3] : 0.0,
-                hh[3] ? (double)hh[2] / hh[3] : 0.0, hh[5] / nt, hh[4] ? nt / hh[4] : 0.0, hh[4] ? (double)hh[5] / hh[4] : 0.0,
-                hh[4] ? (double)hh[11] / hh[4] : 0.0, hh[6] / nt, hh[7] / nt, hh[10] / nt);
+                "[stamps f16] consumers=%.0f tiles/wave=%.0f cyc/tile=%.0f spin/tile=%.0f evpath/tile=%.0f qwait/tile=%.0f "
+                "event tiles=%.3f groups/tile=%.3f | service waves=%.0f cyc=%.0f drain=%.0f (%.0f passes, %.0f cyc each) "
+                "compact=%.0f (%.0f calls, %.1f rounds each) idle polls=%.0f\n",
+                (double)hh[9], nt / hh[9], hh[0] / nt, hh[1] / nt, hh[10] / nt, hh[12] / nt, hh[6] / nt, hh[7] / nt,
+                (double)hh[14], hh[13] / sw, hh[2] / sw, hh[3] / sw, hh[3] ? (double)hh[2] / hh[3] : 0.0, hh[5] / sw,
+                hh[4] / sw, hh[4] ? (double)hh[11] / hh[4] : 0.0, hh[15] / sw);
         unsigned long long z[48] = {0};
         BMX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(bmx_dbg16), z, sizeof(z)));
     }
