@@ -42,17 +42,29 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int NCONS = 8;   // consumer waves (32 queries each): two per SIMD
 constexpr int NPROD = 2;   // producer waves
-constexpr int NSERV = 2;   // service waves (each works off the spill queues of NCONS / NSERV consumers)
+#ifndef BMX_NSERV
+#define BMX_NSERV 4
+#endif
+constexpr int NSERV = BMX_NSERV;   // service waves (each works off the spill queues of NCONS / NSERV consumers)
 constexpr int NQ = NCONS * 32;
 constexpr int QCAP = 64;   // spill records per consumer wave (one group of one tile can fill all 64)
 #ifndef BMX_DRAIN_MIN
 #define BMX_DRAIN_MIN 16
 #endif
 #ifndef BMX_SPRIO
-#define BMX_SPRIO 1
+#define BMX_SPRIO 0
+#endif
+#ifndef BMX_CPRIO_LO
+#define BMX_CPRIO_LO 0
+#endif
+#ifndef BMX_CPRIO_HI
+#define BMX_CPRIO_HI 1
 #endif
 #ifndef BMX_HEAD
 #define BMX_HEAD 4
+#endif
+#ifndef BMX_RING_MAX
+#define BMX_RING_MAX 4
 #endif
 #ifndef BMX_NPIV
 #define BMX_NPIV 4
@@ -209,7 +221,7 @@ __host__ __device__ constexpr int lds_fixed_bytes() { return NCONS * QCAP * 20 +
 __host__ __device__ constexpr int ring_slots_for(int NS, int LCAP) {
     const int rest = 160 * 1024 - lds_fixed_bytes() - NQ * LCAP * 8;
     const int n = rest / (2 * NS * 1024);
-    return n > 4 ? 4 : n;
+    return n > BMX_RING_MAX ? BMX_RING_MAX : n;
 }
 // list capacity: as long as the ring keeps at least two slots (four tiles), else as short as a useful pending part allows
 #ifndef BMX_LCAP_MAX
@@ -846,9 +858,10 @@ __global__ __launch_bounds__((NCONS + NPROD + NSERV) * 64) void knn_topk_f16(
     for (int e = 0; e < 16; ++e) accA[e] = accB[e] = __builtin_inff();  // "previous tile" of step 0: nothing passes
     // at equal priority the second-dispatched half of the consumers (waves 4..7, one per SIMD) loses every contested
     // issue slot to its older partner: it gets the higher static priority (MI355X_MICROARCH.md, two waves per SIMD)
-#ifndef BMX_EXP_NOCPRIO
-    if (wave >= NCONS / 2) __builtin_amdgcn_s_setprio(1);
-#endif
+    if (wave >= NCONS / 2)
+        __builtin_amdgcn_s_setprio(BMX_CPRIO_HI);
+    else
+        __builtin_amdgcn_s_setprio(BMX_CPRIO_LO);
     // the query fragments have arrived: said here once, so that the compiler keeps no vmcnt wait for them in the loop
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     if (nslots > 0) {
