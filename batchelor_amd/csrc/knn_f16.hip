@@ -693,7 +693,19 @@ __global__ __launch_bounds__((NCONS + NPROD + NSERV) * 64) void knn_topk_f16(
     };
     auto hand_back = [&](int slot) __attribute__((always_inline)) {
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
-        lane0_store(&done[pos_n * NCONS + wave], slot + 1);
+        if constexpr (SAMPLE) {
+            lane0_store(&done[pos_n * NCONS + wave], slot + 1);
+        } else {
+            // the done word and, in the same instruction, the number of records pushed so far (they sit behind the
+            // records in the wave's in-order LDS queue): one store per slot instead of one per spill
+            typedef __attribute__((address_space(3))) int* lds_iptr;
+            const lds_iptr dp = (lds_iptr)&done[pos_n * NCONS + wave];
+            const lds_iptr wp = (lds_iptr)&wrL[wave];
+            const int val = slot + 1;
+            asm volatile("s_mov_b64 exec, 1\n\tds_write_b32 %0, %1\n\tds_write_b32 %2, %3\n\ts_mov_b64 exec, -1" ::"v"(dp),
+                         "v"(val), "v"(wp), "v"(wr)
+                         : "memory");
+        }
         pos_n = pos_n + 1 == NSLOT ? 0 : pos_n + 1;
         seen = lds_load_volatile(&ready[pos_n]);
         if constexpr (!SAMPLE) tau_next = __hip_atomic_load(&tauL[wave * 32 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -720,6 +732,7 @@ __global__ __launch_bounds__((NCONS + NPROD + NSERV) * 64) void knn_topk_f16(
 #endif
         rd_seen = __builtin_amdgcn_readfirstlane(lds_load_volatile(&rdL[wave]));
         if (wr + need - rd_seen > QCAP) {
+            lane0_store(&wrL[wave], wr);
             lane0_store(&stL[wave], 1);  // "waiting": the service wave works the queue off whatever its length
             do {
                 __builtin_amdgcn_s_sleep(1);
@@ -844,10 +857,7 @@ __global__ __launch_bounds__((NCONS + NPROD + NSERV) * 64) void knn_topk_f16(
             wait_room(tot);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (m[u]) spill(u, m[u]);
-        __atomic_signal_fence(__ATOMIC_SEQ_CST);
-        lane0_store(&wrL[wave], wr);  // queued behind the records in the wave's in-order LDS queue
+        for (int u = 0; u < 4; ++u) spill(u, m[u]);  // (the count goes out with the slot's done word)
 #ifdef BMX_STAMPS
         dbg_evc += STAMP() - dbg_e0;
 #endif
@@ -904,6 +914,7 @@ __global__ __launch_bounds__((NCONS + NPROD + NSERV) * 64) void knn_topk_f16(
     } else {
         // everything is in the queue: once the service wave has worked it off, both write final lists out
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        lane0_store(&wrL[wave], wr);
         lane0_store(&stL[wave], 2);
         while (__builtin_amdgcn_readfirstlane(lds_load_volatile(&stL[wave])) != 3) __builtin_amdgcn_s_sleep(2);
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
