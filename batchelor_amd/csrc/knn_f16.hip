@@ -266,8 +266,8 @@ __global__ __launch_bounds__((NCONS + NPROD + NSERV) * 64) void knn_topk_f16(
     int* cnt = reinterpret_cast<int*>(qtags + NCONS * QCAP);                                      // [NQ]
     float* tauL = reinterpret_cast<float*>(cnt + NQ);  // [NQ] thresholds as the service waves last published them
     int* ready = reinterpret_cast<int*>(tauL + NQ);    // [NSLOT]
-    int* done = ready + NSLOT;                         // [NSLOT][NCONS]
-    int* wrL = done + NSLOT * NCONS;                   // [NCONS] records pushed so far (written by the consumer)
+    int* done = ready + NSLOT;  // [NSLOT] hand-backs of the position so far (every consumer adds one per slot read)
+    int* wrL = done + NSLOT;    // [NCONS] records pushed so far (written by the consumer)
     int* rdL = wrL + NCONS;                            // [NCONS] records worked off so far (written by its service wave)
     int* stL = rdL + NCONS;  // [NCONS] consumer state: 0 sweeping, 1 waiting for room in its queue, 2 through
 
@@ -287,7 +287,7 @@ __global__ __launch_bounds__((NCONS + NPROD + NSERV) * 64) void knn_topk_f16(
     const int ntiles = (r_end - r_begin) >> 5;  // even: ranges are multiples of 64 rows
     const int nslots = ntiles >> 1;
     const int out_chunk = out_chunk0 + rng;
-    if (tid < NSLOT * (1 + NCONS) + 3 * NCONS) ready[tid] = 0;  // ready[], done[], wrL[], rdL[], stL[] are contiguous
+    if (tid < 2 * NSLOT + 3 * NCONS) ready[tid] = 0;  // ready[], done[], wrL[], rdL[], stL[] are contiguous
     if (tid < NQ) {
         cnt[tid] = 0;
         tauL[tid] = (!SAMPLE && tau_g) ? orderable_f32(tau_g[qblock * NQ + tid]) : __builtin_inff();
@@ -427,16 +427,13 @@ __global__ __launch_bounds__((NCONS + NPROD + NSERV) * 64) void knn_topk_f16(
 #pragma unroll
             for (int s = 0; s < 2 * NS; ++s) r[s] = src[((int64_t)sl * 2 * NS + s) * 64];
         };
-        // slot sl goes to ring position sl % NSLOT once every consumer has read the slot staged there NSLOT slots earlier;
-        // done[pos][c] = number of the last slot consumer c has read from the position, plus one
+        // slot sl goes to ring position sl % NSLOT once every consumer has read the slots staged there before it:
+        // done[pos] counts the hand-backs of the position, NCONS per slot
         auto wait_free = [&](int sl, int pos) __attribute__((always_inline)) {
             if (sl < NSLOT) return;
-            const int need = sl - NSLOT + 1;
-            for (;;) {
-                const int v = lane < NCONS ? lds_load_volatile(&done[pos * NCONS + lane]) : need;
-                if (__builtin_amdgcn_ballot_w64(v < need) == 0) break;
+            const int need = (sl / NSLOT) * NCONS;
+            while (__builtin_amdgcn_readfirstlane(lds_load_volatile(&done[pos])) < need)
                 __builtin_amdgcn_s_sleep(BMX_PSLEEP);
-            }
         };
         auto publish = [&](const f32x4(&r)[2 * NS], int sl) {
             const int pos = sl % NSLOT;
@@ -664,20 +661,31 @@ __global__ __launch_bounds__((NCONS + NPROD + NSERV) * 64) void knn_topk_f16(
     // Hand-over, once per slot (two tiles).  While the tiles of slot sl compute, their fragment registers are refilled
     // from slot sl + 1 (each register right after the MFMA that consumed it); the ready word of slot sl + 1 is checked
     // before the first refill (it was polled a slot earlier: no LDS round trip in steady state), and after the last
-    // refill the wave stores "read up to sl + 1" in its done word -- queued behind the reads in the wave's in-order LDS
-    // queue, so the producers cannot overwrite them early -- and polls the ready word of slot sl + 2 and its queries'
-    // thresholds as the service wave has them now.
+    // refill the wave adds one to the position's hand-back counter -- queued behind the reads in the wave's in-order
+    // LDS queue, so the producers cannot overwrite them early -- and polls the ready word of slot sl + 2 and its
+    // queries' thresholds as the service wave has them now.  The slot loop is unrolled over the ring positions, so
+    // every address below is a register set up once plus a constant.
+    typedef __attribute__((address_space(3))) int* lds_iptr;
+    lds_iptr done_p[NSLOT], ready_p[NSLOT];
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k) {
+        done_p[k] = (lds_iptr)&done[k];
+        ready_p[k] = (lds_iptr)&ready[k];
+        asm volatile("" : "+v"(done_p[k]), "+v"(ready_p[k]));
+    }
+    lds_iptr wr_p = (lds_iptr)&wrL[wave];
+    int one = 1;
+    asm volatile("" : "+v"(wr_p), "+v"(one));
     float tau_next = tau;
     int seen = 0;
-    int pos_n = 0;  // ring position of the slot to read next
-    auto spin_until_staged = [&](int slot) __attribute__((always_inline)) {
+    auto spin_until_staged = [&](const int slot, const int k) __attribute__((always_inline)) {  // slot, at position k
         if (__builtin_amdgcn_readfirstlane(seen) < slot + 1) {
 #ifdef BMX_STAMPS
             const unsigned long long s0 = STAMP();
 #endif
             do {
                 __builtin_amdgcn_s_sleep(1);
-                seen = lds_load_volatile(&ready[pos_n]);
+                seen = *(volatile lds_iptr)ready_p[k];
             } while (seen < slot + 1);
 #ifdef BMX_STAMPS
             dbg_spin += STAMP() - s0;
@@ -687,32 +695,25 @@ __global__ __launch_bounds__((NCONS + NPROD + NSERV) * 64) void knn_topk_f16(
     auto lane0_store = [&](int* word, const int val) __attribute__((always_inline)) {
         // EXEC is all ones here (uniform control flow), so it is narrowed and restored with two scalar moves instead of
         // a compare / saveexec / branch sequence
-        typedef __attribute__((address_space(3))) int* lds_iptr;
         const lds_iptr dp = (lds_iptr)word;
         asm volatile("s_mov_b64 exec, 1\n\tds_write_b32 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(dp), "v"(val) : "memory");
     };
-    auto hand_back = [&](int slot) __attribute__((always_inline)) {
+    auto hand_back = [&](const int k) __attribute__((always_inline)) {  // the slot at position k has been read
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         if constexpr (SAMPLE) {
-            lane0_store(&done[pos_n * NCONS + wave], slot + 1);
+            asm volatile("s_mov_b64 exec, 1\n\tds_add_u32 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(done_p[k]), "v"(one) : "memory");
         } else {
-            // the done word and, in the same instruction, the number of records pushed so far (they sit behind the
-            // records in the wave's in-order LDS queue): one store per slot instead of one per spill
-            typedef __attribute__((address_space(3))) int* lds_iptr;
-            const lds_iptr dp = (lds_iptr)&done[pos_n * NCONS + wave];
-            const lds_iptr wp = (lds_iptr)&wrL[wave];
-            const int val = slot + 1;
-            asm volatile("s_mov_b64 exec, 1\n\tds_write_b32 %0, %1\n\tds_write_b32 %2, %3\n\ts_mov_b64 exec, -1" ::"v"(dp),
-                         "v"(val), "v"(wp), "v"(wr)
+            // ... and, in the same breath, the number of records pushed so far (they sit behind the records in the wave's
+            // in-order LDS queue): one store per slot instead of one per spill
+            asm volatile("s_mov_b64 exec, 1\n\tds_add_u32 %0, %1\n\tds_write_b32 %2, %3\n\ts_mov_b64 exec, -1" ::"v"(done_p[k]),
+                         "v"(one), "v"(wr_p), "v"(wr)
                          : "memory");
         }
-        pos_n = pos_n + 1 == NSLOT ? 0 : pos_n + 1;
-        seen = lds_load_volatile(&ready[pos_n]);
+        seen = *(volatile lds_iptr)ready_p[(k + 1) % NSLOT];
         if constexpr (!SAMPLE) tau_next = __hip_atomic_load(&tauL[wave * 32 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
 
     f32x4 a[NS], b[NS];  // fragments of the even / odd tile of the current slot
-    float sample_mn = __builtin_inff();
     // SAMPLE: the lane's KS / 2 smallest candidates, ascending.  Insertion of x into a sorted list is one median per
     // entry, best'[i] = med3(best[i - 1], best[i], x), all of them independent when taken from the top down
     float best[SAMPLE ? KS / 2 : 1];
@@ -745,127 +746,94 @@ __global__ __launch_bounds__((NCONS + NPROD + NSERV) * 64) void knn_topk_f16(
 #endif
     };
 
-    // One step = the MFMA chain of tile t (fragments in `f`) into `cur`; in its gaps the refill of each fragment
-    // register with the same half of the NEXT slot and the filter of tile t - 1 (products in `prev`); then the spill of
-    // tile t - 1's groups with survivors.  `half` = which tile of its slot t is.
-    auto step = [&](f32x16& cur, const f32x16& prev, f32x4(&f)[NS], const int t, const int half) {
-        typedef __attribute__((address_space(3))) const char* lds_cptr;
-        typedef __attribute__((address_space(3))) const f32x4* lds_f4ptr;
-        lds_cptr tbase = (lds_cptr)ring + (pos_n * SLOT_BYTES + half * TILE_BYTES + lane * 16);
-        asm volatile("" : "+v"(tbase));     // the address is formed here, ...
-        __builtin_amdgcn_sched_barrier(0);  // ... outside the interleaved block below
-        const lds_f4ptr tp = (lds_f4ptr)tbase;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) cur[e] = 0.f;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            cur = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f[s]), bq[s], cur, 0, 0, 0);
-            f[s] = tp[s * 64];
-        }
-        // group minima (4 consecutive references each), then the lane minimum, of the previous tile
+    // ---- filter of one tile (products in `acc`, tile number t) and, where a value is below its query's threshold, the
+    // spill.  Returns the lane minimum (SAMPLE uses nothing else).
+    auto sift = [&](const f32x16& acc, const int t) __attribute__((always_inline)) {
+        // group minima (4 consecutive references each), then the lane minimum.  Every fminf below is half of a
+        // three-way minimum: the compiler forms v_min3_f32 from such pairs and, unlike for a lone v_min_f32, does not put
+        // a v_max x, x (signalling-NaN quieting) in front of its inputs.  The threshold rides along as the sixth operand
+        // of a group: min(group, tau) < tau iff min(group) < tau (SAMPLE: tau = +inf, the plain minimum)
         float g[4];
-        // every fminf below is half of a three-way minimum: the compiler forms v_min3_f32 from such pairs and, unlike
-        // for a lone v_min_f32, does not put a v_max x, x (signalling-NaN quieting) in front of its inputs.  The
-        // threshold rides along as the sixth operand of a group: min(group, tau) < tau iff min(group) < tau
-        // (SAMPLE: tau = +inf, the plain minimum)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const float m3 = fminf(fminf(prev[4 * u], prev[4 * u + 1]), prev[4 * u + 2]);
-            g[u] = fminf(fminf(m3, prev[4 * u + 3]), tau);
+            const float m3 = fminf(fminf(acc[4 * u], acc[4 * u + 1]), acc[4 * u + 2]);
+            g[u] = fminf(fminf(m3, acc[4 * u + 3]), tau);
         }
         const float mn = fminf(fminf(fminf(fminf(g[0], g[1]), g[2]), g[3]), tau);
-        unsigned long long any = 0;
         if constexpr (SAMPLE) {
-            // sorted insertion of ONE candidate per slot: the lane's minimum over both tiles of the slot (32 references
-            // of one query; still one distinct reference per candidate, half the insertions)
-            if (half == 0) {
-                sample_mn = mn;
-            } else {
-                sample_insert(fminf(fminf(mn, sample_mn), mn));
-                asm volatile("" ::"v"(best[KS / 2 - 1]));  // keep it in this block
-            }
+            return mn;
         } else {
 #if defined(BMX_EXP_NOFILTER)
-            any = 0;  // timing experiment: no filter, no events (results are garbage)
+            const unsigned long long any = 0;  // timing experiment: no filter, no events (results are garbage)
 #elif defined(BMX_EXP_NOEVENT)
-            any = __builtin_amdgcn_ballot_w64(mn < -3.0e38f);  // timing experiment: filter runs, nothing passes
+            const unsigned long long any = __builtin_amdgcn_ballot_w64(mn < -3.0e38f);  // timing experiment: nothing passes
 #else
-            any = __builtin_amdgcn_ballot_w64(mn < tau);
+            const unsigned long long any = __builtin_amdgcn_ballot_w64(mn < tau);
 #endif
-            asm volatile("" ::"s"(any), "v"(g[0]), "v"(g[1]), "v"(g[2]), "v"(g[3]));  // keep the filter in this block
-        }
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one LDS read
-            __builtin_amdgcn_sched_group_barrier(0x002, SAMPLE ? 3 + (KS / 2 + NS - 1) / NS : (12 + NS - 1) / NS, 0);
-        }
-        if (half == 1) hand_back(((t - 1) >> 1) + 1);  // both tiles of slot (t - 1) / 2 + 1 have been read
-        if constexpr (SAMPLE) return;
-        if (any == 0) return;  // (a layout hint that keeps the two half-steps adjacent measured 1 % slower)
+            if (any == 0) return mn;
 #ifdef BMX_STAMPS
-        ++dbg_evt;
-        const unsigned long long dbg_e0 = STAMP();
+            ++dbg_evt;
+            const unsigned long long dbg_e0 = STAMP();
 #endif
-        // ---- spill the groups with survivors of tile t - 1: four raw values and a tag per (lane, group) into the
-        // wave's queue; the service wave takes it from there
-        const uint32_t tagbase = ((uint32_t)(t - 1) << 8) | (uint32_t)lane;
-        auto spill = [&](const int u, const unsigned long long m) __attribute__((always_inline)) {
-            if (g[u] < tau) {  // the lanes of m
-                const int slot = (wr + mbcnt64(m)) & (QCAP - 1);
-                f32x4 rec;
-                rec[0] = prev[4 * u];
-                rec[1] = prev[4 * u + 1];
-                rec[2] = prev[4 * u + 2];
-                rec[3] = prev[4 * u + 3];
-                *reinterpret_cast<f32x4*>(qv + slot * 4) = rec;
-                qt[slot] = tagbase | ((uint32_t)u << 6);
-            }
-            wr += __builtin_popcountll(m);
-#ifdef BMX_STAMPS
-            ++dbg_grp;
-#endif
-        };
-        unsigned long long m[4];
-        int tot = 0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            m[u] = __builtin_amdgcn_ballot_w64(g[u] < tau);
-            tot += __builtin_popcountll(m[u]);
-        }
-        if (wr + tot - rd_seen > QCAP) {
-            if (tot > QCAP) {
-                // the first tiles of a sweep that starts without a threshold: one group (<= 64 records) at a time, each
-                // against the threshold as it stands by then
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    wait_room(QCAP);  // (the queue is empty: everything pushed so far has had its effect on the threshold)
-                    const float tl = __hip_atomic_load(&tauL[wave * 32 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    tau = tl < tau ? tl : tau;
-                    const unsigned long long mu = __builtin_amdgcn_ballot_w64(g[u] < tau);
-                    if (mu) {
-                        spill(u, mu);
-                        __atomic_signal_fence(__ATOMIC_SEQ_CST);
-                        lane0_store(&wrL[wave], wr);
-                    }
+            // ---- spill the groups with survivors: four raw values and a tag per (lane, group) into the wave's queue;
+            // the service wave takes it from there
+            const uint32_t tagbase = ((uint32_t)t << 8) | (uint32_t)lane;
+            auto spill = [&](const int u, const unsigned long long m) __attribute__((always_inline)) {
+                if (g[u] < tau) {  // the lanes of m
+                    const int slot = (wr + mbcnt64(m)) & (QCAP - 1);
+                    f32x4 rec;
+                    rec[0] = acc[4 * u];
+                    rec[1] = acc[4 * u + 1];
+                    rec[2] = acc[4 * u + 2];
+                    rec[3] = acc[4 * u + 3];
+                    *reinterpret_cast<f32x4*>(qv + slot * 4) = rec;
+                    qt[slot] = tagbase | ((uint32_t)u << 6);
                 }
+                wr += __builtin_popcountll(m);
 #ifdef BMX_STAMPS
-                dbg_evc += STAMP() - dbg_e0;
+                ++dbg_grp;
 #endif
-                return;
-            }
-            wait_room(tot);
-        }
+            };
+            unsigned long long m[4];
+            int tot = 0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) spill(u, m[u]);  // (the count goes out with the slot's done word)
+            for (int u = 0; u < 4; ++u) {
+                m[u] = __builtin_amdgcn_ballot_w64(g[u] < tau);
+                tot += __builtin_popcountll(m[u]);
+            }
+            if (wr + tot - rd_seen > QCAP) {
+                if (tot > QCAP) {
+                    // the first tiles of a sweep that starts without a threshold: one group (<= 64 records) at a time,
+                    // each against the threshold as it stands by then
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        wait_room(QCAP);  // (the queue is empty: everything pushed so far has had its effect on the threshold)
+                        const float tl =
+                            __hip_atomic_load(&tauL[wave * 32 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        tau = tl < tau ? tl : tau;
+                        const unsigned long long mu = __builtin_amdgcn_ballot_w64(g[u] < tau);
+                        if (mu) {
+                            spill(u, mu);
+                            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                            lane0_store(&wrL[wave], wr);
+                        }
+                    }
 #ifdef BMX_STAMPS
-        dbg_evc += STAMP() - dbg_e0;
+                    dbg_evc += STAMP() - dbg_e0;
 #endif
+                    return mn;
+                }
+                wait_room(tot);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) spill(u, m[u]);  // (the count goes out with the next done word)
+#ifdef BMX_STAMPS
+            dbg_evc += STAMP() - dbg_e0;
+#endif
+            return mn;
+        }
     };
 
-    f32x16 accA, accB;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) accA[e] = accB[e] = __builtin_inff();  // "previous tile" of step 0: nothing passes
     // at equal priority the second-dispatched half of the consumers (waves 4..7, one per SIMD) loses every contested
     // issue slot to its older partner: it gets the higher static priority (MI355X_MICROARCH.md, two waves per SIMD)
     if (wave >= NCONS / 2)
@@ -875,10 +843,14 @@ __global__ __launch_bounds__((NCONS + NPROD + NSERV) * 64) void knn_topk_f16(
     // the query fragments have arrived: said here once, so that the compiler keeps no vmcnt wait for them in the loop
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     if (nslots > 0) {
-        spin_until_staged(0);
+        typedef __attribute__((address_space(3))) const char* lds_cptr;
+        typedef __attribute__((address_space(3))) const f32x4* lds_f4ptr;
+        lds_cptr ring_lane = (lds_cptr)ring + lane * 16;
+        asm volatile("" : "+v"(ring_lane));
+        spin_until_staged(0, 0);
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         {
-            const f32x4* tp = reinterpret_cast<const f32x4*>(ring + pos_n * SLOT_BYTES) + lane;
+            const lds_f4ptr tp = (lds_f4ptr)ring_lane;
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 a[s] = tp[s * 64];
@@ -886,21 +858,53 @@ __global__ __launch_bounds__((NCONS + NPROD + NSERV) * 64) void knn_topk_f16(
             }
         }
         hand_back(0);
-        // steps 0 .. ntiles: step t multiplies tile t (step ntiles: an empty tile, product unused) and filters tile
-        // t - 1; one slot = two steps per iteration, so the two accumulators and the two fragment sets alternate statically
-        for (int sl = 0; sl <= nslots; ++sl) {
-            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the fragments of this slot, the ready word of the next, tau
-            if constexpr (!SAMPLE) tau = fminf(fminf(tau, tau_next), tau_next);
-            spin_until_staged(sl + 1);
-            __atomic_signal_fence(__ATOMIC_SEQ_CST);
-            step(accA, accB, a, 2 * sl, 0);
-            if (sl < nslots) step(accB, accA, b, 2 * sl + 1, 1);
+        // One iteration = one slot = two tiles.  Matrix phase: the two tiles' MFMA chains interleaved (independent
+        // accumulators: the wave issues its 2 NS MFMAs back to back without waiting on its own results), each fragment
+        // register refilled from the next slot right after the MFMA that consumed it.  Vector phase: filter and spill of
+        // both tiles.  The two consumer waves of a SIMD fall into opposite phases: one's vector phase runs under the
+        // other's MFMAs.
+        for (int sl0 = 0; sl0 < nslots; sl0 += NSLOT) {
+#pragma unroll
+            for (int k = 0; k < NSLOT; ++k) {
+                const int sl = sl0 + k;  // its fragments are in a[], b[]; slot sl + 1 sits at position kn
+                if (sl >= nslots) break;
+                const int kn = (k + 1) % NSLOT;
+                __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this slot's fragments, the next one's ready word, tau
+                if constexpr (!SAMPLE) asm("v_min_f32 %0, %0, %1" : "+v"(tau) : "v"(tau_next));
+                spin_until_staged(sl + 1, kn);
+                __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                const lds_f4ptr tp = (lds_f4ptr)(ring_lane + kn * SLOT_BYTES);
+                f32x16 accA, accB;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) accA[e] = accB[e] = 0.f;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[s]), bq[s], accA, 0, 0, 0);
+                    a[s] = tp[s * 64];
+                    accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, b[s]), bq[s], accB, 0, 0, 0);
+                    b[s] = tp[(NS + s) * 64];
+                }
+#pragma unroll
+                for (int s = 0; s < 2 * NS; ++s) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one LDS read
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                hand_back(kn);  // both tiles of slot sl + 1 are on their way into the fragment registers
+                const float mnA = sift(accA, 2 * sl);
+                const float mnB = sift(accB, 2 * sl + 1);
+                if constexpr (SAMPLE) {
+                    // sorted insertion of ONE candidate per slot: the lane's minimum over both tiles (32 references of
+                    // one query; still one distinct reference per candidate, half the insertions)
+                    sample_insert(fminf(fminf(mnA, mnB), mnB));
+                }
+            }
         }
     }
     __builtin_amdgcn_s_setprio(0);
 
     if constexpr (SAMPLE) {
-        sample_insert(sample_mn);  // the last tile's candidate was still waiting for a partner
         const uint32_t mine = f32_orderable(best[KS / 2 - 1]), other = __shfl_xor(mine, 32);
         if (h == 0) tau_g[q] = max(mine, other);
 #ifdef BMX_STAMPS
