@@ -505,11 +505,14 @@ void candidate_pass(hipStream_t stream, KnnWorkspace& ws, const Tier& T, const d
     // Measured work per pair evaluation relative to one range (100k x 400k): 3 ranges 1.12, 5: 1.17, 7: 1.21.
     // Sample size: each sampled row costs every query a filter-only tile visit, each row NOT sampled costs KS / row
     // more candidates to append and select (the harmonic tail of the running threshold) -- with the fp16 kernel's
-    // cheap tiles the balance is flat between 16k and 32k rows
-    const int S_auto = nr >= 65536 && T.id == 1 ? 24576 : 4096;
+    // cheap tiles the balance is flat between 16k and 32k rows at 50 PCs and lower for longer rows (a sampled tile
+    // costs the full matrix work).  The fp16 kernel samples small references too (a quarter of the rows): its sweep
+    // hands every survivor to another wave, which makes a start without thresholds expensive
+    int S_auto = nr >= 32768 ? 4096 : 0;
+    if (T.id == 1 && nr >= 4096) S_auto = std::max(1024, std::min(nr / 4, NS <= 4 ? 24576 : 12288));
     // (a seeded search samples too: the odd query whose seed is loose -- a left cell listed by one far-away right cell --
     // then starts from the sampled threshold like everybody else; the tighter of the two counts)
-    const int S = nr >= 32768 ? (int)round_up(std::getenv("BMX_SAMPLE") ? std::atoi(std::getenv("BMX_SAMPLE")) : S_auto, 64) : 0;
+    const int S = (int)round_up(std::getenv("BMX_SAMPLE") ? std::atoi(std::getenv("BMX_SAMPLE")) : S_auto, 64);
     int C = 1, n_full = 0;
     {
         const int a = nqb / 256, b = nqb % 256;

@@ -45,7 +45,9 @@ constexpr int NPROD = 2;   // producer waves
 #ifndef BMX_NSERV
 #define BMX_NSERV 4
 #endif
-constexpr int NSERV = BMX_NSERV;   // service waves (each works off the spill queues of NCONS / NSERV consumers)
+// service waves (each works off the spill queues of NCONS / n consumers).  Fourteen waves on a CU leave a wave 128
+// registers, twelve 168: the long-K consumers (fragments of two tiles + query fragments + two accumulators) need the latter
+__host__ __device__ constexpr int serv_waves(int NS) { return NS <= 5 ? BMX_NSERV : 2; }
 constexpr int NQ = NCONS * 32;
 constexpr int QCAP = 64;   // spill records per consumer wave (one group of one tile can fill all 64)
 #ifndef BMX_DRAIN_MIN
@@ -246,7 +248,7 @@ __device__ unsigned long long bmx_dbg16[48];
 #endif
 
 template <int NS, int KS, int LCAP, bool SAMPLE>
-__global__ __launch_bounds__((NCONS + NPROD + NSERV) * 64) void knn_topk_f16(
+__global__ __launch_bounds__((NCONS + NPROD + serv_waves(NS)) * 64) void knn_topk_f16(
     const uint16_t* __restrict__ Pq, const uint16_t* __restrict__ PrF, int first_begin, int range_len, int r_limit,
     int n_full, int nranges, int out_chunk0, int out_nchunks, uint32_t* __restrict__ tau_g, int32_t* __restrict__ cand,
     float* __restrict__ cand_v, float* __restrict__ tau_out) {
@@ -255,6 +257,7 @@ __global__ __launch_bounds__((NCONS + NPROD + NSERV) * 64) void knn_topk_f16(
     constexpr int NSLOT = ring_slots_for(NS, LCAP);
     static_assert(NSLOT >= 2, "LDS ring");
     static_assert(LCAP <= 64 && LCAP > KS, "one list entry per lane during compaction");
+    constexpr int NSERV = serv_waves(NS);
     static_assert(NCONS % NSERV == 0 && (NCONS / NSERV) % 2 == 0, "a service wave's consumers: whole groups of 64 queries");
     static_assert((QCAP & (QCAP - 1)) == 0 && QCAP >= 64, "queue positions wrap by masking; one group can hold 64 records");
 
@@ -804,14 +807,20 @@ __global__ __launch_bounds__((NCONS + NPROD + NSERV) * 64) void knn_topk_f16(
             if (wr + tot - rd_seen > QCAP) {
                 if (tot > QCAP) {
                     // the first tiles of a sweep that starts without a threshold: one group (<= 64 records) at a time,
-                    // each against the threshold as it stands by then
+                    // each against the threshold as it stands once there is room for it
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        wait_room(QCAP);  // (the queue is empty: everything pushed so far has had its effect on the threshold)
-                        const float tl =
-                            __hip_atomic_load(&tauL[wave * 32 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        tau = tl < tau ? tl : tau;
-                        const unsigned long long mu = __builtin_amdgcn_ballot_w64(g[u] < tau);
+                        // (taken again: an earlier group of this tile may have waited and come back with a lower threshold)
+                        unsigned long long mu = __builtin_amdgcn_ballot_w64(g[u] < tau);
+                        if (mu == 0) continue;
+                        const int c = __builtin_popcountll(mu);
+                        if (wr + c - rd_seen > QCAP) {
+                            wait_room(c);
+                            const float tl =
+                                __hip_atomic_load(&tauL[wave * 32 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            tau = tl < tau ? tl : tau;
+                            mu = __builtin_amdgcn_ballot_w64(g[u] < tau);
+                        }
                         if (mu) {
                             spill(u, mu);
                             __atomic_signal_fence(__ATOMIC_SEQ_CST);
@@ -955,11 +964,11 @@ void launch(hipStream_t stream, KnnWorkspace& ws, const Bf16Launch& L) {
                          ", false>";
     const int items = L.n_full + (L.nqb - L.n_full) * L.nranges;
     if (L.sample)
-        hipLaunchKernelGGL((knn_topk_f16<NS, KS, LCAP, true>), dim3(items), dim3((NCONS + NPROD + NSERV) * 64), lds, stream,
+        hipLaunchKernelGGL((knn_topk_f16<NS, KS, LCAP, true>), dim3(items), dim3((NCONS + NPROD + serv_waves(NS)) * 64), lds, stream,
                            L.pq, L.pr, L.first_begin, L.range_len, L.r_limit, L.n_full, L.nranges, L.out_chunk0,
                            L.out_nchunks, L.tau_g, L.cand, L.cand_v, L.tau);
     else
-        hipLaunchKernelGGL((knn_topk_f16<NS, KS, LCAP, false>), dim3(items), dim3((NCONS + NPROD + NSERV) * 64), lds, stream,
+        hipLaunchKernelGGL((knn_topk_f16<NS, KS, LCAP, false>), dim3(items), dim3((NCONS + NPROD + serv_waves(NS)) * 64), lds, stream,
                            L.pq, L.pr, L.first_begin, L.range_len, L.r_limit, L.n_full, L.nranges, L.out_chunk0,
                            L.out_nchunks, L.tau_g, L.cand, L.cand_v, L.tau);
     BMX_LAUNCH_CHECK();
