@@ -466,6 +466,9 @@ __global__ void scatter_flagged(const int32_t* __restrict__ flagged, int n, int 
     if (dist_out) dist_out[o] = sub_dist[e];
 }
 
+#ifndef BMX_SEEDED_SAMPLE
+#define BMX_SEEDED_SAMPLE 4096
+#endif
 struct Tier {
     int id;  // 1 = fp16 single product, 2 = split bf16
     int NS, KS;
@@ -510,8 +513,9 @@ void candidate_pass(hipStream_t stream, KnnWorkspace& ws, const Tier& T, const d
     // hands every survivor to another wave, which makes a start without thresholds expensive
     int S_auto = nr >= 32768 ? 4096 : 0;
     if (T.id == 1 && nr >= 4096) S_auto = std::max(1024, std::min(nr / 4, NS <= 4 ? 24576 : 12288));
-    // (a seeded search samples too: the odd query whose seed is loose -- a left cell listed by one far-away right cell --
-    // then starts from the sampled threshold like everybody else; the tighter of the two counts)
+    // (a seeded search samples too, but a sixth of the rows: the odd query whose seed is loose -- a left cell listed by
+    // one far-away right cell -- then starts from a sampled threshold instead of none; the tighter of the two counts)
+    if (seed_d2 && T.id == 1) S_auto = std::min(S_auto, BMX_SEEDED_SAMPLE);
     const int S = (int)round_up(std::getenv("BMX_SAMPLE") ? std::atoi(std::getenv("BMX_SAMPLE")) : S_auto, 64);
     int C = 1, n_full = 0;
     {

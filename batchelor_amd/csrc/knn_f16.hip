@@ -712,7 +712,11 @@ __global__ __launch_bounds__((NCONS + NPROD + serv_waves(NS)) * 64) void knn_top
                          "v"(one), "v"(wr_p), "v"(wr)
                          : "memory");
         }
-        seen = *(volatile lds_iptr)ready_p[(k + 1) % NSLOT];
+    };
+    // the ready word of the slot after next and the thresholds: polled ahead of the slot's fragment reads, looked at
+    // one slot later (they are back long before the reads the wave has to wait for anyway)
+    auto poll = [&](const int k) __attribute__((always_inline)) {
+        seen = *(volatile lds_iptr)ready_p[k];
         if constexpr (!SAMPLE) tau_next = __hip_atomic_load(&tauL[wave * 32 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
 
@@ -867,6 +871,7 @@ __global__ __launch_bounds__((NCONS + NPROD + serv_waves(NS)) * 64) void knn_top
             }
         }
         hand_back(0);
+        poll(1 % NSLOT);
         // One iteration = one slot = two tiles.  Matrix phase: the two tiles' MFMA chains interleaved (independent
         // accumulators: the wave issues its 2 NS MFMAs back to back without waiting on its own results), each fragment
         // register refilled from the next slot right after the MFMA that consumed it.  Vector phase: filter and spill of
@@ -882,6 +887,7 @@ __global__ __launch_bounds__((NCONS + NPROD + serv_waves(NS)) * 64) void knn_top
                 if constexpr (!SAMPLE) asm("v_min_f32 %0, %0, %1" : "+v"(tau) : "v"(tau_next));
                 spin_until_staged(sl + 1, kn);
                 __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                poll((kn + 1) % NSLOT);
                 const lds_f4ptr tp = (lds_f4ptr)(ring_lane + kn * SLOT_BYTES);
                 f32x16 accA, accB;
 #pragma unroll
