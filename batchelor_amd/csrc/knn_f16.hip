@@ -12,22 +12,22 @@
 // 0.05 against a gap of 0.35 between the 20th and the 32nd neighbour, so with KS = 32 kept candidates practically
 // every query is certified.
 //
-// With the matrix work that cheap the vector instructions of the selection set the pace, so the selection is built
-// to need few of them per tile:
-//   * filter: the 32 x 32 accumulator puts a query on each lane; min over its 16 values (v_min3 tree, issued in the
-//     gaps of the MFMA chain of the next tile), one compare, one scalar branch -- most tiles end here;
-//   * spill: a lane whose group of 4 consecutive references holds a survivor dumps the group's four raw values
-//     (one ds_write_b128) and a tag (tile, group, lane) into its wave's queue in the LDS: five vector instructions
-//     per group with survivors, whatever the number of lanes involved, no per-value work;
-//   * drain: when the queue is nearly full (every ~30 tiles) the wave works it off with all 64 lanes busy: 16
-//     records = 64 values per round, each lane re-tests one value against its query's current threshold
-//     (ds_bpermute from the owning lane's register) and appends it to the query's list with an LDS atomic;
-//   * compaction: a query's list (KS kept + pending, <= 64 entries, unsorted) is cut back to its KS smallest by a
-//     quickselect over the wave (pivot by readlane, ballot + popcount per round: ~2 vector instructions per round,
-//     ~8 rounds) and the threshold drops to the cut -- once per ~30 appended candidates.
-// Everything else (LDS ring of reference tiles filled by producer waves, hand-over through LDS words without
-// barriers, software-pipelined tile loop, shared thresholds across reference ranges, register-only sample pass)
-// follows knn_bf16.hip.
+// With the matrix work that cheap, what happens around it sets the pace, so a workgroup (one per CU) splits it over
+// three kinds of waves:
+//   * producers (2 waves) stream the prepared reference image into an LDS ring of slots of two tiles;
+//   * consumers (8 waves x 32 queries) sweep the ring.  Per slot: the two tiles' MFMA chains interleaved on independent
+//     accumulators with the fragment reads of the next slot in their gaps, then the filter -- the 32 x 32 accumulator
+//     puts a query on each lane; min over its 16 values (v_min3 tree), one compare, one scalar branch: most tiles end
+//     here -- and the spill: a lane whose group of 4 consecutive references holds a survivor dumps the group's four raw
+//     values (one ds_write_b128) and a tag (tile, group, lane) into its wave's queue in the LDS.  Nothing else: no
+//     list handling, no threshold bookkeeping in the sweep;
+//   * service waves (4, lowest issue priority) work the queues off while the consumers sweep: 32 records = 128 values
+//     per pass with all 64 lanes busy, each lane re-tests values against their query's current threshold and appends
+//     survivors to the query's list with an LDS atomic; a list (KS kept + pending, <= 64 entries, unsorted) is cut back
+//     to about its KS smallest by pivot trials / quickselect over the wave and the threshold, an LDS word the consumer
+//     re-reads once per slot, drops to the cut.  They also write the final lists out (the consumers help).
+// Hand-over everywhere through LDS words and counters, no barrier in the loop.  Shared thresholds across reference
+// ranges and the register-only sample pass follow knn_bf16.hip.
 #include "bmx_common.hpp"
 #include "knn_select.hpp"
 
