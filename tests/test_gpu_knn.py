@@ -89,3 +89,19 @@ def test_query_knn_clusters_the_first_tier_certifies(oracle, nb):
     idx, dist = nb.query_knn(X, Q, 20)
     oi, od = oracle.query_knn(X, Q, 20)
     assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+
+
+@pytest.mark.parametrize("sample,force_c", [("0", None), ("0", "3"), ("1024", "2")])
+def test_query_knn_spill_queue_under_pressure(oracle, nb, monkeypatch, sample, force_c):
+    # the candidate kernel's consumers hand every survivor to service waves through a 64-record queue.  Without a
+    # sampled threshold ("0") a 20 000-row sweep starts with every value a survivor: the queue wraps many times, the
+    # consumers wait for room, and lists are compacted while more is appended; with ranges, thresholds are shared
+    # through global words as well.  Must still be the oracle's answer, bit for bit.
+    monkeypatch.setenv("BMX_SAMPLE", sample)
+    if force_c:
+        monkeypatch.setenv("BMX_FORCE_C", force_c)
+    X, Q = synth_batches(9, [20000, 2500], 20)
+    idx, dist = nb.query_knn(X, Q, 20)
+    oi, od = oracle.query_knn(X, Q, 20)
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+    assert nb.last_knn_exact_fallbacks() <= 25
