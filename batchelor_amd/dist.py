@@ -108,5 +108,17 @@ def init_engine_rccl(engine, group=None):
     if world > 1:
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
     uid = ctypes.create_string_buffer(box[0], 128)
-    _lib.check(lib.bmx_engine_init_rccl(engine._h, int(rank), int(world), uid, 128))
+    try:
+        _lib.check(lib.bmx_engine_init_rccl(engine._h, int(rank), int(world), uid, 128))
+    except Exception as exc:  # noqa: BLE001
+        err = exc
+    if world > 1:
+        # the same agreement after the communicator set-up: a rank that alone fell back to the host-supplied
+        # all-gather would wait for the others in a different collective for ever
+        flag = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        if int(flag.item()) and err is None:
+            err = RuntimeError("the RCCL communicator could not be made on another rank")
+    if err is not None:
+        raise err
     return rank, world
