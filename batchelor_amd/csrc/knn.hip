@@ -170,6 +170,7 @@ __global__ void seed_tau_kernel(const float* __restrict__ seed_d2, const double*
     tau_g[q] = q < nq ? min(tau_g[q], o) : o;  // the image is order-preserving: min of images = image of the min
 }
 
+template <int REFINE_NC>  // pieces of 8 doubles (one 16-byte load per lane of a quad) a row may have; 0: lane-per-row gather
 __global__ __launch_bounds__(256) void knn_refine(const double* __restrict__ X, const int32_t* __restrict__ ref_rows,
                                                   const double* __restrict__ Q, const int32_t* __restrict__ q_rows,
                                                   int nq, int d, int k, int KS, int nchunks, double eps_k, double eps_qr,
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(256) void knn_refine(const double* __restrict__ X, 
                                                   const float* __restrict__ seed_d2, int32_t* __restrict__ idx_out,
                                                   double* __restrict__ dist_out, int32_t* __restrict__ flagged,
                                                   double* __restrict__ flag_bound) {
-    __shared__ double sd[4][REFINE_MAXM];
+    __shared__ __attribute__((aligned(16))) double sd[4][REFINE_MAXM];
     __shared__ int si[4][REFINE_MAXM];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int q = blockIdx.x * 4 + w;
@@ -194,7 +195,9 @@ __global__ __launch_bounds__(256) void knn_refine(const double* __restrict__ X, 
     const double eps = pass_eps(sqrt(qn2[q]), sqrt(max_rn2), s, eps_k, eps_qr, eps_split, eps_den);
     // 1. dense list of the valid candidates (ballot prefix)
     int M = 0;
-    float* sv = reinterpret_cast<float*>(&sd[w][0]) + REFINE_MAXM;  // upper half of this wave's sd row: approx values
+    // this wave's sd row doubles as the list of rank keys until the exact distances go there: (order-preserving image
+    // of the approximate value) << 32 | index -- unique, and ordered like (value, index)
+    unsigned long long* sk = reinterpret_cast<unsigned long long*>(&sd[w][0]);
     for (int m0 = 0; m0 < Mall; m0 += 64) {
         const int m = m0 + lane;
         const int id = m < Mall ? cand[(int64_t)q * Mall + m] : -1;
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(256) void knn_refine(const double* __restrict__ X, 
         const int pos = M + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
         if (id >= 0) {
             si[w][pos] = id;
-            if (cand_v) sv[pos] = cand_v[(int64_t)q * Mall + m];
+            if (cand_v) sk[pos] = ((unsigned long long)f32_orderable(cand_v[(int64_t)q * Mall + m]) << 32) | (uint32_t)id;
         }
         M += __builtin_popcountll(mask);
     }
@@ -221,15 +224,18 @@ __global__ __launch_bounds__(256) void knn_refine(const double* __restrict__ X, 
             ids[uu] = 0;
             vs[uu] = 0.f;
             if (m < M) {
-                const float vm = sv[m];
-                const int im = si[w][m];
+                const unsigned long long km = sk[m];
+                const float vm = orderable_f32((uint32_t)(km >> 32));
                 int rank = 0;
-                for (int f = 0; f < M; ++f) {
-                    const float vf = sv[f];
-                    rank += (vf < vm || (vf == vm && si[w][f] < im)) ? 1 : 0;
+                int f = 0;
+                for (; f + 2 <= M; f += 2) {  // (16-byte reads: the row is 16-byte aligned, f even)
+                    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+                    const u64x2 kf = *reinterpret_cast<const u64x2*>(sk + f);
+                    rank += (kf[0] < km ? 1 : 0) + (kf[1] < km ? 1 : 0);
                 }
+                if (f < M) rank += sk[f] < km ? 1 : 0;
                 rk[uu] = rank;
-                ids[uu] = im;
+                ids[uu] = (int)(uint32_t)km;
                 vs[uu] = vm;
                 if (rank == k - 1) vk = vm;
                 if (rank == KS) tmerge = vm;  // the first one cut by rank bounds all the others cut from below
@@ -257,9 +263,64 @@ __global__ __launch_bounds__(256) void knn_refine(const double* __restrict__ X, 
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
     // 3. exact distances and ranks
-    for (int m = lane; m < M; m += 64) {
-        const int id = si[w][m];
-        sd[w][m] = exact_d2(qv, X + (int64_t)(ref_rows ? ref_rows[id] : id) * d, d);
+    if constexpr (REFINE_NC > 0) {
+        // Four lanes per candidate row: their 16-byte loads are 64 contiguous bytes of the (randomly placed) row, so
+        // every cache line of it is asked for twice instead of eight times as with a lane per row.  The sum stays the
+        // reference's: one running value per row, handed from lane to lane of the quad (DPP) every two elements,
+        // strictly left to right (compiled with -ffp-contract=off: bit for bit the CPU's sum).
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        const int g = lane >> 2, p = lane & 3;
+        const int np = d >> 1;  // 16-byte pieces per row
+        const d2* q2 = reinterpret_cast<const d2*>(qv);
+        d2 x[REFINE_NC > 0 ? REFINE_NC : 1];
+#pragma unroll
+        for (int c = 0; c < REFINE_NC; ++c) {
+            x[c] = d2{0.0, 0.0};
+            if (4 * c + p < np) x[c] = q2[4 * c + p];
+        }
+        const int p_last = (np - 1) & 3;
+        for (int r0 = 0; r0 < M; r0 += 16) {
+            const int m = r0 + g;
+            const int id = si[w][m < M ? m : 0];
+            const d2* row2 = reinterpret_cast<const d2*>(X + (int64_t)(ref_rows ? ref_rows[id] : id) * d);
+            d2 y[REFINE_NC > 0 ? REFINE_NC : 1];
+#pragma unroll
+            for (int c = 0; c < REFINE_NC; ++c) {
+                y[c] = d2{0.0, 0.0};
+                if (4 * c + p < np) y[c] = row2[4 * c + p];
+            }
+            // the squares: every lane its own two per piece, all at once; only the additions have an order
+#pragma unroll
+            for (int c = 0; c < REFINE_NC; ++c) {
+                const double t0 = x[c][0] - y[c][0], t1 = x[c][1] - y[c][1];
+                y[c][0] = t0 * t0;
+                y[c][1] = t1 * t1;
+            }
+            double acc = 0.0;
+#pragma unroll
+            for (int c = 0; c < REFINE_NC; ++c) {
+                if (4 * c < np) {  // (wave-uniform)
+#pragma unroll
+                    for (int ph = 0; ph < 4; ++ph) {
+                        // the running sum as the previous lane of the quad has it (lane 0: lane 3's, from the piece before)
+                        const unsigned long long bits = (unsigned long long)__double_as_longlong(acc);
+                        const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)bits, 0x93, 0xF, 0xF, false);
+                        const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(bits >> 32), 0x93, 0xF, 0xF, false);
+                        const double prev = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+                        // (0 + x is x exactly: the first element needs no case of its own -- prev is lane 3's untouched 0)
+                        double run = prev + y[c][0];
+                        run += y[c][1];
+                        if (p == ph && 4 * c + ph < np) acc = run;
+                    }
+                }
+            }
+            if (p == p_last && m < M) sd[w][m] = acc;
+        }
+    } else {
+        for (int m = lane; m < M; m += 64) {
+            const int id = si[w][m];
+            sd[w][m] = exact_d2(qv, X + (int64_t)(ref_rows ? ref_rows[id] : id) * d, d);
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     // fewer than k candidates: never certified -- unless the search was seeded, where the row is complete as soon as
@@ -619,9 +680,22 @@ void candidate_pass(hipStream_t stream, KnnWorkspace& ws, const Tier& T, const d
     if (!ok) throw Error(BMX_ERR_ARG, "kNN: unsupported padded dimension");
 
     BMX_HIP(hipMemsetAsync(flagged, 0, sizeof(int32_t), stream));
-    hipLaunchKernelGGL(knn_refine, dim3(cdiv(nq, 4)), dim3(256), 0, stream, X, ref_rows, Qs, qrs, nq, d, k, KS, nchunks,
-                       eps_k, eps_qr, eps_split, eps_den, T.id == 1 ? 1 : 0, cand, cand_v, tau, qn2, maxbits, seed_d2, io,
-                       dout, flagged, flag_bound);
+    {
+        // rows of an even number of doubles are 16-byte aligned: the quad gather, instantiated for the row length
+        const int need = (d & 1) ? 0 : cdiv(d, 8);
+#define BMX_REFINE(NC) \
+    hipLaunchKernelGGL(knn_refine<NC>, dim3(cdiv(nq, 4)), dim3(256), 0, stream, X, ref_rows, Qs, qrs, nq, d, k, KS, nchunks, \
+                       eps_k, eps_qr, eps_split, eps_den, T.id == 1 ? 1 : 0, cand, cand_v, tau, qn2, maxbits, seed_d2, io, \
+                       dout, flagged, flag_bound)
+        if (need == 0 || need > 16) BMX_REFINE(0);
+        else if (need <= 2) BMX_REFINE(2);
+        else if (need <= 4) BMX_REFINE(4);
+        else if (need <= 7) BMX_REFINE(7);
+        else if (need <= 10) BMX_REFINE(10);
+        else if (need <= 13) BMX_REFINE(13);
+        else BMX_REFINE(16);
+#undef BMX_REFINE
+    }
     BMX_LAUNCH_CHECK();
     if (std::getenv("BMX_DEBUG")) {
         std::vector<int32_t> hc((size_t)nq * nchunks * KS);
