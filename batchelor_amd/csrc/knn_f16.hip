@@ -449,16 +449,20 @@ __global__ __launch_bounds__((NCONS + NPROD + serv_waves(NS)) * 64) void knn_top
             // same wave, in-order LDS queue: the flag lands after the tiles
             if (lane == 0) __hip_atomic_store(&ready[pos], sl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         };
-        // two register sets: the loads of slot sl + NPROD are in flight while slot sl is handed over
-        int sl = p;
-        if (sl < nslots) load(ra, sl);
-        if (sl + NPROD < nslots) load(rb, sl + NPROD);
-        for (; sl < nslots; sl += 2 * NPROD) {
-            publish(ra, sl);
-            if (sl + 2 * NPROD < nslots) load(ra, sl + 2 * NPROD);
-            if (sl + NPROD < nslots) {
-                publish(rb, sl + NPROD);
-                if (sl + 3 * NPROD < nslots) load(rb, sl + 3 * NPROD);
+        // two register sets: the loads of slot sl + NPROD stay in flight while slot sl is handed over.  Every load below is
+        // unconditional (past the end: the last slot again, never published): with conditional loads the compiler has to
+        // wait for ALL outstanding loads before it touches a register set -- the set just asked for included -- because
+        // it cannot tell how many are in flight
+        if (nslots > 0) {
+            const int last = nslots - 1;
+            int sl = p;
+            load(ra, sl < last ? sl : last);
+            load(rb, sl + NPROD < last ? sl + NPROD : last);
+            for (; sl < nslots; sl += 2 * NPROD) {
+                publish(ra, sl);
+                load(ra, sl + 2 * NPROD < last ? sl + 2 * NPROD : last);
+                if (sl + NPROD < nslots) publish(rb, sl + NPROD);
+                load(rb, sl + 3 * NPROD < last ? sl + 3 * NPROD : last);
             }
         }
         // two empty slots past the end: the consumers' loop runs one step longer than the data and always refills from
