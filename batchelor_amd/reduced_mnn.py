@@ -172,12 +172,14 @@ class MnnEngine:
             out.append(dict(zip(("nL", "nR", "U", "P", "nL_all", "nR_all"), a.tolist())))
         return out
 
-    def download(self, with_pairs=True) -> MnnResult:
+    def download(self, with_pairs=True, c_order=True) -> MnnResult:
+        """Results to the host.  The boundary writes `corrected` column-major (as R holds matrices); `c_order=False`
+        returns it that way instead of converting it to numpy's row-major default."""
         B, d = self.nbatches, self.d
         N = int(sum(self.nrows))
         nm = B - 1
-        corrected = np.zeros((N, d), dtype=np.float64, order="F")
-        batch = np.zeros(N, dtype=np.int32)
+        corrected = np.empty((N, d), dtype=np.float64, order="F")  # (every element is written by the library)
+        batch = np.empty(N, dtype=np.int32)
         ml = np.zeros((nm, B), dtype=np.int32)
         mr = np.zeros((nm, B), dtype=np.int32)
         bs = np.zeros(nm, dtype=np.float64)
@@ -193,7 +195,7 @@ class MnnEngine:
                 pairs.append((_lib.take_i32(pl, n.value).astype(np.int64), _lib.take_i32(pr, n.value).astype(np.int64)))
         info = MergeInfo(left=[[int(x) for x in row if x] for row in ml], right=[[int(x) for x in row if x] for row in mr],
                          pairs=pairs, batch_size=bs, skipped=sk.astype(bool), lost_var=np.ascontiguousarray(lv))
-        return MnnResult(corrected=np.ascontiguousarray(corrected), batch=batch, merge_info=info,
+        return MnnResult(corrected=np.ascontiguousarray(corrected) if c_order else corrected, batch=batch, merge_info=info,
                          stats=self.merge_stats())
 
 

@@ -363,12 +363,13 @@ def main():
     if world == 1 and not args.no_host_to_host:
         eng.set_profiling(False)
         reps = []
+        fbatches = [np.asfortranarray(b) for b in batches]  # what the boundary is handed: column-major matrices
         for _ in range(2):
             t1 = time.perf_counter()
             e2 = bx.MnnEngine(local_rank)
-            e2.upload(batches)
+            e2.upload(fbatches)
             e2.run(k=k, merge_tree=tree, **run_kw)
-            res = e2.download(with_pairs=True)
+            res = e2.download(with_pairs=True, c_order=False)
             e2.close()
             reps.append(time.perf_counter() - t1)
             del res
