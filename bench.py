@@ -267,8 +267,8 @@ def run_sgk(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS) + ["config4", "sgk"])
     ap.add_argument("--cells", type=int, default=25000, help="config4: cells per batch")
     ap.add_argument("--pca-iters", type=int, default=15, help="config4: subspace iterations")
