@@ -558,7 +558,8 @@ void candidate_pass(hipStream_t stream, KnnWorkspace& ws, const Tier& T, const d
                     int32_t* flagged, double* flag_bound, const float* seed_d2) {
     const int NS = T.NS, KS = T.KS;
     ws.last_variant = T.id == 1 ? 3 : 2;
-    const int unit = 256;  // queries per workgroup: 8 consumer waves of 32 (both ring kernels)
+    // queries per workgroup: 8 consumer waves of 32 in the fp16 kernel; 8 or 4 (long rows, long lists) in the bf16 kernel
+    const int unit = T.id == 1 ? 256 : 32 * bf16_ncons(NS, KS);
     const int nq_pad = (int)round_up(nq, unit);
     const int nqb = nq_pad / unit;
 

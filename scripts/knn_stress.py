@@ -1,0 +1,36 @@
+"""Developer helper (GPU box): random kNN shapes through the C ABI against the CPU oracle, bit for bit.
+   python scripts/knn_stress.py <cases> <seed>"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests.conftest import synth_batches  # noqa: E402
+from batchelor_amd import neighbors as nb  # noqa: E402
+from oracle import fastmnn_oracle as oracle  # noqa: E402
+
+cases, seed = int(sys.argv[1]), int(sys.argv[2])
+rng = np.random.default_rng(seed)
+bad = 0
+for case in range(cases):
+    nx = int(rng.choice([64, 70, 130, 500, 2100, 4095, 4100, 9000, 20000, 33000, 70000]))
+    nq = int(rng.choice([1, 31, 257, 900, 2500, 6000]))
+    d = int(rng.integers(2, 126))
+    k = int(min(rng.choice([1, 5, 20, 21, 36]), nx))
+    force_c = str(rng.choice(["", "1", "2", "3", "5", "7"]))
+    sample = str(rng.choice(["", "", "0", "1024", "4096"]))
+    for name, val in (("BMX_FORCE_C", force_c), ("BMX_SAMPLE", sample)):
+        if val:
+            os.environ[name] = val
+        else:
+            os.environ.pop(name, None)
+    print("case", case, nx, nq, d, k, repr(force_c), repr(sample), flush=True)
+    X, Q = synth_batches(1000 + seed * 1000 + case, [nx, nq], d)
+    idx, dist = nb.query_knn(X, Q, k)
+    oi, od = oracle.query_knn(X, Q, k)
+    ok = np.array_equal(idx, oi) and np.array_equal(dist, od)
+    if not ok:
+        bad += 1
+        print("MISMATCH", case, nx, nq, d, k, force_c, sample, flush=True)
+print("cases", cases, "mismatches", bad, flush=True)

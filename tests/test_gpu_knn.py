@@ -105,3 +105,42 @@ def test_query_knn_spill_queue_under_pressure(oracle, nb, monkeypatch, sample, f
     oi, od = oracle.query_knn(X, Q, 20)
     assert np.array_equal(idx, oi) and np.array_equal(dist, od)
     assert nb.last_knn_exact_fallbacks() <= 25
+
+
+def test_query_knn_random_shapes(oracle, nb, monkeypatch):
+    # seeded draw of shapes, range counts and sample sizes around the candidate kernel's corner cases: rings shorter
+    # than their slot count, one-slot ranges, references just above / below the sampling limits, single queries,
+    # k at both list sizes, every fragment-count class
+    rng = np.random.default_rng(20250314)
+    for case in range(24):
+        nx = int(rng.choice([70, 130, 500, 2100, 4095, 4100, 9000, 33000]))
+        nq = int(rng.choice([1, 31, 257, 900, 2500]))
+        d = int(rng.choice([2, 7, 16, 29, 45, 50, 61, 64, 77, 100, 125]))
+        k = int(min(rng.choice([1, 5, 20, 21, 36]), nx))
+        force_c = rng.choice(["", "1", "2", "5"])
+        sample = rng.choice(["", "0", "1024"])
+        for name, val in (("BMX_FORCE_C", force_c), ("BMX_SAMPLE", sample)):
+            if val:
+                monkeypatch.setenv(name, str(val))
+            else:
+                monkeypatch.delenv(name, raising=False)
+        X, Q = synth_batches(100 + case, [nx, nq], d)
+        idx, dist = nb.query_knn(X, Q, k)
+        oi, od = oracle.query_knn(X, Q, k)
+        assert np.array_equal(idx, oi), (case, nx, nq, d, k, force_c, sample)
+        assert np.array_equal(dist, od), (case, nx, nq, d, k, force_c, sample)
+
+
+@pytest.mark.parametrize("nx,nq,d,k,tier", [(2500, 1200, 84, 20, "2"), (2500, 1200, 120, 20, "2"), (1500, 900, 31, 20, "2"),
+                                            (2500, 1200, 50, 30, "2"), (3000, 2000, 100, 30, None),
+                                            (3000, 2000, 70, 36, None)])
+def test_query_knn_second_tier_shapes(oracle, nb, monkeypatch, nx, nq, d, k, tier):
+    # the split-bf16 kernel runs 8 or 4 consumer waves per workgroup (long rows and long lists: 4), and the host has to
+    # size its query blocks accordingly.  It is the first tier for k in 21..36 beyond 61 dimensions; BMX_KNN_TIER=2 sends
+    # the other shapes through it as well.
+    if tier:
+        monkeypatch.setenv("BMX_KNN_TIER", tier)
+    X, Q = synth_batches(11, [nx, nq], d)
+    idx, dist = nb.query_knn(X, Q, k)
+    oi, od = oracle.query_knn(X, Q, k)
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od)
