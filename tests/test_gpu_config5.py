@@ -74,3 +74,57 @@ def test_variance_adjusted_merge_vs_oracle(oracle, sigma):
     # a later merge runs on top of the adjusted cells without trouble
     three = bx.reducedMNN(*synth_batches(5, [1200, 900, 700], 12), var_adj=True, sigma=sigma)
     assert np.all(np.isfinite(three.corrected)) and len(three.merge_info.pairs) == 2
+
+
+@pytest.fixture(scope="module")
+def full5():
+    """BASELINE.json configs[4] at full size (the bench.py workload): 16 batches of 8 894 .. 281 334 cells, 100 PCs,
+    balanced tree; two runs, each keeping the two matrices one merge searched."""
+    import batchelor_amd as bx
+    from bench import WORKLOADS
+    cfg, sizes, d, k, tree = WORKLOADS["config5"]
+    B = synth_batches(cfg, sizes, d)
+    eng = bx.MnnEngine()
+    eng.upload(B)
+    from batchelor_amd.merge_tree import resolve_merge_order
+    code = resolve_merge_order(len(sizes), tree)
+    runs = {}
+    for m in (9, 14):  # a merge in the middle of the tree, and the root: two eight-batch subtrees
+        eng.set_snapshot(m)
+        eng.run(k=k, merge_tree=code)
+        runs[m] = (eng.download(), eng.snapshot())
+    eng.close()
+    return sizes, d, k, runs
+
+
+def test_full_size_config5_deterministic(full5):
+    sizes, d, k, runs = full5
+    a, b = runs[9][0], runs[14][0]
+    assert np.array_equal(a.corrected, b.corrected) and np.all(np.isfinite(a.corrected))
+    for (l0, r0), (l1, r1) in zip(a.merge_info.pairs, b.merge_info.pairs):
+        assert np.array_equal(l0, l1) and np.array_equal(r0, r1)
+    assert len(a.merge_info.pairs) == 15 and not a.merge_info.skipped.any()
+
+
+@pytest.mark.parametrize("m", [9, 14])
+def test_full_size_config5_pairs_of_sampled_cells_match_oracle(oracle, full5, m):
+    sizes, d, k, runs = full5
+    res, (left, right) = runs[m]
+    lset, rset = res.merge_info.left[m], res.merge_info.right[m]
+    assert left.shape == (sum(sizes[b - 1] for b in lset), d) and right.shape == (sum(sizes[b - 1] for b in rset), d)
+    start = np.concatenate([[0], np.cumsum(sizes)])
+
+    def global_ids(bset):  # 1-based ids, in the input's cell order, of a node's rows (its batches in merge order)
+        return np.concatenate([np.arange(start[b - 1], start[b]) + 1 for b in bset])
+    gl, gr = global_ids(lset), global_ids(rset)
+    rng = np.random.default_rng(500 + m)
+    rows = np.sort(rng.choice(right.shape[0], 160, replace=False))     # sampled right cells (node rows)
+    nn_l, _ = oracle.query_knn(left, right[rows], k)                   # their k nearest left rows (1-based)
+    cand = np.unique(nn_l)
+    nn_r, _ = oracle.query_knn(right, left[cand - 1], k)
+    back = {int(c): set(row.tolist()) for c, row in zip(cand, nn_r)}
+    expect = {(int(gl[l - 1]), int(gr[r])) for r, row in zip(rows, nn_l) for l in row.tolist() if int(r) + 1 in back[int(l)]}
+    pl, pr = res.merge_info.pairs[m]
+    keep = np.isin(pr, gr[rows])
+    got = set(zip(pl[keep].tolist(), pr[keep].tolist()))
+    assert got == expect and len(expect) > 50
