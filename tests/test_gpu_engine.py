@@ -158,3 +158,27 @@ def test_engine_reuse_and_profile(bx):
     prof = eng.profile()
     assert prof["topk_launches"] == 3 and prof["topk_ms"] > 0
     eng.close()
+
+
+def test_engine_random_configurations(oracle, bx):
+    # a seeded draw over batch counts, sizes, dimensions, k / prop.k, merge orders, auto-merge and restrictions
+    # (scripts/engine_stress.py runs the same generator for as long as one likes)
+    rng = np.random.default_rng(20250315)
+    for case in range(8):
+        nb = int(rng.integers(2, 6))
+        sizes = [int(rng.choice([60, 150, 400, 900, 2000])) for _ in range(nb)]
+        d = int(rng.choice([2, 5, 20, 50, 64, 100]))
+        mode = case % 5
+        kw = {}
+        if mode == 0:
+            kw["k"] = int(rng.choice([2, 5, 10, 25, 30]))
+        elif mode == 1:
+            kw["prop_k"] = float(rng.choice([0.01, 0.05, 0.1]))
+        elif mode == 2:
+            kw["merge_order"] = [int(x) for x in rng.permutation(nb) + 1]
+        elif mode == 3:
+            kw["auto_merge"] = True
+        else:
+            kw["restrict"] = [np.sort(rng.choice(n, size=max(30, n // 2), replace=False)) + 1 for n in sizes]
+        B = synth_batches(400 + case, sizes, d)
+        assert_same_result(bx.reducedMNN(*B, **kw), oracle.reduced_mnn(*B, **kw))
