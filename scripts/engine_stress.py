@@ -21,9 +21,10 @@ for case in range(cases):
     kw = {}
     mode = int(rng.integers(0, 6))
     if mode == 1:
-        # (k = 1 with more than two batches is degenerate: a corrected MNN cell lands exactly on its partner, and the next
-        # merge has to break the tie between the two within an ulp)
-        kw["k"] = int(rng.choice([1, 5, 10, 25, 30, 40] if nb == 2 else [2, 5, 10, 25, 30, 40]))
+        # (k <= 2 with more than two batches is degenerate: the tricube bandwidth of an MNN cell is the distance to itself,
+        # a cell with one pair lands exactly on its partner, and the next merge has to break the tie between the two
+        # within an ulp)
+        kw["k"] = int(rng.choice([1, 5, 10, 25, 30, 40] if nb == 2 else [3, 5, 10, 25, 30, 40]))
     elif mode == 2:
         kw["prop_k"] = float(rng.choice([0.01, 0.05, 0.1]))
     elif mode == 3:
