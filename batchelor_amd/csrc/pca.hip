@@ -14,7 +14,8 @@
 // normalisation (R/cosineNorm.R, fastMNN's cos.norm=TRUE) is a per-cell factor folded into the two products, the
 // centring a rank-one correction -- the normalised, centred data is never written.
 // Both products run on the FP64 matrix cores (v_mfma_f64_16x16x4_f64): 64 x 64 output tiles per workgroup, operands
-// staged in the LDS with pitches that keep the 32-lane fragment reads conflict-free.
+// brought in by whole-row 16-byte loads one K step ahead (registers) and staged in the LDS with pitches that keep the
+// 32-lane fragment reads conflict-free.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -27,6 +28,7 @@ namespace bmx {
 namespace {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));  // two doubles at any 8-byte boundary
 constexpr int PL = 64;   // subspace width (MFMA tile multiple)
 constexpr int KC = 32;   // K elements staged per step
 
@@ -41,22 +43,33 @@ __global__ __launch_bounds__(256) void gemm_nt64(const double* __restrict__ X, i
                                                  const double* __restrict__ rs, const double* __restrict__ off,
                                                  double* __restrict__ Z) {
     constexpr int P = KC + 2;  // pitch 34 doubles: lanes (row 0..15, k 0..1) hit 32 different 8-byte bank pairs
-    __shared__ double xs[64 * P];
-    __shared__ double bs[64 * P];
+    __shared__ __attribute__((aligned(16))) double xs[64 * P];
+    __shared__ __attribute__((aligned(16))) double bs[64 * P];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t r0 = (int64_t)blockIdx.x * 64;
     d4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
-    const int lr = tid >> 2, seg = (tid & 3) * 8;  // 64 rows x 4 segments of 8 doubles
-    for (int k0 = 0; k0 < K; k0 += KC) {
+    // a K step of both operands is 64 rows x 256 bytes: sixteen lanes take one row piece in 16-byte loads (whole cache
+    // lines per row), and the step after the one being multiplied is already on its way into registers
+    const int lrow = tid >> 4, lk = (tid & 15) * 2;
+    const double* xp[4];
+    const double* bp[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int k = k0 + seg + e;
-            xs[lr * P + seg + e] = (r0 + lr < n && k < K) ? X[(r0 + lr) * ldx + k] : 0.0;
-            bs[lr * P + seg + e] = k < K ? B[(int64_t)lr * ldb + k] : 0.0;
+    for (int i = 0; i < 4; ++i) {
+        const int64_t r = r0 + lrow + 16 * i;
+        xp[i] = X + (r < n ? r : n - 1) * ldx + lk;  // rows past the end: any valid row, never stored
+        bp[i] = B + (int64_t)(lrow + 16 * i) * ldb + lk;
+    }
+    d2u px[4], pb[4];
+    auto fetch = [&](const int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            px[i] = *reinterpret_cast<const d2u*>(xp[i] + k0);
+            pb[i] = *reinterpret_cast<const d2u*>(bp[i] + k0);
         }
-        __syncthreads();
+    };
+    auto multiply = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int kk = 0; kk < KC / 4; ++kk) {
             const double a = xs[(16 * w + (lane & 15)) * P + 4 * kk + (lane >> 4)];
@@ -66,7 +79,30 @@ __global__ __launch_bounds__(256) void gemm_nt64(const double* __restrict__ X, i
                 acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
             }
         }
+    };
+    const int nfull = K / KC;
+    if (nfull > 0) fetch(0);
+    for (int st = 0; st < nfull; ++st) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<d2u*>(&xs[(lrow + 16 * i) * P + lk]) = px[i];
+            *reinterpret_cast<d2u*>(&bs[(lrow + 16 * i) * P + lk]) = pb[i];
+        }
         __syncthreads();
+        if (st + 1 < nfull) fetch((st + 1) * KC);
+        multiply();
+        __syncthreads();
+    }
+    if (K % KC) {  // the ragged last step, element by element
+        const int k0 = nfull * KC, lr = tid >> 2, seg = (tid & 3) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = k0 + seg + e;
+            xs[lr * P + seg + e] = (r0 + lr < n && k < K) ? X[(r0 + lr) * ldx + k] : 0.0;
+            bs[lr * P + seg + e] = k < K ? B[(int64_t)lr * ldb + k] : 0.0;
+        }
+        __syncthreads();
+        multiply();
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -88,25 +124,15 @@ __global__ __launch_bounds__(256) void gemm_tn64(const double* __restrict__ X, i
                                                  const double* __restrict__ Z, const double* __restrict__ rs,
                                                  int64_t rows_per_split, double* __restrict__ Ypart) {
     constexpr int P = 64 + 16;  // pitch 80 doubles: lanes (col 0..15, k 0..1) hit 32 different bank pairs
-    __shared__ double xs[KC * P];
-    __shared__ double zs[KC * P];
+    __shared__ __attribute__((aligned(16))) double xs[KC * P];
+    __shared__ __attribute__((aligned(16))) double zs[KC * P];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int g0 = blockIdx.x * 64;
     const int64_t rbeg = (int64_t)blockIdx.y * rows_per_split, rend = min(n, rbeg + rows_per_split);
     d4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
-    const int lr = tid >> 3, seg = (tid & 7) * 8;  // 32 rows x 8 segments of 8 doubles
-    for (int64_t r0 = rbeg; r0 < rend; r0 += KC) {
-        const int64_t r = r0 + lr;
-        const double f = (r < rend && rs) ? rs[r] : 1.0;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int g = g0 + seg + e;
-            xs[lr * P + seg + e] = (r < rend && g < G) ? X[r * ldx + g] : 0.0;
-            zs[lr * P + seg + e] = r < rend ? f * Z[r * 64 + seg + e] : 0.0;
-        }
-        __syncthreads();
+    auto multiply = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int kk = 0; kk < KC / 4; ++kk) {
             const double a = xs[(4 * kk + (lane >> 4)) * P + 16 * w + (lane & 15)];  // A[row = gene][k = cell]
@@ -116,7 +142,54 @@ __global__ __launch_bounds__(256) void gemm_tn64(const double* __restrict__ X, i
                 acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
             }
         }
-        __syncthreads();
+    };
+    if (g0 + 64 <= G) {
+        // a step is 32 cells x 64 genes (and x 64 subspace columns): thirty-two lanes take one cell's 512 bytes in 16-byte
+        // loads, the step after the one being multiplied already on its way into registers
+        const int lr = tid >> 5, lg = (tid & 31) * 2;
+        d2u px[4], pz[4];
+        auto fetch = [&](const int64_t r0) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t r = r0 + lr + 8 * i;
+                if (r < rend) {
+                    const double f = rs ? rs[r] : 1.0;
+                    px[i] = *reinterpret_cast<const d2u*>(X + r * ldx + g0 + lg);
+                    const d2u z = *reinterpret_cast<const d2u*>(Z + r * 64 + lg);
+                    pz[i] = d2u{f * z[0], f * z[1]};
+                } else {
+                    px[i] = d2u{0.0, 0.0};
+                    pz[i] = d2u{0.0, 0.0};
+                }
+            }
+        };
+        if (rbeg < rend) fetch(rbeg);
+        for (int64_t r0 = rbeg; r0 < rend; r0 += KC) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                *reinterpret_cast<d2u*>(&xs[(lr + 8 * i) * P + lg]) = px[i];
+                *reinterpret_cast<d2u*>(&zs[(lr + 8 * i) * P + lg]) = pz[i];
+            }
+            __syncthreads();
+            if (r0 + KC < rend) fetch(r0 + KC);
+            multiply();
+            __syncthreads();
+        }
+    } else {  // the ragged last gene tile, element by element
+        const int lr = tid >> 3, seg = (tid & 7) * 8;  // 32 rows x 8 segments of 8 doubles
+        for (int64_t r0 = rbeg; r0 < rend; r0 += KC) {
+            const int64_t r = r0 + lr;
+            const double f = (r < rend && rs) ? rs[r] : 1.0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int g = g0 + seg + e;
+                xs[lr * P + seg + e] = (r < rend && g < G) ? X[r * ldx + g] : 0.0;
+                zs[lr * P + seg + e] = r < rend ? f * Z[r * 64 + seg + e] : 0.0;
+            }
+            __syncthreads();
+            multiply();
+            __syncthreads();
+        }
     }
     double* out = Ypart + (int64_t)blockIdx.y * G * 64;
 #pragma unroll
@@ -130,7 +203,6 @@ __global__ __launch_bounds__(256) void gemm_tn64(const double* __restrict__ X, i
     }
 }
 
-// Y[e] = beta * Y[e] + alpha * sum_s part[s][e]
 __global__ void reduce_parts(const double* __restrict__ part, int nsplit, int64_t len, double alpha, double beta,
                              double* __restrict__ Y) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
