@@ -1,6 +1,8 @@
 // extern "C" boundary of libbatchelor_mi355x.so (declared in include/batchelor_mi355x.h).
 // Nothing throws across it: exceptions become return codes + a thread-local message.
+#include <algorithm>
 #include <climits>
+#include <cstddef>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -62,6 +64,27 @@ double* upload_rm(bmx::DevBuf<double>& tmp, bmx::DevBuf<double>& out, const doub
     const double* dcm = upload(tmp, cm, (size_t)n * d, s);
     double* p = out.reserve(std::max<size_t>((size_t)n * d, 1));
     bmx::transpose_cm_to_rm(s, dcm, n, d, p);
+    return p;
+}
+
+// The caller's bmx_params_t may come from an older (shorter) or a newer (longer) header: struct_size says how much of
+// it is there.  Fields the caller does not have keep their defaults; bytes this library does not know must be zero.
+bmx_params_t read_params(const bmx_params_t* params) {
+    if (!params) throw bmx::Error(BMX_ERR_ARG, "null params");
+    bmx_params_t p;
+    std::memset(&p, 0, sizeof(p));
+    p.sigma = 0.1;
+    const int32_t sz = params->struct_size;
+    const size_t need = offsetof(bmx_params_t, auto_merge) + sizeof(int32_t);
+    if (sz < (int32_t)need)
+        throw bmx::Error(BMX_ERR_ARG, "bmx_params_t.struct_size is not set (expected sizeof(bmx_params_t))");
+    if ((size_t)sz > sizeof(p)) {
+        const unsigned char* extra = reinterpret_cast<const unsigned char*>(params) + sizeof(p);
+        for (size_t i = 0; i < (size_t)sz - sizeof(p); ++i)
+            if (extra[i]) throw bmx::Error(BMX_ERR_ARG, "bmx_params_t carries fields this library version does not know");
+    }
+    std::memcpy(&p, params, std::min((size_t)sz, sizeof(p)));
+    p.struct_size = (int32_t)sizeof(p);
     return p;
 }
 
@@ -472,8 +495,34 @@ int32_t bmx_pca_add_batch(bmx_pca_t* p, const double* x, int64_t n, double weigh
     return guarded([&] { bmx::pca_add_batch(p->impl, x, n, weight, cos_norm); });
 }
 
+int32_t bmx_pca_begin_batch(bmx_pca_t* p, int64_t n, double weight, int32_t cos_norm) {
+    return guarded([&] { bmx::pca_begin_batch(p->impl, n, weight, cos_norm); });
+}
+
+int32_t bmx_pca_add_block(bmx_pca_t* p, const double* x_block, int64_t n_block) {
+    return guarded([&] { bmx::pca_add_block(p->impl, x_block, n_block); });
+}
+
 int32_t bmx_pca_fit(bmx_pca_t* p, int32_t d, int32_t iters, double* centers, double* rotation, double* sdev) {
-    return guarded([&] { bmx::pca_fit(p->impl, d, iters, centers, rotation, sdev); });
+    return guarded([&] { bmx::pca_fit(p->impl, d, 0.0, iters, centers, rotation, sdev, nullptr, nullptr); });
+}
+
+int32_t bmx_pca_fit_tol(bmx_pca_t* p, int32_t d, double tol, int32_t max_iters, double* centers, double* rotation,
+                        double* sdev, int32_t* iters_used, double* residual) {
+    return guarded([&] {
+        if (!(tol > 0.0)) throw bmx::Error(BMX_ERR_ARG, "the PCA tolerance must be positive");
+        int used = 0;
+        double res = 0.0;
+        try {
+            bmx::pca_fit(p->impl, d, tol, max_iters, centers, rotation, sdev, &used, &res);
+        } catch (...) {
+            if (iters_used) *iters_used = used;
+            if (residual) *residual = res;
+            throw;
+        }
+        if (iters_used) *iters_used = used;
+        if (residual) *residual = res;
+    });
 }
 
 int32_t bmx_pca_project(bmx_pca_t* p, int32_t batch, double* out) {
@@ -533,9 +582,9 @@ int32_t bmx_engine_upload(bmx_engine_t* e, int32_t nbatches, int32_t d, const do
 
 int32_t bmx_engine_run(bmx_engine_t* e, const bmx_params_t* params, const int32_t* tree, int32_t tree_len) {
     return guarded([&] {
-        if (!params) throw bmx::Error(BMX_ERR_ARG, "null params");
+        const bmx_params_t p = read_params(params);
         e->impl->knn_ws_.force_exact = g_force_exact;
-        e->impl->run(*params, tree, tree_len);
+        e->impl->run(p, tree, tree_len);
     });
 }
 
@@ -546,6 +595,17 @@ int32_t bmx_engine_download(bmx_engine_t* e, double* corrected, int32_t* batch, 
 
 int32_t bmx_engine_pairs(bmx_engine_t* e, int32_t merge, int32_t** left, int32_t** right, int64_t* npairs) {
     return guarded([&] { e->impl->pairs(merge, left, right, npairs); });
+}
+
+int32_t bmx_engine_pairs_into(bmx_engine_t* e, int32_t merge, int32_t* left, int32_t* right, int64_t capacity,
+                              int64_t* npairs) {
+    return guarded([&] {
+        const int64_t P = e->impl->pairs_count(merge);
+        if (npairs) *npairs = P;
+        if (!left || !right) return;  // size query
+        if (capacity < P) throw bmx::Error(BMX_ERR_ARG, "bmx_engine_pairs_into: the arrays are too short");
+        e->impl->pairs_into(merge, left, right);
+    });
 }
 
 int32_t bmx_engine_merge_stats(bmx_engine_t* e, int32_t merge, int64_t* out6) {
@@ -589,14 +649,14 @@ int32_t bmx_fast_mnn(int32_t nbatches, int32_t d, const double* const* data, con
                      int32_t* merge_right, double* batch_size, int32_t* skipped, double* lost_var,
                      bmx_engine_t** out_engine) {
     return guarded([&] {
-        if (!params) throw bmx::Error(BMX_ERR_ARG, "null params");
+        const bmx_params_t p = read_params(params);
         int dev = 0;
         BMX_HIP(hipGetDevice(&dev));
         auto h = std::make_unique<bmx_engine>();
         h->impl = std::make_unique<bmx::Engine>(dev);
         h->impl->knn_ws_.force_exact = g_force_exact;
         h->impl->upload(nbatches, d, data, nrows, restrict_idx, n_restrict);
-        h->impl->run(*params, tree, tree_len);
+        h->impl->run(p, tree, tree_len);
         h->impl->download(corrected, batch, merge_left, merge_right, batch_size, skipped, lost_var);
         if (out_engine) *out_engine = h.release();
     });

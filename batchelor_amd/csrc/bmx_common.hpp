@@ -41,29 +41,71 @@ struct DevBlockCache {
     struct Block {
         void* p;
         size_t bytes;
+        int device;
     };
     std::vector<Block> blocks;
     DevBlockCache() = default;
     DevBlockCache(const DevBlockCache&) = delete;
     DevBlockCache& operator=(const DevBlockCache&) = delete;
+    // Blocks of an engine that goes away are parked in a process-wide pool (bounded) for the next engine on the same
+    // device: a host that calls fastMNN() again and again (one engine per call at the .Call boundary) then pays the
+    // dozens of hipMallocs of the workspaces once.  The owner has drained its stream before its cache is destroyed, so a
+    // parked block is idle.
+    struct GlobalPool {
+        std::mutex mu;
+        std::vector<Block> blocks;
+        size_t total = 0;
+    };
+    static GlobalPool& global() {
+        static GlobalPool* g = new GlobalPool();  // never destroyed: no hipFree after the runtime is torn down
+        return *g;
+    }
     ~DevBlockCache() {
-        for (const Block& b : blocks) (void)hipFree(b.p);
+        GlobalPool& g = global();
+        {
+            std::lock_guard<std::mutex> lk(g.mu);
+            for (const Block& b : blocks) {
+                if (g.blocks.size() < 96 && g.total + b.bytes <= ((size_t)16 << 30)) {
+                    g.blocks.push_back(b);
+                    g.total += b.bytes;
+                } else {
+                    (void)hipFree(b.p);
+                }
+            }
+        }
+        blocks.clear();
         if (current() == this) current() = nullptr;
     }
     static DevBlockCache*& current() {
         static thread_local DevBlockCache* c = nullptr;
         return c;
     }
-    void* take(size_t bytes, size_t* got) {
+    static int best_fit(const std::vector<Block>& v, size_t bytes, int device) {
         int best = -1;
-        for (int i = 0; i < (int)blocks.size(); ++i)
-            if (blocks[i].bytes >= bytes && blocks[i].bytes <= 2 * bytes + (1u << 20) &&
-                (best < 0 || blocks[i].bytes < blocks[best].bytes))
+        for (int i = 0; i < (int)v.size(); ++i)
+            if (v[i].device == device && v[i].bytes >= bytes && v[i].bytes <= 2 * bytes + (1u << 20) &&
+                (best < 0 || v[i].bytes < v[best].bytes))
                 best = i;
+        return best;
+    }
+    void* take(size_t bytes, size_t* got) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        int best = best_fit(blocks, bytes, dev);
+        if (best >= 0) {
+            void* p = blocks[best].p;
+            *got = blocks[best].bytes;
+            blocks.erase(blocks.begin() + best);
+            return p;
+        }
+        GlobalPool& g = global();
+        std::lock_guard<std::mutex> lk(g.mu);
+        best = best_fit(g.blocks, bytes, dev);
         if (best < 0) return nullptr;
-        void* p = blocks[best].p;
-        *got = blocks[best].bytes;
-        blocks.erase(blocks.begin() + best);
+        void* p = g.blocks[best].p;
+        *got = g.blocks[best].bytes;
+        g.total -= g.blocks[best].bytes;
+        g.blocks.erase(g.blocks.begin() + best);
         return p;
     }
     void give(void* p, size_t bytes) {
@@ -73,7 +115,17 @@ struct DevBlockCache {
             (void)hipFree(p);
             return;
         }
-        blocks.push_back({p, bytes});
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        blocks.push_back({p, bytes, dev});
+    }
+    // an allocation failed: hand everything parked anywhere back to the driver before the retry
+    static void release_global() {
+        GlobalPool& g = global();
+        std::lock_guard<std::mutex> lk(g.mu);
+        for (const Block& b : g.blocks) (void)hipFree(b.p);
+        g.blocks.clear();
+        g.total = 0;
     }
 };
 struct CacheScope {
@@ -132,7 +184,16 @@ struct DevBuf {
                 p = static_cast<T*>(q);
                 cap = got / sizeof(T);
             } else {
-                BMX_HIP(hipMalloc((void**)&p, want * sizeof(T)));
+                hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+                if (e == hipErrorOutOfMemory) {  // parked blocks of earlier engines count as free memory
+                    (void)hipGetLastError();
+                    DevBlockCache::release_global();
+                    e = hipMalloc((void**)&p, want * sizeof(T));
+                }
+                if (e != hipSuccess) {
+                    p = nullptr;
+                    throw bmx::Error(BMX_ERR_HIP, std::string("hipMalloc failed: ") + hipGetErrorString(e));
+                }
                 cap = want;
             }
         }

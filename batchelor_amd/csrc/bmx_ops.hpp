@@ -102,7 +102,12 @@ class Pca;
 Pca* pca_create(int device, int G);
 void pca_destroy(Pca* p);
 void pca_add_batch(Pca* p, const double* x_host, int64_t n, double weight, int cos_norm);
-void pca_fit(Pca* p, int d, int iters, double* centers, double* rotation, double* sdev);
+void pca_begin_batch(Pca* p, int64_t n, double weight, int cos_norm);
+void pca_add_block(Pca* p, const double* x_block_host, int64_t m);
+// tol > 0: until the relative Ritz residual of the d wanted pairs is <= tol, at most max_applies applications of the
+// operator (throws if not reached); tol <= 0: exactly max_applies plain subspace steps
+void pca_fit(Pca* p, int d, double tol, int max_applies, double* centers, double* rotation, double* sdev, int* applies_used,
+             double* resid);
 void pca_project(Pca* p, int batch, double* out_host);
 
 // ---- legacy natives (legacy.hip) -------------------------------------------------------------------

@@ -1,5 +1,6 @@
 // Merge engine (host orchestration of the HIP kernels): R/fastMNN.R:398-562, R/MNN_tree.R:61-77,113-226.
 #include "engine.hpp"
+#include "host_xfer.hpp"
 #include "rccl_dyn.hpp"
 
 #include <algorithm>
@@ -148,7 +149,8 @@ void Engine::upload(int nbatches, int d, const double* const* data, const int32_
         if (nrows[b] < 1) throw Error(BMX_ERR_ARG, "every batch needs at least one cell");
         N_ += nrows[b];
         double* p = inputs_cm_[b].reserve((size_t)nrows[b] * d);
-        BMX_HIP(hipMemcpyAsync(p, data[b], (size_t)nrows[b] * d * sizeof(double), hipMemcpyHostToDevice, stream_));
+        // the caller's matrices are pageable (R-owned): through the pinned staging ring at link speed (host_xfer.hpp)
+        upload_pageable(p, data[b], (size_t)nrows[b] * d * sizeof(double), stream_);
         const bool has = restrict_idx && restrict_idx[b] && n_restrict && n_restrict[b] >= 0;
         if (has) {
             const int m = n_restrict[b];
@@ -703,8 +705,7 @@ void Engine::download(double* corrected, int32_t* batch, int32_t* merge_left, in
             transpose_rm_to_cm(stream_, root_->data.p + (size_t)r0 * d_, s.n, d_, oc, (int)N_, (int)start[s.batch - 1]);
             r0 += s.n;
         }
-        BMX_HIP(hipMemcpyAsync(corrected, oc, (size_t)N_ * d_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
-        BMX_HIP(hipStreamSynchronize(stream_));
+        download_pageable(corrected, oc, (size_t)N_ * d_ * sizeof(double), stream_);
     }
     if (batch) {
         int64_t o = 0;
@@ -732,43 +733,66 @@ void Engine::download(double* corrected, int32_t* batch, int32_t* merge_left, in
     }
 }
 
-void Engine::pairs(int merge, int32_t** left, int32_t** right, int64_t* npairs) {
-    CacheScope cache_scope(&cache_);
-    BMX_HIP(hipSetDevice(device_));
+namespace {
+// node position (1-based) -> output row (1-based), R/fastMNN.R:533-547: a node is a run of whole batches; tab[i] = first
+// position of its i-th batch inside the node (tab[ns] = its size), tab[ns + 1 + i] = that batch's first row in the input
+// batch order
+__global__ void remap_pairs_tab(const int32_t* __restrict__ in, int64_t n, const int32_t* __restrict__ tab, int ns,
+                                int32_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int pos = in[i] - 1;
+    int sgi = 0;
+    for (int t = 1; t < ns; ++t) sgi += pos >= tab[t] ? 1 : 0;
+    out[i] = tab[ns + 1 + sgi] + (pos - tab[sgi]) + 1;
+}
+}  // namespace
+
+int64_t Engine::pairs_count(int merge) const {
     if (!root_) throw Error(BMX_ERR_ARG, "no finished run to download");
     if (merge < 0 || merge >= (int)merges_.size()) throw Error(BMX_ERR_ARG, "merge index out of range");
+    return merges_[merge].npairs;
+}
+
+void Engine::pairs_into(int merge, int32_t* left, int32_t* right) {
+    CacheScope cache_scope(&cache_);
+    BMX_HIP(hipSetDevice(device_));
+    const int64_t P = pairs_count(merge);
+    if (P == 0) return;
     const MergeRecord& rec = merges_[merge];
-    const int64_t P = rec.npairs;
-    std::vector<int32_t> f((size_t)P), s((size_t)P);
-    if (P) {
-        BMX_HIP(hipMemcpyAsync(f.data(), rec.first.p, (size_t)P * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
-        BMX_HIP(hipMemcpyAsync(s.data(), rec.second.p, (size_t)P * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
-        BMX_HIP(hipStreamSynchronize(stream_));
-    }
-    // R/fastMNN.R:533-547: shift to the node's place in the final merged order, then to the input batch order.
-    // Every node is a contiguous run of whole batches in the root's row order, starting with its first batch.
-    std::vector<int64_t> root_start(B_ + 1, 0), in_start(B_ + 1, 0);
-    {
+    // shift to the node's place in the final merged order, then to the input batch order: a short table per side,
+    // applied on the device
+    std::vector<int64_t> in_start(B_ + 1, 0);
+    for (int b = 0; b < B_; ++b) in_start[b + 1] = in_start[b] + nrows_[b];
+    const int nl = (int)rec.left_set.size(), nr = (int)rec.right_set.size();
+    std::vector<int32_t> tab((size_t)2 * (nl + nr) + 2);
+    auto fill = [&](const std::vector<int>& set, int32_t* t) {
+        const int ns = (int)set.size();
         int64_t o = 0;
-        for (const Segment& sg : root_->origin) {
-            root_start[sg.batch] = o;
-            o += sg.n;
+        for (int i = 0; i < ns; ++i) {
+            t[i] = (int32_t)o;
+            t[ns + 1 + i] = (int32_t)in_start[set[i] - 1];
+            o += nrows_[set[i] - 1];
         }
-        for (int b = 0; b < B_; ++b) in_start[b + 1] = in_start[b] + nrows_[b];
-    }
-    auto remap = [&](std::vector<int32_t>& v, const std::vector<int>& set) {
-        // position inside the node -> (batch, row in batch) -> input-order row
-        std::vector<int64_t> seg_start(set.size() + 1, 0);
-        for (size_t i = 0; i < set.size(); ++i) seg_start[i + 1] = seg_start[i] + nrows_[set[i] - 1];
-        for (auto& x : v) {
-            const int64_t pos = x - 1;
-            size_t sgi = std::upper_bound(seg_start.begin(), seg_start.end(), pos) - seg_start.begin() - 1;
-            const int b = set[sgi];
-            x = (int32_t)(in_start[b - 1] + (pos - seg_start[sgi]) + 1);
-        }
+        t[ns] = (int32_t)o;
     };
-    remap(f, rec.left_set);
-    remap(s, rec.right_set);
+    fill(rec.left_set, tab.data());
+    fill(rec.right_set, tab.data() + 2 * nl + 1);
+    DevBuf<int32_t> tmp, dtab;
+    int32_t* t = tmp.reserve((size_t)2 * P);
+    int32_t* dt = dtab.reserve(tab.size());
+    BMX_HIP(hipMemcpyAsync(dt, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+    hipLaunchKernelGGL(remap_pairs_tab, dim3((unsigned)cdiv(P, 256)), dim3(256), 0, stream_, (const int32_t*)rec.first.p, P,
+                       (const int32_t*)dt, nl, t);
+    hipLaunchKernelGGL(remap_pairs_tab, dim3((unsigned)cdiv(P, 256)), dim3(256), 0, stream_, (const int32_t*)rec.second.p, P,
+                       (const int32_t*)(dt + 2 * nl + 1), nr, t + P);
+    BMX_LAUNCH_CHECK();
+    download_pageable(left, t, (size_t)P * sizeof(int32_t), stream_);   // (returns after the copy: tab may go)
+    download_pageable(right, t + P, (size_t)P * sizeof(int32_t), stream_);
+}
+
+void Engine::pairs(int merge, int32_t** left, int32_t** right, int64_t* npairs) {
+    const int64_t P = pairs_count(merge);
     int32_t* L = (int32_t*)std::malloc(std::max<size_t>(1, (size_t)P) * sizeof(int32_t));
     int32_t* R = (int32_t*)std::malloc(std::max<size_t>(1, (size_t)P) * sizeof(int32_t));
     if (!L || !R) {
@@ -776,14 +800,16 @@ void Engine::pairs(int merge, int32_t** left, int32_t** right, int64_t* npairs) 
         std::free(R);
         throw std::bad_alloc();
     }
-    if (P) {
-        std::memcpy(L, f.data(), (size_t)P * sizeof(int32_t));
-        std::memcpy(R, s.data(), (size_t)P * sizeof(int32_t));
+    try {
+        pairs_into(merge, L, R);
+    } catch (...) {
+        std::free(L);
+        std::free(R);
+        throw;
     }
     *left = L;
     *right = R;
     *npairs = P;
-    (void)root_start;
 }
 
 void Engine::snapshot(double* left_rm, double* right_rm, int64_t* nl, int64_t* nr) {

@@ -62,6 +62,8 @@ class Engine {
     void download(double* corrected, int32_t* batch, int32_t* merge_left, int32_t* merge_right, double* batch_size,
                   int32_t* skipped, double* lost_var);
     void pairs(int merge, int32_t** left, int32_t** right, int64_t* npairs);
+    int64_t pairs_count(int merge) const;
+    void pairs_into(int merge, int32_t* left, int32_t* right);  // caller-allocated, pairs_count(merge) entries each
     void merge_stats(int merge, int64_t* out6) const;
     void set_profiling(bool on) { knn_ws_.profile = on; }
     // diagnostics: keep a copy of the two matrices merge `merge` searches (left and right node after

@@ -1,0 +1,188 @@
+// Host <-> device transfers of the caller's PAGEABLE memory at link speed (the .Call boundary hands over R-owned
+// matrices, src/RcppExports.cpp:10-47: nothing about them can be assumed pinned, and pinning 100s of MB per call with
+// hipHostRegister costs more than the copy).
+//
+// A plain hipMemcpy of pageable memory is staged by the runtime through small pinned buffers by ONE host thread:
+// measured 4-5 GB/s on the GPU box against > 50 GB/s that the PCIe link takes.  Here the staging is explicit: two pinned
+// buffers per direction (allocated once per process and kept), a few host threads moving the bytes between the caller's
+// memory and the pinned buffer (which also spreads the first-touch page faults of a freshly allocated result matrix),
+// and the DMA of one buffer in flight while the other is being filled / emptied.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "bmx_common.hpp"
+
+namespace bmx {
+
+// A small persistent pool (the helpers only ever run memcpy: they never touch the caller's runtime, R or Python)
+class HostPool {
+  public:
+    static HostPool& get() {
+        static HostPool* pool = new HostPool();  // never destroyed: worker threads must not be joined at exit of a host
+        return *pool;                            // process that may already have unloaded us
+    }
+    int workers() const { return (int)threads_.size() + 1; }
+    // fn(i) for i in [0, n); the calling thread takes part; returns when all are done
+    void parallel_for(size_t n, const std::function<void(size_t)>& fn) {
+        if (n == 0) return;
+        if (n == 1 || threads_.empty()) {
+            for (size_t i = 0; i < n; ++i) fn(i);
+            return;
+        }
+        std::unique_lock<std::mutex> run_lock(run_mu_);  // one job at a time
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            fn_ = &fn;
+            n_ = n;
+            next_ = 0;
+            pending_ = n;
+            ++generation_;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(mu_);
+        done_cv_.wait(lk, [&] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+
+  private:
+    HostPool() {
+        unsigned hw = std::thread::hardware_concurrency();
+        int n = hw >= 32 ? 12 : (hw >= 8 ? 6 : (hw >= 4 ? 3 : 0));
+        if (const char* v = std::getenv("BMX_HOST_THREADS")) n = std::max(0, std::atoi(v) - 1);
+        for (int i = 0; i < n; ++i) threads_.emplace_back([this] { loop(); });
+        for (auto& t : threads_) t.detach();
+    }
+    void loop() {
+        unsigned long long seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return generation_ != seen; });
+                seen = generation_;
+            }
+            work();
+        }
+    }
+    void work() {
+        for (;;) {
+            size_t i;
+            const std::function<void(size_t)>* fn;
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (!fn_ || next_ >= n_) return;
+                i = next_++;
+                fn = fn_;
+            }
+            (*fn)(i);
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (--pending_ == 0) done_cv_.notify_all();
+            }
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex mu_, run_mu_;
+    std::condition_variable cv_, done_cv_;
+    const std::function<void(size_t)>* fn_ = nullptr;
+    size_t n_ = 0, next_ = 0, pending_ = 0;
+    unsigned long long generation_ = 0;
+};
+
+inline void host_parallel_memcpy(void* dst, const void* src, size_t bytes) {
+    constexpr size_t kPiece = (size_t)2 << 20;
+    if (bytes <= 2 * kPiece) {
+        std::memcpy(dst, src, bytes);
+        return;
+    }
+    const size_t n = (bytes + kPiece - 1) / kPiece;
+    char* d = static_cast<char*>(dst);
+    const char* s = static_cast<const char*>(src);
+    HostPool::get().parallel_for(n, [&](size_t i) {
+        const size_t o = i * kPiece;
+        std::memcpy(d + o, s + o, std::min(kPiece, bytes - o));
+    });
+}
+
+// Process-wide pinned staging buffers (two per direction), handed out under a lock: transfers of different engines on
+// different threads take turns.
+class PinnedRing {
+  public:
+    static constexpr size_t kChunk = (size_t)32 << 20;
+    static PinnedRing& upload_ring() {
+        static PinnedRing* r = new PinnedRing();
+        return *r;
+    }
+    static PinnedRing& download_ring() {
+        static PinnedRing* r = new PinnedRing();
+        return *r;
+    }
+    std::mutex mu;
+    void* buf[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool busy[2] = {false, false};
+    int cur = 0;
+    void ensure() {
+        if (buf[0]) return;
+        for (int i = 0; i < 2; ++i) {
+            BMX_HIP(hipHostMalloc(&buf[i], kChunk, hipHostMallocDefault));
+            BMX_HIP(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+        }
+    }
+};
+
+// host (pageable) -> device on `stream`.  The caller's memory has been read completely when this returns; the last DMA
+// may still be in flight on the stream (later work on the stream is ordered behind it).
+inline void upload_pageable(void* dev, const void* host, size_t bytes, hipStream_t stream) {
+    if (bytes == 0) return;
+    PinnedRing& r = PinnedRing::upload_ring();
+    std::lock_guard<std::mutex> lk(r.mu);
+    r.ensure();
+    const char* src = static_cast<const char*>(host);
+    char* dst = static_cast<char*>(dev);
+    for (size_t o = 0; o < bytes; o += PinnedRing::kChunk) {
+        const size_t m = std::min(PinnedRing::kChunk, bytes - o);
+        const int c = r.cur;
+        if (r.busy[c]) BMX_HIP(hipEventSynchronize(r.ev[c]));
+        host_parallel_memcpy(r.buf[c], src + o, m);
+        BMX_HIP(hipMemcpyAsync(dst + o, r.buf[c], m, hipMemcpyHostToDevice, stream));
+        BMX_HIP(hipEventRecord(r.ev[c], stream));
+        r.busy[c] = true;
+        r.cur ^= 1;
+    }
+}
+
+// device -> host (pageable) on `stream`; returns when the caller's memory holds the bytes.  The device-side work the
+// copy depends on must already be queued on `stream`.
+inline void download_pageable(void* host, const void* dev, size_t bytes, hipStream_t stream) {
+    if (bytes == 0) return;
+    PinnedRing& r = PinnedRing::download_ring();
+    std::lock_guard<std::mutex> lk(r.mu);
+    r.ensure();
+    char* dst = static_cast<char*>(host);
+    const char* src = static_cast<const char*>(dev);
+    const size_t nchunks = (bytes + PinnedRing::kChunk - 1) / PinnedRing::kChunk;
+    auto issue = [&](size_t i) {
+        const size_t o = i * PinnedRing::kChunk, m = std::min(PinnedRing::kChunk, bytes - o);
+        BMX_HIP(hipMemcpyAsync(r.buf[i & 1], src + o, m, hipMemcpyDeviceToHost, stream));
+        BMX_HIP(hipEventRecord(r.ev[i & 1], stream));
+    };
+    issue(0);
+    for (size_t i = 0; i < nchunks; ++i) {
+        BMX_HIP(hipEventSynchronize(r.ev[i & 1]));
+        if (i + 1 < nchunks) issue(i + 1);  // the other buffer fills while this one is copied out
+        const size_t o = i * PinnedRing::kChunk, m = std::min(PinnedRing::kChunk, bytes - o);
+        host_parallel_memcpy(dst + o, r.buf[i & 1], m);
+    }
+    r.busy[0] = r.busy[1] = false;
+}
+
+}  // namespace bmx

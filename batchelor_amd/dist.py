@@ -102,11 +102,18 @@ def init_engine_rccl(engine, group=None):
     if err is not None:
         raise err
     buf = ctypes.create_string_buffer(128)
+    box = [None]
     if rank == 0:
-        _lib.check(lib.bmx_rccl_unique_id(buf, 128))
-    box = [buf.raw]
+        # a failure here must reach every rank: the others are about to wait in the broadcast
+        try:
+            _lib.check(lib.bmx_rccl_unique_id(buf, 128))
+            box = [buf.raw]
+        except Exception as exc:  # noqa: BLE001
+            box = [("error", str(exc))]
     if world > 1:
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    if not isinstance(box[0], (bytes, bytearray)):
+        raise RuntimeError("ncclGetUniqueId failed on rank 0: " + (box[0][1] if box[0] else "no id"))
     uid = ctypes.create_string_buffer(box[0], 128)
     try:
         _lib.check(lib.bmx_engine_init_rccl(engine._h, int(rank), int(world), uid, 128))

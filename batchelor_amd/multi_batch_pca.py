@@ -64,8 +64,9 @@ def _weight_vector(ncells, weights):
 
 
 class DevicePCA:
-    """bmx_pca_t: the batches (genes x cells) stay in HBM; fit() = multiBatchPCA (R/multiBatchPCA.R:211-322) by blocked
-    subspace iteration on the FP64 matrix cores; project(b) = crossprod(cosineNorm(x_b) - centers, rotation)."""
+    """bmx_pca_t: the batches (genes x cells) stay in HBM; fit() = multiBatchPCA (R/multiBatchPCA.R:211-322) by
+    Chebyshev-filtered subspace iteration on the FP64 matrix cores, run until the Ritz residual is below `tol`;
+    project(b) = crossprod(cosineNorm(x_b) - centers, rotation)."""
 
     def __init__(self, n_genes, device=0):
         _lib.require_gpu()
@@ -77,6 +78,8 @@ class DevicePCA:
         self.G = int(n_genes)
         self.ncells = []
         self.d = 0
+        self.iters_used = 0
+        self.residual = float("nan")
 
     def add_batch(self, x, weight=1.0, cos_norm=False):
         x = _lib.as_f(x)
@@ -86,14 +89,39 @@ class DevicePCA:
                                                 ctypes.c_double(float(weight)), 1 if cos_norm else 0))
         self.ncells.append(int(x.shape[1]))
 
-    def fit(self, d=50, iters=15):
+    def begin_batch(self, n, weight=1.0, cos_norm=False):
+        """Announce a batch of n cells whose columns follow in blocks (add_block), so that it never has to exist on the
+        host in one piece."""
+        _lib.check(_lib.lib().bmx_pca_begin_batch(self._h, ctypes.c_int64(int(n)), ctypes.c_double(float(weight)),
+                                                  1 if cos_norm else 0))
+        self.ncells.append(int(n))
+
+    def add_block(self, x_block):
+        x_block = _lib.as_f(x_block)
+        if x_block.ndim != 2 or x_block.shape[0] != self.G:
+            raise ValueError("number of rows is not the same across batches")
+        _lib.check(_lib.lib().bmx_pca_add_block(self._h, _lib.f64p(x_block), ctypes.c_int64(x_block.shape[1])))
+
+    def fit(self, d=50, tol=1e-9, max_iters=500, iters=None):
+        """tol: relative Ritz residual at which the iteration stops (raises if max_iters applications of the operator do
+        not reach it).  iters=N: the fixed-count form of round 2 (N plain subspace iterations, no test)."""
         centers = np.zeros(self.G)
         rotation = np.zeros((self.G, d), order="F")
         sdev = np.zeros(d)
-        _lib.check(_lib.lib().bmx_pca_fit(self._h, int(d), int(iters), _lib.f64p(centers), _lib.f64p(rotation),
-                                          _lib.f64p(sdev)))
+        if iters is not None:
+            _lib.check(_lib.lib().bmx_pca_fit(self._h, int(d), int(iters), _lib.f64p(centers), _lib.f64p(rotation),
+                                              _lib.f64p(sdev)))
+            self.iters_used, self.residual = int(iters), float("nan")
+        else:
+            used, res = ctypes.c_int32(0), ctypes.c_double(0.0)
+            rc = _lib.lib().bmx_pca_fit_tol(self._h, int(d), ctypes.c_double(float(tol)), int(max_iters),
+                                            _lib.f64p(centers), _lib.f64p(rotation), _lib.f64p(sdev), ctypes.byref(used),
+                                            ctypes.byref(res))
+            self.iters_used, self.residual = used.value, res.value
+            _lib.check(rc)
         self.d = int(d)
-        return {"rotation": np.ascontiguousarray(rotation), "centers": centers, "d": sdev}
+        return {"rotation": np.ascontiguousarray(rotation), "centers": centers, "d": sdev,
+                "iters_used": self.iters_used, "residual": self.residual}
 
     def project(self, b):
         out = np.zeros((self.ncells[b], self.d), order="F")
@@ -112,10 +140,18 @@ class DevicePCA:
             pass
 
 
-def multiBatchPCA(*batches, d=50, weights=None, cos_norm=False, iters=15, device=0, return_pcs=True):
-    """multiBatchPCA(..., d=, weights=) on the device (R/multiBatchPCA.R:140-258).  Batches are genes x cells; with
+def multiBatchPCA(*batches, d=50, weights=None, cos_norm=False, tol=1e-9, max_iters=500, iters=None, device=0,
+                  return_pcs=True, l2=None, block=65536):
+    """multiBatchPCA(..., d=, weights=) (R/multiBatchPCA.R:140-258) on the device.  Batches are genes x cells; with
     cos_norm the cosine normalisation of fastMNN (R/fastMNN.R:348-351) is applied on the fly.
-    Returns {"rotation", "centers", "d", "weights"} plus "pcs": the list of cells x d projections."""
+    Returns {"rotation", "centers", "d", "weights", "iters_used", "residual", "path"} plus "pcs": the list of cells x d
+    projections.
+
+    The device path iterates until the relative Ritz residual is <= tol (the reference's irlba stops at 1e-5 on the
+    singular triplets, R/multiBatchPCA.R:386-393) and raises when max_iters passes do not get there.  Inputs the blocked
+    iteration cannot take -- fewer genes or cells than its block of 64 / 128 vectors, d > 120, data of rank below the
+    block -- go to multiBatchPCA_host (north_star keeps multiBatchPCA on the host path anyway), as does a call in
+    round 1's form with per-cell norms `l2=` (and its `block=`)."""
     if len(batches) == 1 and isinstance(batches[0], (list, tuple)):
         batches = tuple(batches[0])
     if len(batches) == 0:
@@ -123,13 +159,38 @@ def multiBatchPCA(*batches, d=50, weights=None, cos_norm=False, iters=15, device
     G = np.asarray(batches[0]).shape[0]
     if any(np.asarray(m).ndim != 2 or np.asarray(m).shape[0] != G for m in batches):
         raise ValueError("number of rows is not the same across batches")
-    w = _weight_vector([np.asarray(m).shape[1] for m in batches], weights)
+    ncells = [np.asarray(m).shape[1] for m in batches]
+    w = _weight_vector(ncells, weights)
+    width = 64 if d <= 56 else 128
+
+    def host(reason):
+        if l2 is not None:
+            norms = l2
+        else:
+            norms = [cosineNorm(m, mode="l2norm") for m in batches] if cos_norm else None
+        out = multiBatchPCA_host(*batches, d=d, weights=weights, l2=norms, block=block)
+        out.update(iters_used=0, residual=0.0, path="host: " + reason)
+        if return_pcs:
+            out["pcs"] = [project(m, out["rotation"], out["centers"], cos_norm=norms is not None) for m in batches]
+        return out
+
+    if l2 is not None:
+        return host("per-cell norms given (round-1 signature)")
+    if d > 120 or G < width or sum(ncells) <= width:
+        return host("fewer genes / cells than the device block, or d > 120")
     pca = DevicePCA(G, device)
     try:
         for m, wi in zip(batches, w):
             pca.add_batch(m, weight=wi, cos_norm=cos_norm)
-        out = pca.fit(d=d, iters=iters)
+        try:
+            out = pca.fit(d=d, tol=tol, max_iters=max_iters, iters=iters)
+        except _lib.BatchelorMI355XError as exc:
+            if "rank below the subspace width" in str(exc):
+                pca.close()
+                return host("data of rank below the device block")
+            raise
         out["weights"] = w
+        out["path"] = "device"
         if return_pcs:
             out["pcs"] = [pca.project(b) for b in range(len(batches))]
     finally:
@@ -166,6 +227,8 @@ def multiBatchPCA_host(*batches, d=50, weights=None, l2=None, block=65536):
             s += cols(i, lo, min(m.shape[1], lo + block)).sum(axis=1)
         grand += (s / m.shape[1]) * w[i]
     grand /= w.sum()
+    if G > 4096:
+        return _host_pca_lanczos(mats, inv, grand, w, d, block)
     # pass 2: Gram matrix of the scaled, centred data: sum_b (w_b / n_b) C_b C_b^T   (scaled = C_b / sqrt(n_b / w_b))
     gram = np.zeros((G, G))
     for i, m in enumerate(mats):
@@ -174,6 +237,42 @@ def multiBatchPCA_host(*batches, d=50, weights=None, l2=None, block=65536):
             gram += (w[i] / m.shape[1]) * (c @ c.T)
     evals, evecs = np.linalg.eigh(gram)
     order = np.argsort(evals)[::-1][:d]
+    return {"rotation": np.ascontiguousarray(evecs[:, order]), "centers": grand,
+            "d": np.sqrt(np.maximum(evals[order], 0.0)), "weights": w}
+
+
+def _host_pca_lanczos(mats, inv, grand, w, d, block):
+    """Many genes: the genes x genes Gram matrix is not formed (20 000 genes: 3.2 GB and a dense eigensolver of 1e13
+    flops); its top d eigenpairs come from implicitly restarted Lanczos on the operator v -> sum_b (w_b/n_b) C_b (C_b^T v),
+    run to machine precision -- the host analogue of the reference's default BSPARAM=IrlbaParam() (R/fastMNN.R:287).
+    C_b = X_b diag(inv_b) - grand 1^T is never formed: the per-cell factors and the centring are applied to the vectors."""
+    from scipy.sparse.linalg import LinearOperator, eigsh
+    G = mats[0].shape[0]
+
+    def matvec(v):
+        v = np.asarray(v, dtype=np.float64).reshape(G)
+        out = np.zeros(G)
+        gv = float(grand @ v)
+        for i, m in enumerate(mats):
+            acc = np.zeros(G)
+            zsum = 0.0
+            for lo in range(0, m.shape[1], block):
+                hi = min(m.shape[1], lo + block)
+                blk = m[:, lo:hi]
+                z = blk.T @ v                 # C_b^T v for these cells ...
+                if inv[i] is not None:
+                    z *= inv[i][lo:hi]
+                z -= gv
+                zsum += float(z.sum())
+                acc += blk @ (z if inv[i] is None else z * inv[i][lo:hi])
+            out += (w[i] / m.shape[1]) * (acc - grand * zsum)
+        return out
+
+    op = LinearOperator((G, G), matvec=matvec, dtype=np.float64)
+    k = min(d, G - 1)
+    evals, evecs = eigsh(op, k=k, which="LA", tol=0, ncv=min(G, max(3 * k, k + 32)),
+                         v0=np.random.default_rng(0).standard_normal(G))
+    order = np.argsort(evals)[::-1]
     return {"rotation": np.ascontiguousarray(evecs[:, order]), "centers": grand,
             "d": np.sqrt(np.maximum(evals[order], 0.0)), "weights": w}
 

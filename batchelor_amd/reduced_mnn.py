@@ -19,7 +19,7 @@ from .merge_tree import encode_postorder, resolve_merge_order
 
 
 class BmxParams(ctypes.Structure):
-    _fields_ = [("k", ctypes.c_int32), ("prop_k", ctypes.c_double), ("ndist", ctypes.c_double),
+    _fields_ = [("struct_size", ctypes.c_int32), ("k", ctypes.c_int32), ("prop_k", ctypes.c_double), ("ndist", ctypes.c_double),
                 ("min_batch_skip", ctypes.c_double), ("auto_merge", ctypes.c_int32), ("var_adj", ctypes.c_int32),
                 ("sigma", ctypes.c_double)]
 
@@ -117,7 +117,7 @@ class MnnEngine:
 
     def run(self, k=20, prop_k=None, ndist=3.0, min_batch_skip=0.0, merge_tree=None, auto_merge=False, var_adj=False,
             sigma=0.1):
-        p = BmxParams(int(k), float("nan") if prop_k is None else float(prop_k), float(ndist),
+        p = BmxParams(ctypes.sizeof(BmxParams), int(k), float("nan") if prop_k is None else float(prop_k), float(ndist),
                       float("nan") if min_batch_skip is None else float(min_batch_skip), 1 if auto_merge else 0,
                       1 if var_adj else 0, float(sigma))
         code = encode_postorder(merge_tree if merge_tree is not None
@@ -190,9 +190,12 @@ class MnnEngine:
         pairs = []
         if with_pairs:
             for m in range(nm):
-                pl, pr, n = _lib.c_i32p(), _lib.c_i32p(), ctypes.c_int64(0)
-                _lib.check(_lib.lib().bmx_engine_pairs(self._h, m, ctypes.byref(pl), ctypes.byref(pr), ctypes.byref(n)))
-                pairs.append((_lib.take_i32(pl, n.value).astype(np.int64), _lib.take_i32(pr, n.value).astype(np.int64)))
+                n = ctypes.c_int64(0)
+                _lib.check(_lib.lib().bmx_engine_pairs_into(self._h, m, None, None, ctypes.c_int64(0), ctypes.byref(n)))
+                pl, pr = np.empty(n.value, dtype=np.int32), np.empty(n.value, dtype=np.int32)  # R's integer vectors
+                _lib.check(_lib.lib().bmx_engine_pairs_into(self._h, m, _lib.i32p(pl), _lib.i32p(pr),
+                                                            ctypes.c_int64(n.value), ctypes.byref(n)))
+                pairs.append((pl, pr))
         info = MergeInfo(left=[[int(x) for x in row if x] for row in ml], right=[[int(x) for x in row if x] for row in mr],
                          pairs=pairs, batch_size=bs, skipped=sk.astype(bool), lost_var=np.ascontiguousarray(lv))
         return MnnResult(corrected=np.ascontiguousarray(corrected) if c_order else corrected, batch=batch, merge_info=info,

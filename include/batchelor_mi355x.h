@@ -86,6 +86,10 @@ void bmx_set_force_exact_knn(int32_t on);
 typedef struct bmx_engine bmx_engine_t;
 
 typedef struct {
+    int32_t struct_size;   /* sizeof(bmx_params_t) as the CALLER's header has it: the library reads that many bytes and
+                              gives the fields a later header added their defaults (var_adj = 0, sigma = 0.1), so a
+                              caller built against an older header keeps working; smaller than the fields up to
+                              auto_merge, or larger than the library's own struct with non-zero bytes beyond: BMX_ERR_ARG */
     int32_t k;             /* k = 20 */
     double prop_k;         /* NaN = NULL (R/MNN_tree.R:140-146) */
     double ndist;          /* ndist = 3 */
@@ -132,6 +136,10 @@ int32_t bmx_engine_download(bmx_engine_t* e, double* corrected, int32_t* batch, 
                             int32_t* merge_right, double* batch_size, int32_t* skipped, double* lost_var);
 /* MNN pairs of merge `merge` (0-based), 1-based OUTPUT-row indices (R/fastMNN.R:533-547); malloc'ed (bmx_free). */
 int32_t bmx_engine_pairs(bmx_engine_t* e, int32_t merge, int32_t** left, int32_t** right, int64_t* npairs);
+/* The same into arrays the caller owns (an R shim allocates its INTSXPs first and saves a copy): *npairs receives the
+ * number of pairs; with left == right == NULL nothing else happens (size query), else capacity must be >= *npairs. */
+int32_t bmx_engine_pairs_into(bmx_engine_t* e, int32_t merge, int32_t* left, int32_t* right, int64_t capacity,
+                              int64_t* npairs);
 /* Sizes of merge `merge`: out[0..5] = {cells searched on the left, on the right, MNN-involved right cells U,
  * pairs P, all left cells, all right cells} -- the inputs of the algorithmic flop / byte counts. */
 int32_t bmx_engine_merge_stats(bmx_engine_t* e, int32_t merge, int64_t* out6);
@@ -209,9 +217,22 @@ void bmx_pca_destroy(bmx_pca_t* p);
 /* x: n_genes x n column-major (host).  weight: the batch's weight w_b (1 = R's default: every batch counts the same
  * whatever its size, R/multiBatchPCA.R:299-334).  cos_norm != 0: cosineNorm(x) (R/cosineNorm.R:63-82) on the fly. */
 int32_t bmx_pca_add_batch(bmx_pca_t* p, const double* x, int64_t n, double weight, int32_t cos_norm);
-/* d <= 56 components; iters: subspace iterations (15 is plenty for data with a spectral gap).  centers [n_genes],
- * rotation [n_genes x d] column-major (columns defined up to sign, as any SVD's), sdev [d] singular values of the
- * scaled matrix; any may be NULL. */
+/* The same batch handed over in column blocks, so that a 32 GB batch (200 000 cells x 20 000 genes, BASELINE.json
+ * configs[3]) never has to exist in host memory at once: announce the batch, then its cells in order.  x_block is
+ * n_genes x n_block column-major host memory, pageable or pinned; it has been read completely when the call returns
+ * (it goes through a pinned double-buffered staging ring: host copy and DMA overlap). */
+int32_t bmx_pca_begin_batch(bmx_pca_t* p, int64_t n, double weight, int32_t cos_norm);
+int32_t bmx_pca_add_block(bmx_pca_t* p, const double* x_block, int64_t n_block);
+/* multiBatchPCA's SVD (R/multiBatchPCA.R:386-393; the reference's irlba stops at tol = 1e-5) by Chebyshev-filtered
+ * subspace iteration on a block of 64 vectors (d <= 56) or 128 (d <= 120): iterates until the Ritz residuals
+ * max_j |M x_j - theta_j x_j| / theta_1 of the d wanted pairs are <= tol; at most max_iters applications of the operator
+ * (one pass over every batch each), then BMX_ERR_ARG with the residual reached in the message.  iters_used / residual
+ * (nullable) are written in both cases.  centers [n_genes], rotation [n_genes x d] column-major (columns defined up to
+ * sign, as any SVD's), sdev [d] singular values of the scaled matrix; any may be NULL.  Needs n_genes and the total
+ * number of cells above the block width. */
+int32_t bmx_pca_fit_tol(bmx_pca_t* p, int32_t d, double tol, int32_t max_iters, double* centers, double* rotation,
+                        double* sdev, int32_t* iters_used, double* residual);
+/* Fixed-count form: exactly `iters` plain subspace iterations, no convergence test (kept for callers of round 2). */
 int32_t bmx_pca_fit(bmx_pca_t* p, int32_t d, int32_t iters, double* centers, double* rotation, double* sdev);
 /* crossprod(cosineNorm(x_b) - centers, rotation) (R/multiBatchPCA.R:236-239): out [n_b x d] column-major. */
 int32_t bmx_pca_project(bmx_pca_t* p, int32_t batch, double* out);

@@ -74,17 +74,25 @@ def process_listed_matrices_for_pca(mat_list, weights=None):
     return centered, scaled, grand
 
 
-def multi_batch_pca(mat_list, d=50, weights=None, get_variance=False):
+def multi_batch_pca(mat_list, d=50, weights=None, get_variance=False, method="svd"):
     """R/multiBatchPCA.R:211-258 (.multi_pca_list): SVD of the scaled matrix, projection of the UNSCALED centred
-    batches on u.  Returns (list of cells x d matrices, metadata dict)."""
+    batches on u.  Returns (list of cells x d matrices, metadata dict).
+    method="gram": the same left singular vectors from the dense eigendecomposition of scaled^T scaled (cells x cells),
+    u = scaled v / s -- for shapes with far more genes than cells, where LAPACK's SVD of the tall matrix takes minutes."""
     if len(mat_list) == 0:
         raise ValueError("at least one batch must be specified")
     g = np.asarray(mat_list[0]).shape[0]
     if any(np.asarray(m).shape[0] != g for m in mat_list):
         raise ValueError("number of rows is not the same across batches")
     centered, scaled, centers = process_listed_matrices_for_pca(mat_list, weights)
-    u, s, _ = np.linalg.svd(scaled, full_matrices=False)
-    u = u[:, :d]
+    if method == "gram":
+        ev, v = np.linalg.eigh(scaled.T @ scaled)
+        top = np.argsort(ev)[::-1][:d]
+        s = np.sqrt(np.maximum(ev[np.argsort(ev)[::-1]], 0.0))
+        u = (scaled @ v[:, top]) / s[:d][None, :]
+    else:
+        u, s, _ = np.linalg.svd(scaled, full_matrices=False)
+        u = u[:, :d]
     out = [c.T @ u for c in centered]
     meta = {"rotation": u, "centers": centers}
     if get_variance:
@@ -94,8 +102,28 @@ def multi_batch_pca(mat_list, d=50, weights=None, get_variance=False):
     return out, meta
 
 
+def fast_mnn_single(x, batch, k=20, prop_k=None, restrict=None, cos_norm=True, ndist=3, d=50, weights=None,
+                    merge_order=None, auto_merge=False, min_batch_skip=0.0, nthreads=0):
+    """R/fastMNN.R:364-388 (.fast_mnn_single): one genes x cells object, `batch` names each cell's batch.  The PCA takes
+    the levels of factor(batch) as the batches (.multi_pca_single, R/multiBatchPCA.R:241-258); the PCs are divided into
+    batches (R/fastMNN.R:379), corrected, and rows / pairs are put back in the caller's order (:383-385)."""
+    x = np.asarray(x, dtype=np.float64)
+    batch = np.asarray(batch)
+    if cos_norm:
+        x = cosine_norm(x)
+    levels = sorted(set(batch.tolist()))
+    pcs, meta = multi_batch_pca([x[:, batch == lev] for lev in levels], d=d, weights=weights)
+    allpcs = np.empty((x.shape[1], pcs[0].shape[1]))
+    for lev, pc in zip(levels, pcs):
+        allpcs[batch == lev] = pc
+    out = engine.reduced_mnn(allpcs, batch=batch, k=k, prop_k=prop_k, restrict=None if restrict is None else [restrict],
+                             ndist=ndist, merge_order=merge_order, auto_merge=auto_merge, min_batch_skip=min_batch_skip,
+                             nthreads=nthreads)
+    return out, meta
+
+
 def fast_mnn(*batches, k=20, prop_k=None, restrict=None, cos_norm=True, ndist=3, d=50, weights=None,
-             merge_order=None, auto_merge=False, min_batch_skip=0.0, nthreads=0):
+             merge_order=None, auto_merge=False, min_batch_skip=0.0, nthreads=0, pca_method="svd"):
     """R/fastMNN.R:339-358 (.fast_mnn_list): cosine normalisation, multi-batch PCA, merge engine.
     Batches are genes x cells.  Returns (engine result, pca metadata)."""
     if len(batches) < 2:
@@ -103,7 +131,7 @@ def fast_mnn(*batches, k=20, prop_k=None, restrict=None, cos_norm=True, ndist=3,
     mats = [np.asarray(b, dtype=np.float64) for b in batches]
     if cos_norm:
         mats = [cosine_norm(m) for m in mats]
-    pcs, meta = multi_batch_pca(mats, d=d, weights=weights)
+    pcs, meta = multi_batch_pca(mats, d=d, weights=weights, method=pca_method)
     out = engine.fast_mnn(pcs, k=k, prop_k=prop_k, restrict=restrict, ndist=ndist, merge_order=merge_order,
                           auto_merge=auto_merge, min_batch_skip=min_batch_skip, nthreads=nthreads)
     return out, meta

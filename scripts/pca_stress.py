@@ -28,7 +28,7 @@ for case in range(cases):
     try:
         ref_in = [pca.cosine_norm(m) for m in mats] if cos_norm else mats
         ref, meta = pca.multi_batch_pca(ref_in, d=d, weights=weights, get_variance=True)
-        mine = bx.multiBatchPCA(*mats, d=d, weights=weights, cos_norm=cos_norm, iters=60)
+        mine = bx.multiBatchPCA(*mats, d=d, weights=weights, cos_norm=cos_norm)
         sgn = np.sign((mine["rotation"] * meta["rotation"]).sum(axis=0))
         np.testing.assert_allclose(mine["centers"], meta["centers"], rtol=1e-10, atol=1e-12)
         np.testing.assert_allclose(mine["rotation"] * sgn[None, :], meta["rotation"], rtol=1e-5, atol=1e-7)

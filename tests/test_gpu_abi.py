@@ -24,7 +24,7 @@ def test_bmx_fast_mnn_one_shot_as_the_shim_calls_it(oracle):
     nrows = np.asarray([m.shape[0] for m in mats], dtype=np.int32)
     n_restrict = np.full(nb, -1, dtype=np.int32)                   # restrict = NULL
     tree = encode_postorder(resolve_merge_order(nb, [3, 1, 2]))    # merge.order = c(3, 1, 2)
-    params = BmxParams(20, float("nan"), 3.0, 0.0, 0)
+    params = BmxParams(ctypes.sizeof(BmxParams), 20, float("nan"), 3.0, 0.0, 0)   # var_adj / sigma left zero-initialised
     N = int(nrows.sum())
     corrected = np.zeros((N, d), dtype=np.float64, order="F")
     batch = np.zeros(N, dtype=np.int32)

@@ -71,7 +71,8 @@ def test_device_multi_batch_pca_matches_svd_oracle(bx, pca, weights, cos_norm):
         mats = [m + 3.0 for m in mats]          # away from the origin, as normalised expression is
     ref_in = [pca.cosine_norm(m) for m in mats] if cos_norm else mats
     ref, meta = pca.multi_batch_pca(ref_in, d=10, weights=weights, get_variance=True)
-    mine = bx.multiBatchPCA(*mats, d=10, weights=weights, cos_norm=cos_norm, iters=40)
+    mine = bx.multiBatchPCA(*mats, d=10, weights=weights, cos_norm=cos_norm)   # default: until the residual is small
+    assert mine["path"] == "device" and mine["residual"] <= 1e-9 and 1 <= mine["iters_used"] <= 200
     rot = align_sign(mine["rotation"], meta["rotation"])
     sgn = np.sign((mine["rotation"] * meta["rotation"]).sum(axis=0))
     np.testing.assert_allclose(mine["centers"], meta["centers"], rtol=1e-11, atol=1e-13)
@@ -83,18 +84,65 @@ def test_device_multi_batch_pca_matches_svd_oracle(bx, pca, weights, cos_norm):
     assert w.size == 3
     with pytest.raises(ValueError, match="not the same"):
         bx.multiBatchPCA(mats[0], mats[1][:0])
-    with pytest.raises(RuntimeError, match="d <= 56"):
-        bx.multiBatchPCA(*mats, d=60)
 
 
-def test_device_pca_without_a_spectral_gap_converges_with_more_iterations(bx, pca):
-    # pure noise: the d-th and the 65th eigenvalue are close, subspace iteration needs many more sweeps
+def test_device_pca_wide_block_d_above_56(bx, pca):
+    # fastMNN(d = 100) (BASELINE.json configs[4]): d > 56 takes the 128-vector block
+    rng = np.random.default_rng(1200008)
+    G, r = 400, 90
+    load = rng.standard_normal((G, r)) * np.linspace(4.0, 1.0, r)
+    mats = [load @ rng.standard_normal((r, n)) + 0.2 * rng.standard_normal((G, n)) + off
+            for n, off in ((700, 0.0), (500, 0.3))]
+    ref, meta = pca.multi_batch_pca(mats, d=80, get_variance=True)
+    mine = bx.multiBatchPCA(*mats, d=80)
+    assert mine["path"] == "device"
+    sgn = np.sign((mine["rotation"] * meta["rotation"]).sum(axis=0))
+    np.testing.assert_allclose(mine["d"] ** 2 / 2, meta["var.explained"], rtol=1e-9)
+    np.testing.assert_allclose(mine["rotation"] * sgn[None, :], meta["rotation"], rtol=1e-5, atol=1e-7)
+    for got, want in zip(mine["pcs"], ref):
+        np.testing.assert_allclose(got * sgn[None, :], want, rtol=1e-5, atol=1e-7)
+
+
+def test_small_or_low_rank_inputs_take_the_host_path(bx, pca):
+    # what the 64-vector device block cannot take: 60 genes; d = 130; data of exact rank 10
+    rng = np.random.default_rng(1200009)
+    few = [rng.standard_normal((60, 300)), rng.standard_normal((60, 200)) + 0.5]
+    ref, meta = pca.multi_batch_pca(few, d=5)
+    mine = bx.multiBatchPCA(*few, d=5)
+    assert mine["path"].startswith("host")
+    sgn = np.sign((mine["rotation"] * meta["rotation"]).sum(axis=0))
+    np.testing.assert_allclose(mine["rotation"] * sgn[None, :], meta["rotation"], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(mine["pcs"][1] * sgn[None, :], ref[1], rtol=1e-6, atol=1e-8)
+    low = [rng.standard_normal((300, 10)) @ rng.standard_normal((10, n)) for n in (400, 500)]
+    ref, meta = pca.multi_batch_pca(low, d=6)
+    mine = bx.multiBatchPCA(*low, d=6)
+    assert mine["path"].startswith("host")
+    sgn = np.sign((mine["rotation"] * meta["rotation"]).sum(axis=0))
+    np.testing.assert_allclose(mine["rotation"] * sgn[None, :], meta["rotation"], rtol=1e-6, atol=1e-8)
+    wide = [rng.standard_normal((300, 400)), rng.standard_normal((300, 500))]
+    assert bx.multiBatchPCA(*wide, d=130, return_pcs=False)["path"].startswith("host")
+    # round 1's host signature still works
+    l2 = [bx.cosineNorm(m, mode="l2norm") for m in few]
+    old = bx.multiBatchPCA(*few, d=5, l2=l2, block=128)
+    assert old["path"].startswith("host") and old["rotation"].shape == (60, 5)
+
+
+def test_device_pca_without_a_spectral_gap_converges_by_itself(bx, pca):
+    # pure noise: the d-th and the 65th eigenvalue are close.  Default arguments: the iteration runs until the Ritz
+    # residual says it is done (round 2 stopped after a fixed 15 sweeps and was off by 0.1 here)
     rng = np.random.default_rng(1200002)
     t1, t2 = rng.standard_normal((200, 900)), rng.standard_normal((200, 700)) + 0.3
     ref, meta = pca.multi_batch_pca([t1, t2], d=8)
-    mine = bx.multiBatchPCA(t1, t2, d=8, iters=400)
+    mine = bx.multiBatchPCA(t1, t2, d=8)
+    assert mine["path"] == "device" and mine["residual"] <= 1e-9
     rot = align_sign(mine["rotation"], meta["rotation"])
     np.testing.assert_allclose(rot, meta["rotation"], rtol=1e-5, atol=1e-7)
+    # a budget that is too small is an error, not a silently wrong subspace
+    with pytest.raises(RuntimeError, match="did not reach the tolerance"):
+        bx.multiBatchPCA(t1, t2, d=8, max_iters=3)
+    # the fixed-count form of round 2 is still there for whoever asks for it
+    fixed = bx.multiBatchPCA(t1, t2, d=8, iters=5, return_pcs=False)
+    assert fixed["iters_used"] == 5
 
 
 def test_fast_mnn_front_end(bx, pca):
@@ -127,10 +175,54 @@ def test_fast_mnn_front_end_device_pca(bx, pca):
         z = cent[:, rng.integers(0, 5, n)] + rng.standard_normal((r, n))
         return np.abs(load @ z + 0.5 * rng.standard_normal((G, n)) + 6.0 + off)
     B = [batch(1500, 0.0), batch(1800, 0.8), batch(1200, -0.5)]
-    out = bx.fastMNN(*B, d=8, pca_iters=60)
+    out = bx.fastMNN(*B, d=8)
     ref, meta = pca.fast_mnn(*B, d=8)
     sgn = np.sign((out.rotation * meta["rotation"]).sum(axis=0))
     np.testing.assert_allclose(out.rotation * sgn[None, :], meta["rotation"], rtol=1e-6, atol=1e-8)
     np.testing.assert_allclose(out.corrected * sgn[None, :], ref.corrected, rtol=1e-5, atol=1e-8)
     for (ol, orr), (rl, rr) in zip(out.merge_info.pairs, ref.merge_info.pairs):
         assert np.array_equal(ol, rl) and np.array_equal(orr, rr)
+
+
+def test_fast_mnn_single_object_with_batch_labels(bx, pca):
+    # .fast_mnn_single (R/fastMNN.R:364-388): one genes x cells matrix + batch=, cells of the batches interleaved;
+    # results and pairs in the caller's cell order (tests/testthat/test-fast-mnn.R:152-177)
+    rng = np.random.default_rng(1200012)
+    G, r = 300, 6
+    load = rng.standard_normal((G, r)) * 2.0
+    n = [900, 700, 800]
+    mats = [np.abs(load @ rng.standard_normal((r, m)) + 0.4 * rng.standard_normal((G, m)) + 5.0 + 0.6 * i)
+            for i, m in enumerate(n)]
+    x = np.hstack(mats)
+    labels = np.repeat(["b2", "b0", "b1"], n)
+    shuffle = rng.permutation(x.shape[1])
+    x, labels = x[:, shuffle], labels[shuffle]
+    out = bx.fastMNN(x, batch=labels, d=6)
+    ref, meta = pca.fast_mnn_single(x, labels, d=6)
+    sgn = np.sign((out.rotation * meta["rotation"]).sum(axis=0))
+    np.testing.assert_allclose(out.corrected * sgn[None, :], ref.corrected, rtol=1e-5, atol=1e-8)
+    assert list(out.batch) == list(ref.batch) == list(labels)
+    for (ol, orr), (rl, rr) in zip(out.merge_info.pairs, ref.merge_info.pairs):
+        assert np.array_equal(ol, rl) and np.array_equal(orr, rr)
+    with pytest.raises(ValueError, match="'batch' must be specified"):
+        bx.fastMNN(x)
+
+
+@pytest.mark.parametrize("where", ["device", "host"])
+def test_config4_shape_20000_genes_50_pcs_4_batches(bx, pca, where):
+    # BASELINE.json configs[3] at test scale: 20 000 genes -> cosineNorm -> multiBatchPCA(d = 50) -> reducedMNN over
+    # 4 batches (3 000 cells each: 1.9 GB of input), PCA on the device and on the host (R/fastMNN.R:339-358,
+    # R/multiBatchPCA.R:211-258), against the oracle's dense decomposition; MNN pairs bit-exact
+    rng = np.random.default_rng(20250314 + 4000)
+    G, d, nb, n = 20000, 50, 4, 3000
+    load = np.abs(rng.standard_normal((G, d))) * (1.0 / np.sqrt(1.0 + np.arange(d) / 5.0))
+    B = [load @ rng.standard_normal((d, n)) + 0.5 * (rng.random((G, n)) - 0.5) * 3.4641 + 4.0 + 0.3 * b for b in range(nb)]
+    out = bx.fastMNN(*B, d=d, pca=where)
+    ref, meta = pca.fast_mnn(*B, d=d, pca_method="gram")
+    sgn = np.sign((out.rotation * meta["rotation"]).sum(axis=0))
+    np.testing.assert_allclose(out.rotation * sgn[None, :], meta["rotation"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(out.corrected * sgn[None, :], ref.corrected, rtol=1e-5, atol=1e-8)
+    assert [p[0].size for p in out.merge_info.pairs] == [p[0].size for p in ref.merge_info.pairs]
+    for (ol, orr), (rl, rr) in zip(out.merge_info.pairs, ref.merge_info.pairs):
+        assert np.array_equal(ol, rl) and np.array_equal(orr, rr)
+    np.testing.assert_allclose(out.merge_info.lost_var, ref.merge_info.lost_var, rtol=1e-6, atol=1e-10)
