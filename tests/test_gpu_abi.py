@@ -92,3 +92,30 @@ def test_exact_path_with_more_queries_than_grid_y(oracle):
     oi, od = oracle.query_knn(X, Q[rows], 7)
     assert np.array_equal(idx[rows], oi) and np.array_equal(dist[rows], od)
     assert idx.min() >= 1 and idx.max() <= 40 and np.all(np.diff(dist, axis=1) >= 0)
+
+
+def test_params_struct_of_an_older_header_and_unset_size(oracle):
+    # bmx_params_t.struct_size: a caller built against round 1's header (fields up to auto_merge) gets the defaults of
+    # the fields added later (var_adj = 0, sigma = 0.1); a struct whose size was never set is refused, not misread
+    from batchelor_amd import _lib
+    from batchelor_amd.merge_tree import encode_postorder, resolve_merge_order
+    from batchelor_amd.reduced_mnn import MnnEngine
+    from tests.test_gpu_engine import assert_same_result
+
+    class OldParams(ctypes.Structure):
+        _fields_ = [("struct_size", ctypes.c_int32), ("k", ctypes.c_int32), ("prop_k", ctypes.c_double),
+                    ("ndist", ctypes.c_double), ("min_batch_skip", ctypes.c_double), ("auto_merge", ctypes.c_int32)]
+
+    B = synth_batches(12, [600, 500], 20)
+    eng = MnnEngine()
+    try:
+        eng.upload(B)
+        tree = encode_postorder(resolve_merge_order(2))
+        old = OldParams(ctypes.sizeof(OldParams), 20, float("nan"), 3.0, 0.0, 0)
+        _lib.check(_lib.lib().bmx_engine_run(eng._h, ctypes.byref(old), _lib.i32p(tree), int(tree.size)))
+        assert_same_result(eng.download(), oracle.reduced_mnn(*B))
+        unset = OldParams(0, 20, float("nan"), 3.0, 0.0, 0)
+        rc = _lib.lib().bmx_engine_run(eng._h, ctypes.byref(unset), _lib.i32p(tree), int(tree.size))
+        assert rc != 0 and "struct_size" in _lib.lib().bmx_last_error().decode()
+    finally:
+        eng.close()

