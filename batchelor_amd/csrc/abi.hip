@@ -612,6 +612,14 @@ int32_t bmx_engine_merge_stats(bmx_engine_t* e, int32_t merge, int64_t* out6) {
     return guarded([&] { e->impl->merge_stats(merge, out6); });
 }
 
+int32_t bmx_engine_set_watchdog(bmx_engine_t* e, double base_ms) {
+    return guarded([&] { e->impl->set_watchdog(1e-3 * base_ms); });
+}
+
+int32_t bmx_engine_debug_stall(bmx_engine_t* e, int32_t ms) {
+    return guarded([&] { e->impl->debug_stall(ms); });
+}
+
 int32_t bmx_engine_set_profiling(bmx_engine_t* e, int32_t on) {
     return guarded([&] { e->impl->set_profiling(on != 0); });
 }

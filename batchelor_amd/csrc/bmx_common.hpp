@@ -28,6 +28,22 @@ struct Error : std::runtime_error {
 
 #define BMX_LAUNCH_CHECK() BMX_HIP(hipGetLastError())
 
+// The candidate kernels hand data between waves through LDS words polled in unbounded loops (a bound that ends in
+// s_trap doubled their run time): a protocol bug or a hardware fault would show up as a kernel that never
+// ends.  So the HOST never waits without a deadline: every wait on the engine's stream polls hipStreamQuery against a
+// budget scaled from the work that was queued, and gives up with this error.  The engine that sees it marks itself
+// dead (its stream cannot be trusted any more; only a fresh process gets the GPU back).
+struct WatchdogTimeout : Error {
+    explicit WatchdogTimeout(const std::string& m) : Error(BMX_ERR_HIP, m) {}
+};
+// budget_s <= 0: plain hipStreamSynchronize
+void guarded_stream_sync(hipStream_t stream, double budget_s);
+
+// candidates the fp16 tier keeps per query and reference range for k <= 20 (A/B builds: make VARIANT=x EXTRA=-DBMX_KS1=24)
+#ifndef BMX_KS1
+#define BMX_KS1 32
+#endif
+
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 
@@ -44,6 +60,7 @@ struct DevBlockCache {
         int device;
     };
     std::vector<Block> blocks;
+    bool leak = false;  // the owner's stream is stuck (watchdog): blocks are abandoned, hipFree would wait for ever
     DevBlockCache() = default;
     DevBlockCache(const DevBlockCache&) = delete;
     DevBlockCache& operator=(const DevBlockCache&) = delete;
@@ -62,7 +79,7 @@ struct DevBlockCache {
     }
     ~DevBlockCache() {
         GlobalPool& g = global();
-        {
+        if (!leak) {
             std::lock_guard<std::mutex> lk(g.mu);
             for (const Block& b : blocks) {
                 if (g.blocks.size() < 96 && g.total + b.bytes <= ((size_t)16 << 30)) {
@@ -109,6 +126,7 @@ struct DevBlockCache {
         return p;
     }
     void give(void* p, size_t bytes) {
+        if (leak) return;
         size_t total = bytes;
         for (const Block& x : blocks) total += x.bytes;
         if (blocks.size() >= 48 || total > ((size_t)24 << 30)) {
@@ -220,6 +238,17 @@ struct KnnWorkspace {
     DevBuf<double> xd;             // short exact lists
     DevBuf<int32_t> xcnt, xi, slow;
     int force_exact = 0;           // testing hook: route every query through the exact path
+    double wd_budget_s = 0.0;      // deadline of every host wait inside a search (0 = none); the engine scales it per search
+    void sync(hipStream_t s) const { guarded_stream_sync(s, wd_budget_s); }
+    // Small read-backs (counts that decide what is launched next) land in PINNED host memory owned by the workspace: the
+    // copy is then really asynchronous -- a read-back into pageable memory may block inside hipMemcpyAsync, where no
+    // deadline applies -- and its target outlives a wait that gives up.  64 words: [0] read_count, the rest the engine's.
+    int64_t* pinned_words() {
+        if (!pin_) BMX_HIP(hipHostMalloc((void**)&pin_, 64 * sizeof(int64_t), hipHostMallocDefault));
+        return pin_;
+    }
+    int64_t* pin_ = nullptr;
+    bool abandon = false;          // the stream is stuck (watchdog): nothing that would wait for the device may be called
     // diagnostics of the last search / totals since the engine reset them
     int64_t last_exact = 0;             // queries that took the exact FP64 path
     int64_t last_flagged_tier[2] = {0, 0};  // queries each candidate tier could not certify
@@ -243,6 +272,8 @@ struct KnnWorkspace {
         return events[events_used++];
     }
     ~KnnWorkspace() {
+        if (abandon) return;
+        if (pin_) (void)hipHostFree(pin_);
         for (auto& e : events) {
             (void)hipEventDestroy(e.first);
             (void)hipEventDestroy(e.second);
@@ -277,8 +308,10 @@ bool bf16_launch(hipStream_t stream, KnnWorkspace& ws, int NS, int KS, const Bf1
 // for neighbours.  The search then starts from that threshold instead of a sampled one and a row may come back with
 // fewer than k neighbours, padded with -1: exactly the references within the bound, or the k nearest if there are
 // more than k of them.
+// centre (nullable, [d] device): a point near the middle of the reference rows (the prepared images are taken relative to
+// it: any vector is valid, a good one keeps the error bound tight); null: the mean of a strided sample is computed here.
 void knn_device(hipStream_t stream, KnnWorkspace& ws, const double* X, const int32_t* ref_rows, int nr,
                 const double* Q, const int32_t* q_rows, int nq, int d, int k, int32_t* idx_out, double* dist_out,
-                int q_begin, int q_end, const float* seed_d2 = nullptr);
+                int q_begin, int q_end, const float* seed_d2 = nullptr, const double* centre = nullptr);
 
 }  // namespace bmx

@@ -130,6 +130,57 @@ __global__ __launch_bounds__(256) void tricube_apply_kernel(double* __restrict__
     }
 }
 
+// The same for k <= 32 and an even d (rows of whole 16-byte pieces): half a wave per row.  Lane j of the half holds
+// neighbour j (one coalesced read of the row's k distances and indices), the weights are formed once per row -- the
+// normalising sum taken in neighbour order, like rowSums -- and each lane accumulates two columns from 16-byte loads of
+// the gathered correction vectors, in neighbour order (the reference's loop over k, R/utils_tricube.R:18-20).
+template <bool IN_PLACE>
+__global__ __launch_bounds__(256) void tricube_apply_half(double* __restrict__ X, int n, int d,
+                                                          const double* __restrict__ averaged,
+                                                          const int32_t* __restrict__ idx, const double* __restrict__ dist,
+                                                          int k, double ndist) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x & 63, hl = lane & 31, half = lane >> 5;
+    const int i = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + half;
+    const bool live = i < n;
+    const int64_t ib = live ? i : 0;  // (an idle half follows row 0 and stores nothing: the shuffles stay convergent)
+    const double dj = hl < k ? dist[ib * k + hl] : 0.0;
+    const int ij = hl < k ? idx[ib * k + hl] : 0;
+    const int middle = (k + 1) / 2;  // ceiling(k / 2), 1-based
+    double bw = __shfl(dj, (half << 5) + middle - 1) * ndist;
+    bw = bw < 1e-8 ? 1e-8 : bw;  // pmax(1e-8, bandwidth)
+    double rel = dj / bw;
+    rel = rel > 1.0 ? 1.0 : rel;
+    const double t = 1.0 - rel * rel * rel;
+    const double wu = t * t * t;
+    double total = 0.0;
+    for (int j = 0; j < k; ++j) total += __shfl(wu, (half << 5) + j);
+    const double w = wu / total;
+    const int np = d >> 1;  // 16-byte pieces per row
+    for (int p0 = 0; p0 < np; p0 += 32) {
+        const int p = p0 + hl;
+        d2 acc = d2{0.0, 0.0};
+        for (int j = 0; j < k; ++j) {
+            const int src = __shfl(ij, (half << 5) + j);
+            const double wj = __shfl(w, (half << 5) + j);
+            if (p < np) {
+                const d2 a = reinterpret_cast<const d2*>(averaged + (int64_t)src * d)[p];
+                acc[0] = acc[0] + a[0] * wj;
+                acc[1] = acc[1] + a[1] * wj;
+            }
+        }
+        if (live && p < np) {
+            d2* row = reinterpret_cast<d2*>(X + ib * d);
+            if (IN_PLACE) {
+                const d2 x = row[p];
+                acc[0] = x[0] + acc[0];
+                acc[1] = x[1] + acc[1];
+            }
+            row[p] = acc;
+        }
+    }
+}
+
 __global__ void add_scaled_rows_kernel(double* __restrict__ X, int64_t total, int d, const double* __restrict__ corr,
                                        const double* __restrict__ scaling) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -388,8 +439,12 @@ void average_correction(hipStream_t stream, const double* L, const int32_t* lrow
 void tricube_apply(hipStream_t stream, double* X, int n, int d, const double* averaged, const int32_t* idx,
                    const double* dist, int k, double ndist) {
     if (n <= 0 || k <= 0) return;  // k == 0: the weighted correction is all zeros (R/utils_tricube.R:22-23)
-    hipLaunchKernelGGL(tricube_apply_kernel<true>, dim3(cdiv(n, 4)), dim3(256), 0, stream, X, n, d, averaged, idx, dist, k,
-                       ndist);
+    if (k <= 32 && (d & 1) == 0)
+        hipLaunchKernelGGL(tricube_apply_half<true>, dim3(cdiv(n, 8)), dim3(256), 0, stream, X, n, d, averaged, idx, dist, k,
+                           ndist);
+    else
+        hipLaunchKernelGGL(tricube_apply_kernel<true>, dim3(cdiv(n, 4)), dim3(256), 0, stream, X, n, d, averaged, idx, dist, k,
+                           ndist);
     BMX_LAUNCH_CHECK();
 }
 
@@ -400,8 +455,12 @@ void tricube_vectors(hipStream_t stream, int n, int d, const double* averaged, c
         BMX_HIP(hipMemsetAsync(correction, 0, (size_t)n * d * sizeof(double), stream));
         return;
     }
-    hipLaunchKernelGGL(tricube_apply_kernel<false>, dim3(cdiv(n, 4)), dim3(256), 0, stream, correction, n, d, averaged, idx,
-                       dist, k, ndist);
+    if (k <= 32 && (d & 1) == 0)
+        hipLaunchKernelGGL(tricube_apply_half<false>, dim3(cdiv(n, 8)), dim3(256), 0, stream, correction, n, d, averaged, idx,
+                           dist, k, ndist);
+    else
+        hipLaunchKernelGGL(tricube_apply_kernel<false>, dim3(cdiv(n, 4)), dim3(256), 0, stream, correction, n, d, averaged,
+                           idx, dist, k, ndist);
     BMX_LAUNCH_CHECK();
 }
 

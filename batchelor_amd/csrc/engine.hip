@@ -18,6 +18,12 @@ __global__ void gather_rows_i32(const int32_t* __restrict__ pos, int n, const in
     if (i < n) out[i] = rows ? rows[pos[i]] : pos[i];
 }
 
+// testing hook of the watchdog: spins on the 100 MHz real-time counter, then ends
+__global__ void stall_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+
 __global__ void iota_offset(int32_t* __restrict__ out, int n, int off) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = off + i;
@@ -50,10 +56,41 @@ Engine::Engine(int device) : device_(device) {
     BMX_HIP(hipSetDevice(device_));
     BMX_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     scal_.reserve(4096);
+    if (const char* v = std::getenv("BMX_WATCHDOG_MS")) wd_base_s_ = 1e-3 * std::atof(v);
+}
+
+void Engine::check_alive() const {
+    if (dead_)
+        throw Error(BMX_ERR_HIP, "the engine is dead after a watchdog timeout (GPU work that never finished); restart the "
+                                 "process to get the GPU back");
+}
+
+void Engine::wait(double work_s) {
+    try {
+        guarded_stream_sync(stream_, wd_base_s_ > 0.0 ? wd_base_s_ + work_s : 0.0);
+    } catch (const WatchdogTimeout&) {
+        dead_ = true;
+        cache_.leak = true;  // hipFree would wait for the device
+        knn_ws_.abandon = true;
+        throw;
+    }
+}
+
+void Engine::debug_stall(int ms) {
+    check_alive();
+    BMX_HIP(hipSetDevice(device_));
+    hipLaunchKernelGGL(stall_kernel, dim3(1), dim3(64), 0, stream_, (unsigned long long)std::max(0, ms) * 100000ull);
+    BMX_LAUNCH_CHECK();
 }
 
 Engine::~Engine() {
     (void)hipSetDevice(device_);
+    if (dead_) {
+        // nothing on this stream can be waited for: the stream, the communicator and the device blocks are abandoned
+        DevBlockCache::current() = &cache_;
+        return;
+    }
+    if (scal_pin_) (void)hipHostFree(scal_pin_);
     if (comm_ && rccl::api().CommDestroy) {
         if (stream_) (void)hipStreamSynchronize(stream_);
         (void)rccl::api().CommDestroy(comm_);
@@ -130,6 +167,7 @@ void Engine::exchange(void* buf, int64_t bytes_per_rank) {
 
 void Engine::upload(int nbatches, int d, const double* const* data, const int32_t* nrows,
                     const int32_t* const* restrict_idx, const int32_t* n_restrict) {
+    check_alive();
     CacheScope cache_scope(&cache_);
     BMX_HIP(hipSetDevice(device_));
     root_.reset();  // results of an earlier run describe other inputs
@@ -177,11 +215,14 @@ void Engine::upload(int nbatches, int d, const double* const* data, const int32_
 }
 
 void Engine::knn(const double* X, const int32_t* ref_rows, int nr, const double* Q, const int32_t* q_rows, int nq,
-                 int k, int32_t* idx, double* dist, const float* seed_d2) {
+                 int k, int32_t* idx, double* dist, const float* seed_d2, const double* centre) {
     // query rows are split over ranks; the padded per-rank slices are contiguous, so the all-gather is in place
     int64_t b = 0, e = nq;
     bmx_shard_range_impl(nq, rank_, world_, &b, &e);
-    knn_device(stream_, knn_ws_, X, ref_rows, nr, Q, q_rows, nq, d_, k, idx, dist, (int)b, (int)e, seed_d2);
+    // watchdog budget of this search's waits: ~1e4 times what the candidate pass takes per pair evaluation (1.5e-13 s),
+    // and enough for a search that falls through to the FP64 scan (1e-10 s per pair and dimension)
+    knn_ws_.wd_budget_s = wd_base_s_ > 0.0 ? wd_base_s_ + 2e-10 * (double)nq * (double)nr * (double)d_ / 50.0 : 0.0;
+    knn_device(stream_, knn_ws_, X, ref_rows, nr, Q, q_rows, nq, d_, k, idx, dist, (int)b, (int)e, seed_d2, centre);
     {
         const int64_t per = (nq + world_ - 1) / world_;
         exchange(idx, per * k * (int64_t)sizeof(int32_t));
@@ -189,7 +230,8 @@ void Engine::knn(const double* X, const int32_t* ref_rows, int nr, const double*
     }
 }
 
-Engine::MnnOut Engine::find_mnn(const Node& left, const Node& right, int k, double prop_k) {
+Engine::MnnOut Engine::find_mnn(const Node& left, const Node& right, int k, double prop_k, const double* mu_left,
+                                const double* mu_right) {
     // .restricted_mnn (R/MNN_tree.R:113-133): search among the restricted rows only
     const int nL = left.has_restrict ? left.n_restrict : left.n;
     const int nR = right.has_restrict ? right.n_restrict : right.n;
@@ -203,16 +245,17 @@ Engine::MnnOut Engine::find_mnn(const Node& left, const Node& right, int k, doub
     int32_t* idxRL = idxRL_.reserve((size_t)perR * o.k1);
     // 1. every right cell's neighbours in LEFT, with their distances
     double* distRL = distRL_.reserve((size_t)perR * o.k1);
-    knn(left.data.p, lrows, nL, right.data.p, rrows, nR, o.k1, idxRL, distRL);
+    knn(left.data.p, lrows, nL, right.data.p, rrows, nR, o.k1, idxRL, distRL, nullptr, mu_left);
     // 2. a pair needs its left cell in some right cell's list, so only those left cells are searched in RIGHT (with a
     //    growing merged reference most left cells are in nobody's list).  The result is the same set of pairs.
     int32_t* flagL = flagL_.reserve(nL);
     int32_t* offSel = offSel_.reserve((size_t)nL + 1);
     int32_t* lsel = lsel_.reserve(nL);
     select_listed_rows(stream_, scan_ws_, idxRL, (int64_t)nR * o.k1, nL, flagL, offSel, lsel);
-    int32_t nsel = 0;
-    BMX_HIP(hipMemcpyAsync(&nsel, offSel + nL, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
-    BMX_HIP(hipStreamSynchronize(stream_));
+    int32_t* pin = reinterpret_cast<int32_t*>(knn_ws_.pinned_words() + 1);  // (pinned: see KnnWorkspace::pinned_words)
+    BMX_HIP(hipMemcpyAsync(pin, offSel + nL, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+    wait(knn_ws_.wd_budget_s);
+    const int32_t nsel = pin[0];
     o.nsel = nsel;
     if (std::getenv("BMX_DEBUG")) fprintf(stderr, "[bmx] find_mnn: %d of %d left cells are in some right cell's list\n", nsel, nL);
     const int32_t* qsel = lsel;  // rows of left.data to query with
@@ -228,7 +271,7 @@ Engine::MnnOut Engine::find_mnn(const Node& left, const Node& right, int k, doub
     // sample pass, and few candidates beyond the ones that matter).  Rows may come back short, padded with -1.
     float* seed = seedL_.reserve((size_t)std::max<int64_t>(1, perL));
     seed_thresholds(stream_, idxRL, distRL, (int64_t)nR * o.k1, offSel, nsel, seed);
-    knn(right.data.p, rrows, nR, left.data.p, qsel, nsel, o.k2, idxLR, nullptr, seed);
+    knn(right.data.p, rrows, nR, left.data.p, qsel, nsel, o.k2, idxLR, nullptr, seed, mu_right);
     int32_t* cntL = cntL_.reserve(std::max(1, nsel));
     int32_t* offL = offL_.reserve((size_t)nsel + 1);
     int32_t* partR = partR_.reserve((size_t)nR * o.k1);
@@ -240,12 +283,11 @@ Engine::MnnOut Engine::find_mnn(const Node& left, const Node& right, int k, doub
                   maskL_.reserve(std::max(1, nsel)));
     exclusive_scan_i32(stream_, scan_ws_, cntL, offL, nsel);
     compact_mnn_cells(stream_, scan_ws_, cntR, nR, flagR, offR, second_u);
-    int32_t h[2] = {0, 0};
-    BMX_HIP(hipMemcpyAsync(&h[0], offL + nsel, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
-    BMX_HIP(hipMemcpyAsync(&h[1], offR + nR, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
-    BMX_HIP(hipStreamSynchronize(stream_));
-    o.P = h[0];
-    o.U = h[1];
+    BMX_HIP(hipMemcpyAsync(&pin[2], offL + nsel, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+    BMX_HIP(hipMemcpyAsync(&pin[3], offR + nR, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+    wait(knn_ws_.wd_budget_s);
+    o.P = pin[2];
+    o.U = pin[3];
     return o;
 }
 
@@ -392,7 +434,7 @@ void Engine::merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p,
                                (size_t)right.n * d_ * sizeof(double), hipMemcpyDeviceToDevice, stream_));
     }
     sec.reset();
-    const MnnOut mo = find_mnn(left, right, p.k, p.prop_k);  // R/fastMNN.R:476-477
+    const MnnOut mo = find_mnn(left, right, p.k, p.prop_k, mu_l, mu_r);  // R/fastMNN.R:476-477
     if (mo.P == 0) throw Error(BMX_ERR_NO_PAIRS, "no mutual nearest neighbours found between batches");
     sec = std::make_unique<Section>(this);  // streaming section 2: pairs, averaging, centring + statistics
     const int nLs = left.has_restrict ? left.n_restrict : left.n;
@@ -432,9 +474,10 @@ void Engine::merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p,
         rec.bs_slot = n_slots_++;
         batch_magnitude(stream_, overall, msq, d_, scal_.p + rec.bs_slot);
         if (p.min_batch_skip > 0.0) {
-            double h = 0.0;
-            BMX_HIP(hipMemcpyAsync(&h, scal_.p + rec.bs_slot, sizeof(double), hipMemcpyDeviceToHost, stream_));
-            BMX_HIP(hipStreamSynchronize(stream_));
+            double* hp = reinterpret_cast<double*>(knn_ws_.pinned_words() + 4);
+            BMX_HIP(hipMemcpyAsync(hp, scal_.p + rec.bs_slot, sizeof(double), hipMemcpyDeviceToHost, stream_));
+            wait();
+            const double h = *hp;
             if (h < p.min_batch_skip) {
                 do_correct = false;
                 rec.skipped = true;
@@ -462,7 +505,7 @@ void Engine::merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p,
         int32_t* idxT = idxT_.reserve((size_t)per * safe_k);
         double* distT = distT_.reserve((size_t)per * safe_k);
         sec.reset();
-        knn(right.data.p, srows, mo.U, right.data.p, nullptr, right.n, safe_k, idxT, distT);
+        knn(right.data.p, srows, mo.U, right.data.p, nullptr, right.n, safe_k, idxT, distT, nullptr, mu_r);
         sec = std::make_unique<Section>(this);  // streaming section 3: tricube apply, rbind
         if (!p.var_adj) {
             tricube_apply(stream_, right.data.p, right.n, d_, averaged, idxT, distT, safe_k, p.ndist);
@@ -490,6 +533,7 @@ void Engine::merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p,
             double* scaling = asv_scale_.reserve(right.n);
             adjust_shift_variance_device(stream_, left.data.p, d_, left.n, right.data.p, right.n, corr, p.sigma, r1, nLs, r2,
                                          nRs, scaling, ws, /* vect_row_major */ 1);
+            run_tail_budget_s_ += 1e-6 * (double)right.n * ((double)nLs + (double)nRs);
             add_scaled_rows(stream_, right.data.p, right.n, d_, corr, scaling);
         }
         right.stat_slot.assign(right.origin.size(), -1);  // the corrected cells moved
@@ -542,8 +586,10 @@ void Engine::merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p,
 void Engine::run(const bmx_params_t& p, const int32_t* tree, int tree_len) {
     CacheScope cache_scope(&cache_);
     BMX_HIP(hipSetDevice(device_));
+    check_alive();
     if (B_ < 2) throw Error(BMX_ERR_ARG, "at least two batches must be specified");
     if (p.k < 1) throw Error(BMX_ERR_ARG, "'k' must be positive");
+    run_tail_budget_s_ = 0.0;
     const int nmerges = B_ - 1;
     root_.reset();  // a run that fails half-way leaves nothing to download
     merges_.clear();
@@ -682,14 +728,22 @@ void Engine::run(const bmx_params_t& p, const int32_t* tree, int tree_len) {
         }
         root_ = std::move(rem[0]);
     }
-    BMX_HIP(hipMemcpyAsync(scal_host_.data(), scal_.p, scal_host_.size() * sizeof(double), hipMemcpyDeviceToHost,
-                           stream_));
-    BMX_HIP(hipStreamSynchronize(stream_));
+    if (scal_pin_cap_ < scal_host_.size()) {
+        if (scal_pin_) (void)hipHostFree(scal_pin_);
+        scal_pin_ = nullptr;
+        BMX_HIP(hipHostMalloc((void**)&scal_pin_, scal_host_.size() * sizeof(double), hipHostMallocDefault));
+        scal_pin_cap_ = scal_host_.size();
+    }
+    BMX_HIP(hipMemcpyAsync(scal_pin_, scal_.p, scal_host_.size() * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    // (with var_adj the last merge's adjust_shift_variance is still running: its budget is n2 (nr1 + nr2) pair visits)
+    wait(run_tail_budget_s_);
+    std::memcpy(scal_host_.data(), scal_pin_, scal_host_.size() * sizeof(double));
     fallbacks_ = knn_ws_.exact_total;
 }
 
 void Engine::download(double* corrected, int32_t* batch, int32_t* merge_left, int32_t* merge_right,
                       double* batch_size, int32_t* skipped, double* lost_var) {
+    check_alive();
     CacheScope cache_scope(&cache_);
     BMX_HIP(hipSetDevice(device_));
     if (!root_) throw Error(BMX_ERR_ARG, "no finished run to download");
@@ -749,6 +803,7 @@ __global__ void remap_pairs_tab(const int32_t* __restrict__ in, int64_t n, const
 }  // namespace
 
 int64_t Engine::pairs_count(int merge) const {
+    check_alive();
     if (!root_) throw Error(BMX_ERR_ARG, "no finished run to download");
     if (merge < 0 || merge >= (int)merges_.size()) throw Error(BMX_ERR_ARG, "merge index out of range");
     return merges_[merge].npairs;

@@ -66,6 +66,12 @@ class Engine {
     void pairs_into(int merge, int32_t* left, int32_t* right);  // caller-allocated, pairs_count(merge) entries each
     void merge_stats(int merge, int64_t* out6) const;
     void set_profiling(bool on) { knn_ws_.profile = on; }
+    // Host-side watchdog (bmx_common.hpp: guarded_stream_sync): every wait of a run has a deadline of base_s plus a term
+    // scaled from the work queued; base_s <= 0 switches it off.  Default 60 s (BMX_WATCHDOG_MS overrides).
+    void set_watchdog(double base_s) { wd_base_s_ = base_s; }
+    bool dead() const { return dead_; }
+    // testing hook: a kernel that keeps the engine's stream busy for `ms` milliseconds and then ends by itself
+    void debug_stall(int ms);
     // diagnostics: keep a copy of the two matrices merge `merge` searches (left and right node after
     // orthogonalisation, R/fastMNN.R:473-477); -1 = off
     void set_snapshot(int merge) { snap_merge_ = merge; }
@@ -81,7 +87,7 @@ class Engine {
 
     // single primitives (also used by the host-pointer parity entry points)
     void knn(const double* X, const int32_t* ref_rows, int nr, const double* Q, const int32_t* q_rows, int nq, int k,
-             int32_t* idx, double* dist, const float* seed_d2 = nullptr);
+             int32_t* idx, double* dist, const float* seed_d2 = nullptr, const double* centre = nullptr);
     struct MnnOut {
         int64_t P = 0;
         int U = 0;
@@ -90,7 +96,8 @@ class Engine {
     };
     // findMutualNN on (restricted) left / right rows; leaves idxLR_ (one row per SELECTED left cell, lsel_), idxRL_,
     // cntL_, offL_ (per row of idxLR_), partR_, cntR_, second_u_
-    MnnOut find_mnn(const Node& left, const Node& right, int k, double prop_k);
+    MnnOut find_mnn(const Node& left, const Node& right, int k, double prop_k, const double* mu_left = nullptr,
+                    const double* mu_right = nullptr);
 
   private:
     DevBlockCache cache_;  // first member: destroyed last, after every DevBuf below has handed its block back
@@ -121,6 +128,14 @@ class Engine {
     int count_mnn_pairs(const Node& left, const Node& right, const bmx_params_t& p);
     std::unique_ptr<Node> clone_node(const Node& src);
     void exchange(void* buf, int64_t bytes_per_rank);
+
+    void wait(double work_s = 0.0);  // guarded wait on the engine's stream: deadline wd_base_s_ + work_s
+    void check_alive() const;
+    double wd_base_s_ = 60.0;
+    double run_tail_budget_s_ = 0.0;
+    double* scal_pin_ = nullptr;  // pinned landing area of the end-of-run scalar read-back
+    size_t scal_pin_cap_ = 0;
+    bool dead_ = false;
 
     int device_ = 0;
     hipStream_t stream_ = nullptr;

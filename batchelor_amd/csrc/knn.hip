@@ -20,8 +20,11 @@
 #include "knn_select.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
+#include <thread>
 
 namespace bmx {
 
@@ -543,7 +546,7 @@ int candidate_tiers(int d, int k, int nr, Tier out[2]) {
     }();
     int n = 0;
     if (k > 36) return 0;
-    const int KS1 = k <= 20 ? 32 : 48, KS2 = k <= 20 ? 24 : 40;
+    const int KS1 = k <= 20 ? BMX_KS1 : 48, KS2 = k <= 20 ? 24 : 40;
     const int ns1 = f16_pick_ns(d, KS1);
     if (ns1 && nr > 2 * KS1 && (only == 0 || only == 1)) out[n++] = Tier{1, ns1, KS1};
     const int ns2 = bf16_pick_ns(d);
@@ -555,7 +558,7 @@ int candidate_tiers(int d, int k, int nr, Tier out[2]) {
 // are listed in `flagged` (count in flagged[0]) with their k-th candidate distance in flag_bound.
 void candidate_pass(hipStream_t stream, KnnWorkspace& ws, const Tier& T, const double* X, const int32_t* ref_rows, int nr,
                     const double* Qs, const int32_t* qrs, int nq, int d, int k, int32_t* io, double* dout,
-                    int32_t* flagged, double* flag_bound, const float* seed_d2) {
+                    int32_t* flagged, double* flag_bound, const float* seed_d2, const double* centre) {
     const int NS = T.NS, KS = T.KS;
     ws.last_variant = T.id == 1 ? 3 : 2;
     // queries per workgroup: 8 consumer waves of 32 in the fp16 kernel; 8 or 4 (long rows, long lists) in the bf16 kernel
@@ -624,23 +627,27 @@ void candidate_pass(hipStream_t stream, KnnWorkspace& ws, const Tier& T, const d
 
     // centre of the reference: any vector is valid (the error bound uses the norms actually obtained), a point
     // near the mean keeps it tight -- the mean of a strided sample of <= 16k rows costs next to nothing
-    const int cstride = std::max(1, nr / 16384);
-    const int ncs = cdiv(nr, cstride);
-    const int rpb = 256;
-    const int nb = cdiv(ncs, rpb);
-    double* red = ws.red.reserve((size_t)nb * d);
-    hipLaunchKernelGGL(colsum_partial, dim3(nb), dim3(256), 0, stream, X, ref_rows, ncs, d, rpb, cstride, red);
-    BMX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_final, dim3(cdiv(d, 64)), dim3(64), 0, stream, red, nb, d, 1.0 / ncs, mean);
-    BMX_LAUNCH_CHECK();
+    // (the merge engine already holds the column mean of the reference's node and hands it in: nothing to compute)
+    if (!centre) {
+        const int cstride = std::max(1, nr / 16384);
+        const int ncs = cdiv(nr, cstride);
+        const int rpb = 256;
+        const int nb = cdiv(ncs, rpb);
+        double* red = ws.red.reserve((size_t)nb * d);
+        hipLaunchKernelGGL(colsum_partial, dim3(nb), dim3(256), 0, stream, X, ref_rows, ncs, d, rpb, cstride, red);
+        BMX_LAUNCH_CHECK();
+        hipLaunchKernelGGL(colsum_final, dim3(cdiv(d, 64)), dim3(64), 0, stream, red, nb, d, 1.0 / ncs, mean);
+        BMX_LAUNCH_CHECK();
+        centre = mean;
+    }
     BMX_HIP(hipMemsetAsync(maxbits, 0, sizeof(unsigned long long), stream));
 
     if (T.id == 1) {
-        f16_prep(stream, X, ref_rows, nr, nr_pad, d, NS, mean, 0, reinterpret_cast<uint16_t*>(pr), rn2, maxbits, slots);
-        f16_prep(stream, Qs, qrs, nq, nq_pad, d, NS, mean, 1, reinterpret_cast<uint16_t*>(pq), qn2, maxbits, slots);
+        f16_prep(stream, X, ref_rows, nr, nr_pad, d, NS, centre, 0, reinterpret_cast<uint16_t*>(pr), rn2, maxbits, slots);
+        f16_prep(stream, Qs, qrs, nq, nq_pad, d, NS, centre, 1, reinterpret_cast<uint16_t*>(pq), qn2, maxbits, slots);
     } else {
-        bf16_prep(stream, X, ref_rows, nr, nr_pad, d, NS, mean, 0, reinterpret_cast<uint16_t*>(pr), rn2, maxbits, slots);
-        bf16_prep(stream, Qs, qrs, nq, nq_pad, d, NS, mean, 1, reinterpret_cast<uint16_t*>(pq), qn2, maxbits, slots);
+        bf16_prep(stream, X, ref_rows, nr, nr_pad, d, NS, centre, 0, reinterpret_cast<uint16_t*>(pr), rn2, maxbits, slots);
+        bf16_prep(stream, Qs, qrs, nq, nq_pad, d, NS, centre, 1, reinterpret_cast<uint16_t*>(pq), qn2, maxbits, slots);
     }
     double eps_k, eps_qr, eps_split, eps_den;
     if (T.id == 1) {
@@ -701,7 +708,7 @@ void candidate_pass(hipStream_t stream, KnnWorkspace& ws, const Tier& T, const d
     if (std::getenv("BMX_DEBUG")) {
         std::vector<int32_t> hc((size_t)nq * nchunks * KS);
         BMX_HIP(hipMemcpyAsync(hc.data(), cand, hc.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-        BMX_HIP(hipStreamSynchronize(stream));
+        ws.sync(stream);
         size_t valid = 0;
         for (int32_t v : hc) valid += v >= 0;
         fprintf(stderr, "[bmx] candidates per query after the top-k pass: %.1f (of %d slots)\n", (double)valid / nq,
@@ -709,12 +716,42 @@ void candidate_pass(hipStream_t stream, KnnWorkspace& ws, const Tier& T, const d
     }
 }
 
-int read_count(hipStream_t stream, const int32_t* dev) {
-    int32_t h = 0;
-    BMX_HIP(hipMemcpyAsync(&h, dev, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-    BMX_HIP(hipStreamSynchronize(stream));
-    return h;
+int read_count(hipStream_t stream, KnnWorkspace& ws, const int32_t* dev) {
+    int32_t* h = reinterpret_cast<int32_t*>(ws.pinned_words());
+    BMX_HIP(hipMemcpyAsync(h, dev, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    ws.sync(stream);
+    return *h;
 }
+
+}  // namespace
+
+void guarded_stream_sync(hipStream_t stream, double budget_s) {
+    if (!(budget_s > 0.0)) {
+        BMX_HIP(hipStreamSynchronize(stream));
+        return;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(stream);
+        if (e == hipSuccess) return;
+        if (e != hipErrorNotReady) {
+            (void)hipGetLastError();
+            throw Error(BMX_ERR_HIP, std::string("hipStreamQuery failed: ") + hipGetErrorString(e));
+        }
+        (void)hipGetLastError();  // hipErrorNotReady is sticky for hipGetLastError otherwise
+        const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (el > budget_s) {
+            char msg[200];
+            std::snprintf(msg, sizeof(msg),
+                          "watchdog: the GPU work queued on the engine's stream did not finish within %.1f s; the engine is "
+                          "dead (restart the process)", budget_s);
+            throw WatchdogTimeout(msg);
+        }
+        if (el > 2e-3) std::this_thread::sleep_for(std::chrono::microseconds(100));  // short waits spin, long ones sleep
+    }
+}
+
+namespace {
 
 // Exact FP64 search: `count` queries listed in scan-list form (list[1 + f], nullptr = queries 0 .. count-1).  With
 // bounds (the k-th candidate distance of each listed query) a bounded filter pass runs first; what overflows it, or
@@ -740,7 +777,7 @@ void exact_search(hipStream_t stream, KnnWorkspace& ws, const double* X, const i
         hipLaunchKernelGGL(knn_exact_pick, dim3(cdiv(count, 4)), dim3(256), 0, stream, list, count, k, xcnt, xd, xi, io,
                            dout, slow);
         BMX_LAUNCH_CHECK();
-        count = read_count(stream, slow);
+        count = read_count(stream, ws, slow);
         scan_list = slow;
     }
     if (count > 0) {
@@ -763,7 +800,7 @@ void exact_search(hipStream_t stream, KnnWorkspace& ws, const double* X, const i
 // queries (Qs, qrs)[0, nq) through the tiers tiers[t ...]
 void search_tiers(hipStream_t stream, KnnWorkspace& ws, const Tier* tiers, int ntiers, int t, const double* X,
                   const int32_t* ref_rows, int nr, const double* Qs, const int32_t* qrs, int nq, int d, int k, int32_t* io,
-                  double* dout, const float* seed_d2 = nullptr) {
+                  double* dout, const float* seed_d2 = nullptr, const double* centre = nullptr) {
     if (t >= ntiers) {
         exact_search(stream, ws, X, ref_rows, nr, Qs, qrs, d, k, io, dout, nullptr, nullptr, nq);
         return;
@@ -771,9 +808,9 @@ void search_tiers(hipStream_t stream, KnnWorkspace& ws, const Tier* tiers, int n
     int32_t* flagged = ws.flagged_t[t].reserve((size_t)nq + 1);
     double* bound = ws.flag_bound_t[t].reserve((size_t)nq + 1);
     // (what a seeded pass cannot settle goes on unseeded: the full k nearest serve the caller just as well)
-    candidate_pass(stream, ws, tiers[t], X, ref_rows, nr, Qs, qrs, nq, d, k, io, dout, flagged, bound, seed_d2);
+    candidate_pass(stream, ws, tiers[t], X, ref_rows, nr, Qs, qrs, nq, d, k, io, dout, flagged, bound, seed_d2, centre);
     // the number of uncertified queries decides what is launched next, so it is read back (one small synchronisation)
-    const int count = read_count(stream, flagged);
+    const int count = read_count(stream, ws, flagged);
     if (count == 0) return;
     ws.last_flagged_tier[t] += count;
     // a few hundred leftovers are cheaper in one bounded FP64 sweep than in another candidate pass (prep of the whole
@@ -786,7 +823,7 @@ void search_tiers(hipStream_t stream, KnnWorkspace& ws, const Tier* tiers, int n
         BMX_LAUNCH_CHECK();
         int32_t* sub_idx = ws.sub_idx[t].reserve((size_t)count * k);
         double* sub_dist = dout ? ws.sub_dist[t].reserve((size_t)count * k) : nullptr;
-        search_tiers(stream, ws, tiers, ntiers, t + 1, X, ref_rows, nr, Qs, rows2, count, d, k, sub_idx, sub_dist);
+        search_tiers(stream, ws, tiers, ntiers, t + 1, X, ref_rows, nr, Qs, rows2, count, d, k, sub_idx, sub_dist, nullptr, centre);
         hipLaunchKernelGGL(scatter_flagged, dim3(cdiv((int64_t)count * k, 256)), dim3(256), 0, stream, flagged, count, k,
                            sub_idx, sub_dist, io, dout);
         BMX_LAUNCH_CHECK();
@@ -799,7 +836,7 @@ void search_tiers(hipStream_t stream, KnnWorkspace& ws, const Tier* tiers, int n
 
 void knn_device(hipStream_t stream, KnnWorkspace& ws, const double* X, const int32_t* ref_rows, int nr,
                 const double* Q, const int32_t* q_rows, int nq_total, int d, int k, int32_t* idx_out,
-                double* dist_out, int q_begin, int q_end, const float* seed_d2) {
+                double* dist_out, int q_begin, int q_end, const float* seed_d2, const double* centre) {
     (void)nq_total;
     const int nq = q_end - q_begin;
     if (nq <= 0 || k <= 0) return;
@@ -819,7 +856,7 @@ void knn_device(hipStream_t stream, KnnWorkspace& ws, const double* X, const int
     ws.last_exact = 0;
     ws.last_flagged_tier[0] = ws.last_flagged_tier[1] = 0;
     search_tiers(stream, ws, tiers, ntiers, 0, X, ref_rows, nr, Qs, qrs, nq, d, k, io, dout,
-                 seed_d2 ? seed_d2 + q_begin : nullptr);
+                 seed_d2 ? seed_d2 + q_begin : nullptr, centre);
     if (ntiers > 0) ws.exact_total += ws.last_exact;
     if (ntiers > 0) ws.tier2_total += ws.last_flagged_tier[0] * (ntiers > 1 ? 1 : 0);
 }

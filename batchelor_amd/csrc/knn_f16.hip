@@ -1009,7 +1009,7 @@ void launch(hipStream_t stream, KnnWorkspace& ws, const Bf16Launch& L) {
 // MFMA k-steps (16 fp16 each) for d + 3 columns; 0 = this tier does not take the shape
 int f16_pick_ns(int d, int KS) {
     const int ns = (d + 3 + 15) / 16;
-    if (KS == 32) return ns <= 8 ? ns : 0;
+    if (KS == BMX_KS1) return ns <= 8 ? ns : 0;
     if (KS == 48) return ns <= 4 ? ns : 0;
     return 0;
 }
@@ -1041,8 +1041,8 @@ void f16_prep(hipStream_t stream, const double* X, const int32_t* rows, int n, i
 bool f16_launch(hipStream_t stream, KnnWorkspace& ws, int NS, int KS, const Bf16Launch& L) {
 #define BMX_CASE(N)                       \
     case N:                               \
-        if (KS == 32)                     \
-            launch<N, 32>(stream, ws, L); \
+        if (KS == BMX_KS1)                \
+            launch<N, BMX_KS1>(stream, ws, L); \
         else if constexpr (N <= 4)        \
             launch<N, 48>(stream, ws, L); \
         else                              \

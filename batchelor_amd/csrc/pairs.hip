@@ -88,9 +88,19 @@ __global__ void mutual_left(const int32_t* __restrict__ idxLR, int nL, int k2, c
     if (maskL) maskL[c0] = m;
 }
 
+// position of `want` in row[0, k), -1 if absent
+__device__ __forceinline__ int row_find(const int32_t* __restrict__ row, int k, int32_t want) {
+    int at = -1;
+    for (int t = 0; t < k; ++t) at = row[t] == want ? t : at;
+    return at;
+}
+
+// One probe serves both sides: right cell r lists left cell l; if l's row lists r at rank j2, the pair is mutual -- r
+// keeps l among its partners and bit j2 of l's mask is set (64-bit atomic OR; the masks were zeroed).  With maskL == null
+// (k2 > 64) only the right side is written and mutual_left does the left side.
 __global__ void mutual_right(const int32_t* __restrict__ idxLR, int k2, const int32_t* __restrict__ idxRL, int nR,
                              int k1, const int32_t* __restrict__ lpos2c, int32_t* __restrict__ partR,
-                             int32_t* __restrict__ cntR) {
+                             int32_t* __restrict__ cntR, unsigned long long* __restrict__ maskL) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nR) return;
     int32_t* row = partR + (int64_t)r * k1;
@@ -98,7 +108,9 @@ __global__ void mutual_right(const int32_t* __restrict__ idxLR, int k2, const in
     for (int j = 0; j < k1; ++j) {
         const int32_t l = idxRL[(int64_t)r * k1 + j];
         const int64_t c = lpos2c ? lpos2c[l] : l;
-        if (!row_contains(idxLR + c * k2, k2, r)) continue;
+        const int j2 = row_find(idxLR + c * k2, k2, r);
+        if (j2 < 0) continue;
+        if (maskL) atomicOr(maskL + c, 1ull << j2);
         int p = m++;  // insertion keeps the partners ascending = the order `rowsum` adds them in
         while (p > 0 && row[p - 1] > l) {
             row[p] = row[p - 1];
@@ -107,6 +119,11 @@ __global__ void mutual_right(const int32_t* __restrict__ idxLR, int k2, const in
         row[p] = l;
     }
     cntR[r] = m;
+}
+
+__global__ void popcount_rows(const unsigned long long* __restrict__ mask, int n, int32_t* __restrict__ cnt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) cnt[i] = __popcll(mask[i]);
 }
 
 __global__ void emit_pairs_kernel(const int32_t* __restrict__ idxLR, int nL, int k2, const int32_t* __restrict__ idxRL,
@@ -184,14 +201,23 @@ void exclusive_scan_i32(hipStream_t stream, ScanWorkspace& ws, const int32_t* in
 void mutual_counts(hipStream_t stream, const int32_t* idxLR, int nL, int k2, const int32_t* idxRL, int nR, int k1,
                    int32_t* cntL, int32_t* partR, int32_t* cntR, const int32_t* lsel, const int32_t* lpos2c,
                    unsigned long long* maskL) {
-    if (nL > 0) {
+    // k2 <= 64 (and a mask buffer): the right cells' probe finds every mutual pair once and marks it on both sides;
+    // otherwise the left side is probed separately
+    const bool fused = maskL != nullptr && k2 <= 64;
+    if (fused && nL > 0) BMX_HIP(hipMemsetAsync(maskL, 0, (size_t)nL * sizeof(unsigned long long), stream));
+    if (!fused && nL > 0) {
         hipLaunchKernelGGL(mutual_left, dim3(cdiv(nL, 256)), dim3(256), 0, stream, idxLR, nL, k2, idxRL, k1, lsel,
-                           cntL, k2 <= 64 ? maskL : nullptr);
+                           cntL, (unsigned long long*)nullptr);
         BMX_LAUNCH_CHECK();
     }
     if (nR > 0) {
         hipLaunchKernelGGL(mutual_right, dim3(cdiv(nR, 256)), dim3(256), 0, stream, idxLR, k2, idxRL, nR, k1, lpos2c,
-                           partR, cntR);
+                           partR, cntR, fused ? maskL : nullptr);
+        BMX_LAUNCH_CHECK();
+    }
+    if (fused && nL > 0) {
+        hipLaunchKernelGGL(popcount_rows, dim3(cdiv(nL, 256)), dim3(256), 0, stream, (const unsigned long long*)maskL, nL,
+                           cntL);
         BMX_LAUNCH_CHECK();
     }
 }

@@ -133,6 +133,14 @@ class MnnEngine:
         _lib.check(_lib.lib().bmx_engine_exchange_stats(self._h, ctypes.byref(calls), ctypes.byref(nbytes)))
         return {"calls": calls.value, "bytes": nbytes.value}
 
+    def set_watchdog(self, base_ms):
+        """Deadline base of every wait of a run in milliseconds (<= 0: off); see bmx_engine_set_watchdog."""
+        _lib.check(_lib.lib().bmx_engine_set_watchdog(self._h, ctypes.c_double(float(base_ms))))
+
+    def _debug_stall(self, ms):
+        """Testing hook: keep the engine's stream busy for `ms` milliseconds."""
+        _lib.check(_lib.lib().bmx_engine_debug_stall(self._h, int(ms)))
+
     def set_profiling(self, on=True):
         _lib.check(_lib.lib().bmx_engine_set_profiling(self._h, 1 if on else 0))
 

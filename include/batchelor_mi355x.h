@@ -143,6 +143,17 @@ int32_t bmx_engine_pairs_into(bmx_engine_t* e, int32_t merge, int32_t* left, int
 /* Sizes of merge `merge`: out[0..5] = {cells searched on the left, on the right, MNN-involved right cells U,
  * pairs P, all left cells, all right cells} -- the inputs of the algorithmic flop / byte counts. */
 int32_t bmx_engine_merge_stats(bmx_engine_t* e, int32_t merge, int64_t* out6);
+/* Hang safety.  The candidate kernels synchronise their waves through LDS words in unbounded poll loops, so the HOST
+ * never waits without a deadline: every wait of a run polls the engine's stream against base_ms plus a term scaled from
+ * the work queued (about 1e4 times its expected duration).  When a deadline passes the call returns BMX_ERR_HIP with a
+ * message starting "watchdog:", and the engine is dead: every later call on it fails at once and bmx_engine_destroy
+ * abandons its stream and device memory instead of waiting for them -- only a fresh process gets the GPU back.
+ * Default base 60 000 ms (environment BMX_WATCHDOG_MS overrides); base_ms <= 0 switches the watchdog off (plain
+ * hipStreamSynchronize). */
+int32_t bmx_engine_set_watchdog(bmx_engine_t* e, double base_ms);
+/* Testing hook of the watchdog: queues a kernel that keeps the engine's stream busy for `ms` milliseconds and then ends
+ * by itself (the GPU stays healthy). */
+int32_t bmx_engine_debug_stall(bmx_engine_t* e, int32_t ms);
 /* With profiling on, every launch of the dominant kernel (knn_topk_mfma) is bracketed by HIP events on the engine's
  * stream; after a run: total milliseconds, number of launches, and queries that needed the exact re-scan. */
 int32_t bmx_engine_set_profiling(bmx_engine_t* e, int32_t on);

@@ -119,3 +119,32 @@ def test_params_struct_of_an_older_header_and_unset_size(oracle):
         assert rc != 0 and "struct_size" in _lib.lib().bmx_last_error().decode()
     finally:
         eng.close()
+
+
+def test_watchdog_turns_a_stuck_stream_into_an_error():
+    # the candidate kernels poll LDS words without a bound (a bound ending in s_trap doubled their run time), so the host
+    # side never waits without a deadline.  Fault injection: a kernel that keeps the stream busy for 1.5 s (and then ends
+    # by itself) in front of a run whose waits are given 0.2 s.
+    import time
+    import batchelor_amd as bx
+    B = synth_batches(13, [500, 400], 10)
+    eng = bx.MnnEngine()
+    eng.upload(B)
+    eng.run()                      # healthy first
+    eng.set_watchdog(200)
+    eng._debug_stall(1500)
+    t0 = time.perf_counter()
+    with pytest.raises(bx.BatchelorMI355XError, match="watchdog"):
+        eng.run()
+    assert time.perf_counter() - t0 < 1.2      # gave up at the deadline, did not sit the stall out
+    with pytest.raises(bx.BatchelorMI355XError, match="dead"):
+        eng.run()                  # the engine stays dead ...
+    with pytest.raises(bx.BatchelorMI355XError, match="dead"):
+        eng.download()
+    eng.close()                    # ... and closing it does not wait for the stream either
+    time.sleep(1.6)                # the stall kernel ends by itself: the GPU is fine, a new engine works
+    fresh = bx.MnnEngine()
+    fresh.upload(B)
+    fresh.run()
+    assert np.all(np.isfinite(fresh.download().corrected))
+    fresh.close()
