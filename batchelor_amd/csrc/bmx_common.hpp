@@ -173,16 +173,30 @@ template <typename T>
 struct DevBuf {
     T* p = nullptr;
     size_t cap = 0;
+    bool view = false;  // p points into somebody else's block: nothing to release
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
-    DevBuf(DevBuf&& o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+    DevBuf(DevBuf&& o) noexcept : p(o.p), cap(o.cap), view(o.view) { o.p = nullptr; o.cap = 0; o.view = false; }
     DevBuf& operator=(DevBuf&& o) noexcept {
-        if (this != &o) { release(); p = o.p; cap = o.cap; o.p = nullptr; o.cap = 0; }
+        if (this != &o) { release(); p = o.p; cap = o.cap; view = o.view; o.p = nullptr; o.cap = 0; o.view = false; }
         return *this;
     }
     ~DevBuf() { release(); }
+    // a window of n elements at q inside a block that outlives this buffer
+    void alias(T* q, size_t n) {
+        release();
+        p = q;
+        cap = n;
+        view = true;
+    }
     void release() {
+        if (p && view) {
+            p = nullptr;
+            cap = 0;
+            view = false;
+            return;
+        }
         if (p) {
             if (DevBlockCache* c = DevBlockCache::current())
                 c->give(p, cap * sizeof(T));

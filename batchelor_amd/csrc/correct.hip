@@ -96,6 +96,51 @@ __global__ __launch_bounds__(256) void average_correction_kernel(
     }
 }
 
+// The same for an even d <= 64 and k1 <= 32: half a wave per MNN-involved right cell, 16-byte pieces, the partner rows of
+// four partners in flight at a time; the sum runs over the partners in ascending order, as above.
+__global__ __launch_bounds__(256) void average_correction_half(
+    const double* __restrict__ L, const int32_t* __restrict__ lrows, const double* __restrict__ R,
+    const int32_t* __restrict__ rrows, int d, const int32_t* __restrict__ second_u, int U,
+    const int32_t* __restrict__ partR, const int32_t* __restrict__ cntR, int k1, double* __restrict__ averaged) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x & 63, hl = lane & 31, half = lane >> 5;
+    const int u = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + half;
+    const bool live = u < U;
+    const int r = second_u[live ? u : 0];
+    const int m = live ? cntR[r] : 0;
+    const int np = d >> 1;
+    const bool act = hl < np;
+    // lane j of the half holds partner j's row
+    int64_t prow = 0;
+    if (hl < m) {
+        const int l = partR[(int64_t)r * k1 + hl];
+        prow = lrows ? lrows[l] : l;
+    }
+    const d2 rc = act ? reinterpret_cast<const d2*>(R + (int64_t)(rrows ? rrows[r] : r) * d)[hl] : d2{0.0, 0.0};
+    d2 s = d2{0.0, 0.0};
+    const int mm = max(m, __shfl_xor(m, 32));  // both halves run the same trip count (shuffles stay convergent)
+    for (int p0 = 0; p0 < mm; p0 += 4) {
+        d2 x[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int64_t row = __shfl(prow, (half << 5) + ((p0 + t) & 31));
+            x[t] = (act && p0 + t < m) ? reinterpret_cast<const d2*>(L + row * d)[hl] : rc;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (p0 + t < m) {
+                s[0] += x[t][0] - rc[0];
+                s[1] += x[t][1] - rc[1];
+            }
+    }
+    if (live && act) {
+        d2 o;
+        o[0] = s[0] / (double)m;
+        o[1] = s[1] / (double)m;
+        reinterpret_cast<d2*>(averaged + (int64_t)u * d)[hl] = o;
+    }
+}
+
 // one wave per row: tricube weights from the k ascending distances, then the weighted sum of correction vectors
 template <bool IN_PLACE>
 __global__ __launch_bounds__(256) void tricube_apply_kernel(double* __restrict__ X, int n, int d,
@@ -318,6 +363,104 @@ __global__ __launch_bounds__(256) void rows_pass(double* __restrict__ X, int d, 
     }
 }
 
+// The same pass for an even d <= 128 (rows of whole 16-byte pieces): LPR lanes per row -- 32 (d <= 64: two rows per wave
+// instruction) or 64 -- each lane holding one 16-byte piece (two columns), four wave-loads of rows in flight per trip.
+// Partial statistics come out in the layout rows_stats_final reads.
+template <bool APPLY, bool STATS, int LPR>
+__global__ __launch_bounds__(256) void rows_pass_v2(double* __restrict__ X, int d, SegDesc sd, const double* __restrict__ mu,
+                                                    const double* __restrict__ vec_pool, VecIds ids,
+                                                    const double* __restrict__ pivots, int maxnb,
+                                                    double* __restrict__ partial) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    constexpr int RPW = 64 / LPR;   // rows per wave-load
+    constexpr int UNR = 4;          // wave-loads in flight
+    __shared__ double vhat[APPLY ? PASS_EMAX : 1][128];
+    __shared__ double red[STATS ? 4 * RPW : 1][2][128];
+    const int seg = blockIdx.y;
+    if (blockIdx.x * PASS_ROWS >= sd.n[seg]) return;
+    const int b0 = sd.start[seg] + blockIdx.x * PASS_ROWS;
+    const int b1 = min(sd.start[seg] + sd.n[seg], b0 + PASS_ROWS);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int hl = lane & (LPR - 1), sub = lane / LPR;  // piece of the row, row of the wave-load
+    const int np = d >> 1;
+    const bool act = hl < np;
+    if constexpr (APPLY) {
+        for (int e = w; e < ids.n; e += 4) {  // unit vectors of this launch's batch vectors: wave e normalises vector e, e + 4
+            const double* v = vec_pool + (int64_t)ids.id[e] * d;
+            double sq = 0.0;
+            for (int c = lane; c < d; c += 64) sq += v[c] * v[c];
+            for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+            const double nrm = sqrt(sq);
+            for (int c = lane; c < d; c += 64) vhat[e][c] = v[c] / nrm;
+        }
+        __syncthreads();
+    }
+    d2 m_ = d2{0.0, 0.0}, pv = d2{0.0, 0.0}, s1 = d2{0.0, 0.0}, s2 = d2{0.0, 0.0};
+    if (act) {
+        if (APPLY) m_ = reinterpret_cast<const d2*>(mu)[hl];
+        if (STATS) pv = reinterpret_cast<const d2*>(pivots + (int64_t)seg * d)[hl];
+    }
+    for (int r0 = b0 + (w * UNR) * RPW; r0 < b1; r0 += 4 * UNR * RPW) {
+        d2 x[UNR];
+        bool ok[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int r = r0 + u * RPW + sub;
+            ok[u] = act && r < b1;
+            x[u] = ok[u] ? reinterpret_cast<const d2*>(X + (int64_t)r * d)[hl] : d2{0.0, 0.0};
+        }
+        if constexpr (APPLY) {
+            for (int e = 0; e < ids.n; ++e) {
+                const d2 vh = act ? *reinterpret_cast<const d2*>(&vhat[e][2 * hl]) : d2{0.0, 0.0};
+                double pr[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) pr[u] = (x[u][0] - m_[0]) * vh[0] + (x[u][1] - m_[1]) * vh[1];
+#pragma unroll
+                for (int o = LPR / 2; o > 0; o >>= 1) {
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u) pr[u] += __shfl_xor(pr[u], o);
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    x[u][0] = x[u][0] - pr[u] * vh[0];
+                    x[u][1] = x[u][1] - pr[u] * vh[1];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u)
+                if (ok[u]) reinterpret_cast<d2*>(X + (int64_t)(r0 + u * RPW + sub) * d)[hl] = x[u];
+        }
+        if constexpr (STATS) {
+#pragma unroll
+            for (int u = 0; u < UNR; ++u)
+                if (ok[u]) {
+                    const double t0 = x[u][0] - pv[0], t1 = x[u][1] - pv[1];
+                    s1[0] += t0;
+                    s1[1] += t1;
+                    s2[0] += t0 * t0;
+                    s2[1] += t1 * t1;
+                }
+        }
+    }
+    if constexpr (STATS) {
+        if (act) {
+            red[w * RPW + sub][0][2 * hl] = s1[0];
+            red[w * RPW + sub][0][2 * hl + 1] = s1[1];
+            red[w * RPW + sub][1][2 * hl] = s2[0];
+            red[w * RPW + sub][1][2 * hl + 1] = s2[1];
+        }
+        __syncthreads();
+        double* out = partial + ((int64_t)seg * maxnb + blockIdx.x) * 2 * d;
+        for (int e = threadIdx.x; e < 2 * d; e += 256) {
+            const int which = e / d, c = e - which * d;
+            double t = 0.0;
+#pragma unroll
+            for (int q = 0; q < 4 * RPW; ++q) t += red[q][which][c];
+            out[e] = t;
+        }
+    }
+}
+
 // first row of every segment: the shift of the one-pass variance
 __global__ void gather_pivots(const double* __restrict__ X, int d, SegDesc sd, double* __restrict__ pivots) {
     const int seg = blockIdx.x;
@@ -431,8 +574,12 @@ void average_correction(hipStream_t stream, const double* L, const int32_t* lrow
                         const int32_t* rrows, int d, const int32_t* second_u, int U, const int32_t* partR,
                         const int32_t* cntR, int k1, double* averaged) {
     if (U <= 0) return;
-    hipLaunchKernelGGL(average_correction_kernel, dim3(cdiv(U, 4)), dim3(256), 0, stream, L, lrows, R, rrows, d,
-                       second_u, U, partR, cntR, k1, averaged);
+    if ((d & 1) == 0 && d <= 64 && k1 <= 32)
+        hipLaunchKernelGGL(average_correction_half, dim3(cdiv(U, 8)), dim3(256), 0, stream, L, lrows, R, rrows, d, second_u, U,
+                           partR, cntR, k1, averaged);
+    else
+        hipLaunchKernelGGL(average_correction_kernel, dim3(cdiv(U, 4)), dim3(256), 0, stream, L, lrows, R, rrows, d,
+                           second_u, U, partR, cntR, k1, averaged);
     BMX_LAUNCH_CHECK();
 }
 
@@ -527,21 +674,31 @@ void rows_apply_stats(hipStream_t stream, ReduceWorkspace& ws, double* X, int d,
             ids.n = std::min(PASS_EMAX, nvec - e0);
             for (int e = 0; e < ids.n; ++e) ids.id[e] = vec_ids[e0 + e];
             const bool last = e0 + ids.n >= nvec;
+            const int form = (d & 1) || d > 128 ? 0 : (d <= 64 ? 32 : 64);  // lanes per row of the 16-byte form
+#define BMX_ROWS_PASS(A, S, PIV, PART)                                                                                       \
+    do {                                                                                                                     \
+        if (form == 32)                                                                                                      \
+            hipLaunchKernelGGL((rows_pass_v2<A, S, 32>), grid, dim3(256), 0, stream, X, d, sd, mu, vec_pool, ids, PIV, maxnb, \
+                               PART);                                                                                        \
+        else if (form == 64)                                                                                                 \
+            hipLaunchKernelGGL((rows_pass_v2<A, S, 64>), grid, dim3(256), 0, stream, X, d, sd, mu, vec_pool, ids, PIV, maxnb, \
+                               PART);                                                                                        \
+        else                                                                                                                 \
+            hipLaunchKernelGGL((rows_pass<A, S>), grid, dim3(256), 0, stream, X, d, sd, mu, vec_pool, ids, PIV, maxnb, PART); \
+    } while (0)
             if (stats && last) {
                 // the pivots are read from rows this very launch rewrites: take them first, after the earlier launches
                 hipLaunchKernelGGL(gather_pivots, dim3(sd.nseg), dim3(64), 0, stream, X, d, sd, pivots);
                 if (ids.n > 0)
-                    hipLaunchKernelGGL((rows_pass<true, true>), grid, dim3(256), 0, stream, X, d, sd, mu, vec_pool, ids,
-                                       pivots, maxnb, partial);
+                    BMX_ROWS_PASS(true, true, (const double*)pivots, partial);
                 else
-                    hipLaunchKernelGGL((rows_pass<false, true>), grid, dim3(256), 0, stream, X, d, sd, mu, vec_pool, ids,
-                                       pivots, maxnb, partial);
+                    BMX_ROWS_PASS(false, true, (const double*)pivots, partial);
                 hipLaunchKernelGGL(rows_stats_final, dim3(sd.nseg), dim3(256), 0, stream, partial, maxnb, d, sd, pivots, sl,
                                    means_pool, scal);
             } else if (ids.n > 0) {
-                hipLaunchKernelGGL((rows_pass<true, false>), grid, dim3(256), 0, stream, X, d, sd, mu, vec_pool, ids,
-                                   nullptr, maxnb, nullptr);
+                BMX_ROWS_PASS(true, false, (const double*)nullptr, (double*)nullptr);
             }
+#undef BMX_ROWS_PASS
             BMX_LAUNCH_CHECK();
             e0 += ids.n;
         } while (e0 < nvec);

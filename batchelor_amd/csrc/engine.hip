@@ -65,13 +65,17 @@ void Engine::check_alive() const {
                                  "process to get the GPU back");
 }
 
+void Engine::mark_dead() {
+    dead_ = true;
+    cache_.leak = true;  // hipFree would wait for the device
+    knn_ws_.abandon = true;
+}
+
 void Engine::wait(double work_s) {
     try {
         guarded_stream_sync(stream_, wd_base_s_ > 0.0 ? wd_base_s_ + work_s : 0.0);
     } catch (const WatchdogTimeout&) {
-        dead_ = true;
-        cache_.leak = true;  // hipFree would wait for the device
-        knn_ws_.abandon = true;
+        mark_dead();
         throw;
     }
 }
@@ -222,11 +226,20 @@ void Engine::knn(const double* X, const int32_t* ref_rows, int nr, const double*
     // watchdog budget of this search's waits: ~1e4 times what the candidate pass takes per pair evaluation (1.5e-13 s),
     // and enough for a search that falls through to the FP64 scan (1e-10 s per pair and dimension)
     knn_ws_.wd_budget_s = wd_base_s_ > 0.0 ? wd_base_s_ + 2e-10 * (double)nq * (double)nr * (double)d_ / 50.0 : 0.0;
-    knn_device(stream_, knn_ws_, X, ref_rows, nr, Q, q_rows, nq, d_, k, idx, dist, (int)b, (int)e, seed_d2, centre);
+    try {
+        knn_device(stream_, knn_ws_, X, ref_rows, nr, Q, q_rows, nq, d_, k, idx, dist, (int)b, (int)e, seed_d2, centre);
+    } catch (const WatchdogTimeout&) {  // (the search's own waits go through knn_ws_.sync, not through wait())
+        mark_dead();
+        throw;
+    }
     {
         const int64_t per = (nq + world_ - 1) / world_;
+        // indices and distances of one search: grouped, RCCL sends them as one launch
+        const bool group = dist && comm_ && world_ > 1 && rccl::api().GroupStart && rccl::api().GroupEnd;
+        if (group) (void)rccl::api().GroupStart();
         exchange(idx, per * k * (int64_t)sizeof(int32_t));
         if (dist) exchange(dist, per * k * (int64_t)sizeof(double));
+        if (group && rccl::api().GroupEnd() != 0) throw Error(BMX_ERR_EXCHANGE, "ncclGroupEnd failed");
     }
 }
 
@@ -552,10 +565,16 @@ void Engine::merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p,
     m.index = left.index;
     m.index.insert(m.index.end(), right.index.begin(), right.index.end());
     m.n = left.n + right.n;
-    double* md = m.data.reserve((size_t)m.n * d_);
-    BMX_HIP(hipMemcpyAsync(md, left.data.p, (size_t)left.n * d_ * sizeof(double), hipMemcpyDeviceToDevice, stream_));
-    BMX_HIP(hipMemcpyAsync(md + (size_t)left.n * d_, right.data.p, (size_t)right.n * d_ * sizeof(double),
-                           hipMemcpyDeviceToDevice, stream_));
+    if (left.data.view && right.data.view && left.data.p + (size_t)left.n * d_ == right.data.p) {
+        // both children sit next to each other in the run's arena (leaves laid out in tree order): the merged node IS
+        // that stretch of rows, rbind copies nothing
+        m.data.alias(left.data.p, (size_t)m.n * d_);
+    } else {
+        double* md = m.data.reserve((size_t)m.n * d_);
+        BMX_HIP(hipMemcpyAsync(md, left.data.p, (size_t)left.n * d_ * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+        BMX_HIP(hipMemcpyAsync(md + (size_t)left.n * d_, right.data.p, (size_t)right.n * d_ * sizeof(double),
+                               hipMemcpyDeviceToDevice, stream_));
+    }
     m.origin = left.origin;
     m.origin.insert(m.origin.end(), right.origin.begin(), right.origin.end());
     m.stat_slot = left.stat_slot;
@@ -610,12 +629,25 @@ void Engine::run(const bmx_params_t& p, const int32_t* tree, int tree_len) {
 
     // leaves: row-major working copies of the resident inputs
     std::vector<TreeSlot> slots;
+    // Predefined tree: the leaves go into ONE arena in the order the post-order code names them (= left to right in the
+    // tree), so the two children of every merge are adjacent row ranges and the merged node is their union in place.
+    // Auto-merge picks pairs as it goes: its leaves own their buffers and a merge copies.
+    double* arena = nullptr;
+    int64_t arena_rows = 0;
+    if (!p.auto_merge) arena = arena_.reserve((size_t)N_ * d_);
     auto make_leaf = [&](int b) {
         auto n = std::make_unique<Node>();
         n->index = {b + 1};
         n->n = nrows_[b];
         n->origin = {Segment{b + 1, nrows_[b]}};
-        double* dp = n->data.reserve((size_t)n->n * d_);
+        double* dp;
+        if (arena) {
+            n->data.alias(arena + (size_t)arena_rows * d_, (size_t)n->n * d_);
+            dp = n->data.p;
+            arena_rows += n->n;
+        } else {
+            dp = n->data.reserve((size_t)n->n * d_);
+        }
         transpose_cm_to_rm(stream_, inputs_cm_[b].p, n->n, d_, dp);
         if (n_restrict_[b] >= 0) {
             n->has_restrict = true;

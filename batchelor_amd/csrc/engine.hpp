@@ -113,6 +113,7 @@ class Engine {
     DevBuf<double> distT_, distRL_, averaged_, loc_, vecs_, scal_, means_pool_;
     DevBuf<float> seedL_;
     DevBuf<double> corr_, asv_ws_, asv_scale_;
+    DevBuf<double> arena_;  // [N][d]: the rows of a predefined-tree run, leaves in tree order (root_ aliases it)
     DevBuf<int32_t> iota_l_, iota_r_;
     int n_slots_ = 0, slot_cap_ = 0;
 
@@ -131,6 +132,7 @@ class Engine {
 
     void wait(double work_s = 0.0);  // guarded wait on the engine's stream: deadline wd_base_s_ + work_s
     void check_alive() const;
+    void mark_dead();
     double wd_base_s_ = 60.0;
     double run_tail_budget_s_ = 0.0;
     double* scal_pin_ = nullptr;  // pinned landing area of the end-of-run scalar read-back

@@ -32,6 +32,8 @@ void load(const char* path) {
     a.CommDestroy = reinterpret_cast<int (*)(Comm)>(sym("ncclCommDestroy"));
     a.AllGather = reinterpret_cast<int (*)(const void*, void*, size_t, int, Comm, hipStream_t)>(sym("ncclAllGather"));
     a.GetErrorString = reinterpret_cast<const char* (*)(int)>(sym("ncclGetErrorString"));
+    a.GroupStart = reinterpret_cast<int (*)()>(dlsym(h, "ncclGroupStart"));
+    a.GroupEnd = reinterpret_cast<int (*)()>(dlsym(h, "ncclGroupEnd"));
 }
 
 }  // namespace rccl

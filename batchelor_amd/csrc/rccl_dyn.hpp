@@ -22,6 +22,8 @@ struct Api {
     int (*CommDestroy)(Comm) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, Comm, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*GroupStart)() = nullptr;  // optional: two gathers of one search go out as one launch
+    int (*GroupEnd)() = nullptr;
     bool ready() const { return GetUniqueId && CommInitRank && CommDestroy && AllGather; }
 };
 

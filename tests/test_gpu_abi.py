@@ -137,9 +137,9 @@ def test_watchdog_turns_a_stuck_stream_into_an_error():
     with pytest.raises(bx.BatchelorMI355XError, match="watchdog"):
         eng.run()
     assert time.perf_counter() - t0 < 1.2      # gave up at the deadline, did not sit the stall out
-    with pytest.raises(bx.BatchelorMI355XError, match="dead"):
-        eng.run()                  # the engine stays dead ...
-    with pytest.raises(bx.BatchelorMI355XError, match="dead"):
+    with pytest.raises(bx.BatchelorMI355XError, match="dead after a watchdog timeout"):
+        eng.run()                  # the engine stays dead: refused at once, nothing is queued or waited for ...
+    with pytest.raises(bx.BatchelorMI355XError, match="dead after a watchdog timeout"):
         eng.download()
     eng.close()                    # ... and closing it does not wait for the stream either
     time.sleep(1.6)                # the stall kernel ends by itself: the GPU is fine, a new engine works

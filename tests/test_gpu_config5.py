@@ -76,6 +76,34 @@ def test_variance_adjusted_merge_vs_oracle(oracle, sigma):
     assert np.all(np.isfinite(three.corrected)) and len(three.merge_info.pairs) == 2
 
 
+def test_config5_scaled_tree_with_variance_adjustment(oracle):
+    # BASELINE.json configs[4] as named -- the 16-batch tree "with adjust_shift_variance on" -- at test scale.  The
+    # adjustment picks a discrete quantile per cell (see the test above): a cell whose walk is decided on the last bit
+    # lands on a neighbouring quantile in one of the two implementations, and every later merge of the tree searches on
+    # top of it, so the whole-tree claim is statistical: same merges, nearly all cells and nearly all pairs the same,
+    # everything finite, two runs bit-identical.
+    import batchelor_amd as bx
+    rng = np.random.Generator(np.random.PCG64(20250314 + 5001))
+    sizes = [int(x) for x in np.exp(rng.uniform(np.log(150), np.log(2500), 16))]
+    tree = balanced_tree([int(i) + 1 for i in np.argsort(sizes)[::-1]])
+    B = synth_batches(5, sizes, 100)
+    out = bx.reducedMNN(*B, merge_order=tree, var_adj=True, sigma=1.0)
+    again = bx.reducedMNN(*B, merge_order=tree, var_adj=True, sigma=1.0)
+    assert np.array_equal(out.corrected, again.corrected)
+    ref = oracle.reduced_mnn(*B, merge_order=tree, var_adj=True, sigma=1.0)
+    assert out.merge_info.left == ref.merge_info.left and out.merge_info.right == ref.merge_info.right
+    assert np.all(np.isfinite(out.corrected)) and len(out.merge_info.pairs) == 15
+    close = np.isclose(out.corrected, ref.corrected, rtol=1e-5, atol=1e-9).all(axis=1)
+    assert close.mean() > 0.97, close.mean()
+    N = int(sum(sizes))
+    for (ol, orr), (rl, rr) in zip(out.merge_info.pairs, ref.merge_info.pairs):
+        mine = set((ol.astype(np.int64) * (N + 1) + orr).tolist())
+        want = set((rl.astype(np.int64) * (N + 1) + rr).tolist())
+        assert len(mine & want) >= 0.97 * len(mine | want), (len(mine & want), len(mine | want))
+    plain = bx.reducedMNN(*B, merge_order=tree)
+    assert not np.array_equal(plain.corrected, out.corrected)          # the switch does something
+
+
 @pytest.fixture(scope="module")
 def full5():
     """BASELINE.json configs[4] at full size (the bench.py workload): 16 batches of 8 894 .. 281 334 cells, 100 PCs,
