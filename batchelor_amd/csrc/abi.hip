@@ -138,6 +138,10 @@ void bmx_shard_range(int64_t n, int32_t rank, int32_t world, int64_t* begin, int
     bmx::bmx_shard_range_impl(n, rank, world, begin, end);
 }
 
+int64_t bmx_shard_gather_bytes(int64_t n, int32_t world, int64_t bytes_per_row) {
+    return bmx::bmx_shard_rows_per_rank(n, world) * bytes_per_row;
+}
+
 int32_t bmx_query_knn(const double* X, int32_t nx, const double* query, int32_t nq, int32_t d, int32_t k,
                       int32_t* index, double* distance) {
     return guarded([&] {

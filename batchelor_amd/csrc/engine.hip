@@ -44,8 +44,13 @@ int choose_k(int k, double prop_k, int N) {
 
 }  // namespace
 
+// The one place the sharded search's layout is decided (the engine and the host-side tests both go through it): n query
+// rows are cut into `world` padded slices of rows_per_rank rows; rank r owns rows [r * rows_per_rank, ...) clipped to n,
+// and the list buffers hold world * rows_per_rank rows so that the all-gather is in place with equal counts.
+int64_t bmx_shard_rows_per_rank(int64_t n, int world) { return world > 0 ? (n + world - 1) / world : n; }
+
 void bmx_shard_range_impl(int64_t n, int rank, int world, int64_t* begin, int64_t* end) {
-    const int64_t per = world > 0 ? (n + world - 1) / world : n;
+    const int64_t per = bmx_shard_rows_per_rank(n, world);
     const int64_t b = std::min<int64_t>(n, per * rank);
     *begin = b;
     *end = std::min<int64_t>(n, b + per);
@@ -233,7 +238,7 @@ void Engine::knn(const double* X, const int32_t* ref_rows, int nr, const double*
         throw;
     }
     {
-        const int64_t per = (nq + world_ - 1) / world_;
+        const int64_t per = bmx_shard_rows_per_rank(nq, world_);
         // indices and distances of one search: grouped, RCCL sends them as one launch
         const bool group = dist && comm_ && world_ > 1 && rccl::api().GroupStart && rccl::api().GroupEnd;
         if (group) (void)rccl::api().GroupStart();
@@ -254,7 +259,7 @@ Engine::MnnOut Engine::find_mnn(const Node& left, const Node& right, int k, doub
     o.k1 = std::min(choose_k(k, prop_k, nL), nL);  // neighbours sought in LEFT for each right cell
     o.k2 = std::min(choose_k(k, prop_k, nR), nR);  // neighbours sought in RIGHT for each left cell
     if (o.k1 < 1 || o.k2 < 1) throw Error(BMX_ERR_ARG, "'k' must be positive");
-    const int64_t perR = (nR + world_ - 1) / world_ * (int64_t)world_;
+    const int64_t perR = bmx_shard_rows_per_rank(nR, world_) * (int64_t)world_;
     int32_t* idxRL = idxRL_.reserve((size_t)perR * o.k1);
     // 1. every right cell's neighbours in LEFT, with their distances
     double* distRL = distRL_.reserve((size_t)perR * o.k1);
@@ -277,7 +282,7 @@ Engine::MnnOut Engine::find_mnn(const Node& left, const Node& right, int k, doub
         compose_row_list(stream_, lsel, nsel, lrows, q);
         qsel = q;
     }
-    const int64_t perL = (nsel + world_ - 1) / world_ * (int64_t)world_;
+    const int64_t perL = bmx_shard_rows_per_rank(nsel, world_) * (int64_t)world_;
     int32_t* idxLR = idxLR_.reserve((size_t)std::max<int64_t>(1, perL) * o.k2);
     // A right cell r can only pair with a left cell l if it lists l, at a distance search 1 has just measured: the
     // largest such distance bounds how far search 2 has to look for l -- a tight starting threshold for free (no
@@ -514,7 +519,7 @@ void Engine::merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p,
         hipLaunchKernelGGL(gather_rows_i32, dim3(cdiv(mo.U, 256)), dim3(256), 0, stream_, second_u_.p, mo.U, rrows,
                            srows);
         BMX_LAUNCH_CHECK();
-        const int64_t per = (right.n + world_ - 1) / world_ * (int64_t)world_;
+        const int64_t per = bmx_shard_rows_per_rank(right.n, world_) * (int64_t)world_;
         int32_t* idxT = idxT_.reserve((size_t)per * safe_k);
         double* distT = distT_.reserve((size_t)per * safe_k);
         sec.reset();

@@ -45,6 +45,7 @@ struct MergeRecord {
 };
 
 void bmx_shard_range_impl(int64_t n, int rank, int world, int64_t* begin, int64_t* end);
+int64_t bmx_shard_rows_per_rank(int64_t n, int world);
 
 class Engine {
   public:

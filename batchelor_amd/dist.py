@@ -21,6 +21,32 @@ def shard_range(n, rank, world):
     return b.value, e.value
 
 
+def shard_gather_bytes(n, world, bytes_per_row):
+    """Bytes per rank of the in-place all-gather of a per-query list (bmx_shard_gather_bytes: padded equal slices)."""
+    f = _lib.lib().bmx_shard_gather_bytes
+    f.restype = ctypes.c_int64
+    return int(f(ctypes.c_int64(int(n)), int(world), ctypes.c_int64(int(bytes_per_row))))
+
+
+def sharded_rows(fn, nq, row_shape, dtype, exchange, rank, world):
+    """The engine's sharded search on host arrays: `fn(begin, end)` returns this rank's rows [begin, end) of a per-query
+    list (bmx_shard_range); they are written into their slice of the padded buffer and completed by ONE in-place
+    all-gather through `exchange` (a TorchExchange); every rank returns the full [nq, ...] list.  The layout arithmetic is
+    the library's (the engine sizes its device-side exchanges with the same two functions)."""
+    import numpy as np
+    import torch
+    width = int(np.prod(row_shape)) if row_shape else 1
+    item = np.dtype(dtype).itemsize
+    per_bytes = shard_gather_bytes(nq, world, width * item)
+    per_rows = per_bytes // (width * item) if width * item else 0
+    buf = np.zeros((per_rows * world,) + tuple(row_shape), dtype=dtype)
+    b, e = shard_range(nq, rank, world)
+    if e > b:
+        buf[b:e] = fn(b, e)
+    exchange.allgather_tensor_(torch.from_numpy(buf.reshape(-1).view(np.uint8)), per_bytes)
+    return buf[:nq]
+
+
 class _RawDeviceBuffer:
     """Exposes a raw device pointer to torch through the CUDA array interface (no copy)."""
 

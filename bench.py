@@ -393,16 +393,24 @@ def main():
         eng.set_profiling(False)
         reps = []
         fbatches = [np.asfortranarray(b) for b in batches]  # what the boundary is handed: column-major matrices
-        for _ in range(2):
+        stages = []
+        for _ in range(3):
             t1 = time.perf_counter()
             e2 = bx.MnnEngine(local_rank)
+            ta = time.perf_counter()
             e2.upload(fbatches)
+            tb = time.perf_counter()
             e2.run(k=k, merge_tree=tree, **run_kw)
+            tc = time.perf_counter()
             res = e2.download(with_pairs=True, c_order=False)
+            td = time.perf_counter()
             e2.close()
             reps.append(time.perf_counter() - t1)
+            stages.append({"create_ms": 1e3 * (ta - t1), "upload_ms": 1e3 * (tb - ta), "run_ms": 1e3 * (tc - tb),
+                           "download_ms": 1e3 * (td - tc), "close_ms": 1e3 * (reps[-1] - (td - t1))})
             del res
         h2h = min(reps)
+        h2h_stages = stages[int(np.argmin(reps))]
 
     if rank == 0:
         flops = algorithmic_flops(stats, d) / world  # this rank's share of the query rows
@@ -455,6 +463,7 @@ def main():
         if h2h is not None:
             line["value_host_to_host"] = n_cells / h2h
             line["host_to_host_ms"] = 1e3 * h2h
+            line["host_to_host_stages_ms"] = h2h_stages
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"], line["cpu_baseline_variants"] = cpu_baselines(batches, stats, d, k)

@@ -187,6 +187,10 @@ int32_t bmx_fast_mnn(int32_t nbatches, int32_t d, const double* const* data, con
 
 /* Row range [begin, end) of `n` query rows owned by `rank` of `world` (pure host arithmetic, no GPU). */
 void bmx_shard_range(int64_t n, int32_t rank, int32_t world, int64_t* begin, int64_t* end);
+/* Bytes each rank contributes to the in-place all-gather of a list with bytes_per_row bytes per query row (the slices
+ * are padded to equal length: the gathered buffer holds world * this many bytes).  The engine sizes its exchanges with
+ * the same function. */
+int64_t bmx_shard_gather_bytes(int64_t n, int32_t world, int64_t bytes_per_row);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Single primitives of the merge step, host in / host out, for parity tests that read like the reference's own
