@@ -258,8 +258,38 @@ struct KnnWorkspace {
     // copy is then really asynchronous -- a read-back into pageable memory may block inside hipMemcpyAsync, where no
     // deadline applies -- and its target outlives a wait that gives up.  64 words: [0] read_count, the rest the engine's.
     int64_t* pinned_words() {
-        if (!pin_) BMX_HIP(hipHostMalloc((void**)&pin_, 64 * sizeof(int64_t), hipHostMallocDefault));
+        if (!pin_) pin_ = static_cast<int64_t*>(pinned_small_take());
         return pin_;
+    }
+    // 64 KiB pinned blocks are kept in a process-wide free list: hipHostMalloc / hipHostFree cost milliseconds, an engine
+    // per call (the .Call boundary) would pay them every time
+    static constexpr size_t kPinnedSmall = (size_t)64 << 10;
+    static std::vector<void*>& pinned_small_pool() {
+        static std::vector<void*>* v = new std::vector<void*>();
+        return *v;
+    }
+    static std::mutex& pinned_small_mu() {
+        static std::mutex* m = new std::mutex();
+        return *m;
+    }
+    static void* pinned_small_take() {
+        {
+            std::lock_guard<std::mutex> lk(pinned_small_mu());
+            auto& v = pinned_small_pool();
+            if (!v.empty()) {
+                void* p = v.back();
+                v.pop_back();
+                return p;
+            }
+        }
+        void* p = nullptr;
+        BMX_HIP(hipHostMalloc(&p, kPinnedSmall, hipHostMallocDefault));
+        return p;
+    }
+    static void pinned_small_give(void* p) {
+        if (!p) return;
+        std::lock_guard<std::mutex> lk(pinned_small_mu());
+        pinned_small_pool().push_back(p);
     }
     int64_t* pin_ = nullptr;
     bool abandon = false;          // the stream is stuck (watchdog): nothing that would wait for the device may be called
@@ -287,7 +317,7 @@ struct KnnWorkspace {
     }
     ~KnnWorkspace() {
         if (abandon) return;
-        if (pin_) (void)hipHostFree(pin_);
+        pinned_small_give(pin_);
         for (auto& e : events) {
             (void)hipEventDestroy(e.first);
             (void)hipEventDestroy(e.second);

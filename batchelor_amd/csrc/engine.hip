@@ -99,7 +99,8 @@ Engine::~Engine() {
         DevBlockCache::current() = &cache_;
         return;
     }
-    if (scal_pin_) (void)hipHostFree(scal_pin_);
+    if (scal_pin_ && scal_pin_bytes_ > KnnWorkspace::kPinnedSmall) (void)hipHostFree(scal_pin_);
+    else KnnWorkspace::pinned_small_give(scal_pin_);
     if (comm_ && rccl::api().CommDestroy) {
         if (stream_) (void)hipStreamSynchronize(stream_);
         (void)rccl::api().CommDestroy(comm_);
@@ -765,11 +766,18 @@ void Engine::run(const bmx_params_t& p, const int32_t* tree, int tree_len) {
         }
         root_ = std::move(rem[0]);
     }
-    if (scal_pin_cap_ < scal_host_.size()) {
-        if (scal_pin_) (void)hipHostFree(scal_pin_);
+    const size_t scal_bytes = scal_host_.size() * sizeof(double);
+    if (scal_bytes > scal_pin_bytes_) {  // (more than ~60 batches: a block of its own instead of a pooled 64 KiB one)
+        if (scal_pin_ && scal_pin_bytes_ > KnnWorkspace::kPinnedSmall) (void)hipHostFree(scal_pin_);
+        else KnnWorkspace::pinned_small_give(scal_pin_);
         scal_pin_ = nullptr;
-        BMX_HIP(hipHostMalloc((void**)&scal_pin_, scal_host_.size() * sizeof(double), hipHostMallocDefault));
-        scal_pin_cap_ = scal_host_.size();
+        if (scal_bytes <= KnnWorkspace::kPinnedSmall) {
+            scal_pin_ = static_cast<double*>(KnnWorkspace::pinned_small_take());
+            scal_pin_bytes_ = KnnWorkspace::kPinnedSmall;
+        } else {
+            BMX_HIP(hipHostMalloc((void**)&scal_pin_, scal_bytes, hipHostMallocDefault));
+            scal_pin_bytes_ = scal_bytes;
+        }
     }
     BMX_HIP(hipMemcpyAsync(scal_pin_, scal_.p, scal_host_.size() * sizeof(double), hipMemcpyDeviceToHost, stream_));
     // (with var_adj the last merge's adjust_shift_variance is still running: its budget is n2 (nr1 + nr2) pair visits)

@@ -137,7 +137,7 @@ class Engine {
     double wd_base_s_ = 60.0;
     double run_tail_budget_s_ = 0.0;
     double* scal_pin_ = nullptr;  // pinned landing area of the end-of-run scalar read-back
-    size_t scal_pin_cap_ = 0;
+    size_t scal_pin_bytes_ = 0;
     bool dead_ = false;
 
     int device_ = 0;
