@@ -429,8 +429,8 @@ int32_t bmx_adjust_shift_variance(const double* data1, int32_t g1, int32_t n1, c
         const int32_t* q2 = upload(dr2, restrict2, (size_t)nr2, s);
         double* po = dO.reserve(n2);
         int asv_blocks = 1, asv_npad = 1, asv_exact = 1;
-        double* pw = dW.reserve(std::max<size_t>(1, bmx::adjust_shift_variance_scratch(n2, nr1, nr2, &asv_blocks, &asv_npad,
-                                                                                      &asv_exact)));
+        double* pw = dW.reserve(bmx::adjust_shift_variance_scratch(n2, nr1, nr2, &asv_blocks, &asv_npad, &asv_exact) +
+                                bmx::adjust_shift_variance_extra(g, n1, n2, 0));
         bmx::adjust_shift_variance_device(s, p1, g, n1, p2, n2, pv, sigma2, q1, nr1, q2, nr2, po, pw);
         BMX_HIP(hipMemcpyAsync(out, po, (size_t)n2 * sizeof(double), hipMemcpyDeviceToHost, s));
         BMX_HIP(hipStreamSynchronize(s));
@@ -667,7 +667,9 @@ int32_t bmx_fast_mnn(int32_t nbatches, int32_t d, const double* const* data, con
         auto h = std::make_unique<bmx_engine>();
         h->impl = std::make_unique<bmx::Engine>(dev);
         h->impl->knn_ws_.force_exact = g_force_exact;
-        h->impl->upload(nbatches, d, data, nrows, restrict_idx, n_restrict);
+        // the caller's matrices stay valid for the whole call: their upload is pulled by the run itself, batch by batch
+        // (the first two ahead of merge 1, the others while the GPU is busy searching)
+        h->impl->upload(nbatches, d, data, nrows, restrict_idx, n_restrict, /* lazy */ true);
         h->impl->run(p, tree, tree_len);
         h->impl->download(corrected, batch, merge_left, merge_right, batch_size, skipped, lost_var);
         if (out_engine) *out_engine = h.release();

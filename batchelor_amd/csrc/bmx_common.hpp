@@ -82,7 +82,7 @@ struct DevBlockCache {
         if (!leak) {
             std::lock_guard<std::mutex> lk(g.mu);
             for (const Block& b : blocks) {
-                if (g.blocks.size() < 96 && g.total + b.bytes <= ((size_t)16 << 30)) {
+                if (g.blocks.size() < 256 && g.total + b.bytes <= ((size_t)16 << 30)) {
                     g.blocks.push_back(b);
                     g.total += b.bytes;
                 } else {
@@ -129,7 +129,7 @@ struct DevBlockCache {
         if (leak) return;
         size_t total = bytes;
         for (const Block& x : blocks) total += x.bytes;
-        if (blocks.size() >= 48 || total > ((size_t)24 << 30)) {
+        if (blocks.size() >= 160 || total > ((size_t)24 << 30)) {
             (void)hipFree(p);
             return;
         }

@@ -51,6 +51,9 @@ struct ReduceWorkspace {
 // out[c] = scale * sum.  Deterministic two-stage reduction.
 void col_reduce(hipStream_t stream, ReduceWorkspace& ws, const double* X, const int32_t* rows, int r0, int r1, int d,
                 int mode, const double* centre, double scale, double* out);
+// out_sum[c] = scale * sum_r X[r][c], out_sq[c] = scale * sum_r X[r][c]^2 in one pass over X [n][d]
+void col_reduce2(hipStream_t stream, ReduceWorkspace& ws, const double* X, int n, int d, double scale, double* out_sum,
+                 double* out_sq);
 // Fused row pass over the segments (row ranges) of one node, in place on X [*][d]:
 //   * nvec > 0: centre along the batch vectors vec_pool[vec_ids[e]] in turn, x <- x - ((x - mu) . v^) v^  with mu [d]
 //     the column mean over the node's restrict rows BEFORE the pass (it is invariant under every step), i.e.
@@ -115,6 +118,8 @@ void smooth_gaussian_kernel_device(hipStream_t stream, const double* averaged, i
                                    const double* mat, int gd, int n, double sigma2, double* out, double* ws_density);
 // doubles of scratch adjust_shift_variance_device needs (and the launch shape it will use)
 size_t adjust_shift_variance_scratch(int n2, int nr1, int nr2, int* blocks, int* npad, int* exact);
+// doubles needed BEHIND that scratch (norms of the cells, a row-major copy of vect): reserve scratch + extra
+size_t adjust_shift_variance_extra(int g, int n1, int n2, int vect_row_major);
 void adjust_shift_variance_device(hipStream_t stream, const double* data1, int g, int n1, const double* data2, int n2,
                                   const double* vect, double sigma2, const int32_t* restrict1, int nr1,
                                   const int32_t* restrict2, int nr2, double* out, double* ws_pairs,

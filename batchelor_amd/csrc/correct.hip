@@ -56,6 +56,51 @@ __global__ __launch_bounds__(256) void col_reduce_final(const double* __restrict
     }
 }
 
+// column sums and column sums of squares of X [n][d] in one pass (overall.batch and the mean squares that
+// .get_batch_magnitude wants, R/fastMNN.R:481,588); same two-stage shape as col_reduce
+__global__ __launch_bounds__(256) void col_reduce2_partial(const double* __restrict__ X, int n, int d,
+                                                           double* __restrict__ partial) {
+    __shared__ double sm[4][2][64];
+    const int c0 = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int b0 = blockIdx.x * RED_ROWS;
+    const int b1 = min(n, b0 + RED_ROWS);
+    for (int cb = 0; cb < d; cb += 64) {
+        const int c = cb + c0;
+        double s = 0.0, q = 0.0;
+        if (c < d)
+            for (int r = b0 + rl; r < b1; r += 4) {
+                const double x = X[(int64_t)r * d + c];
+                s += x;
+                q += x * x;
+            }
+        sm[rl][0][c0] = s;
+        sm[rl][1][c0] = q;
+        __syncthreads();
+        if (rl == 0 && c < d) {
+            partial[(int64_t)blockIdx.x * 2 * d + c] = (sm[0][0][c0] + sm[1][0][c0]) + (sm[2][0][c0] + sm[3][0][c0]);
+            partial[(int64_t)blockIdx.x * 2 * d + d + c] = (sm[0][1][c0] + sm[1][1][c0]) + (sm[2][1][c0] + sm[3][1][c0]);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void col_reduce2_final(const double* __restrict__ partial, int nblocks, int d, double scale,
+                                                         double* __restrict__ out_sum, double* __restrict__ out_sq) {
+    __shared__ double sm[4][64];
+    const int c0 = threadIdx.x & 63, g = threadIdx.x >> 6;
+    for (int which = 0; which < 2; ++which)
+        for (int cb = 0; cb < d; cb += 64) {
+            const int c = cb + c0;
+            double s = 0.0;
+            if (c < d)
+                for (int b = g; b < nblocks; b += 4) s += partial[(int64_t)b * 2 * d + which * d + c];
+            sm[g][c0] = s;
+            __syncthreads();
+            if (g == 0 && c < d) (which ? out_sq : out_sum)[c] = ((sm[0][c0] + sm[1][c0]) + (sm[2][c0] + sm[3][c0])) * scale;
+            __syncthreads();
+        }
+}
+
 // ---- segments: the original batches of a node (row ranges), at most 16 per launch ------------------------------
 struct SegDesc {
     int start[16];
@@ -562,6 +607,16 @@ void col_reduce(hipStream_t stream, ReduceWorkspace& ws, const double* X, const 
     hipLaunchKernelGGL(col_reduce_partial, dim3(nb), dim3(256), 0, stream, X, rows, r0, r1, d, mode, centre, partial);
     BMX_LAUNCH_CHECK();
     hipLaunchKernelGGL(col_reduce_final, dim3(1), dim3(256), 0, stream, partial, nb, d, scale, out);
+    BMX_LAUNCH_CHECK();
+}
+
+void col_reduce2(hipStream_t stream, ReduceWorkspace& ws, const double* X, int n, int d, double scale, double* out_sum,
+                 double* out_sq) {
+    const int nb = std::max(1, cdiv(n, RED_ROWS));
+    double* partial = ws.partial.reserve((size_t)nb * 2 * d);
+    hipLaunchKernelGGL(col_reduce2_partial, dim3(nb), dim3(256), 0, stream, X, n, d, partial);
+    BMX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(col_reduce2_final, dim3(1), dim3(256), 0, stream, (const double*)partial, nb, d, scale, out_sum, out_sq);
     BMX_LAUNCH_CHECK();
 }
 

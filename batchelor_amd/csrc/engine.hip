@@ -77,12 +77,15 @@ void Engine::mark_dead() {
 }
 
 void Engine::wait(double work_s) {
+    // the deadline covers everything queued since the last wait that came back (queued_work_s_), e.g. the
+    // adjust_shift_variance of the previous merge in front of this merge's first search
     try {
-        guarded_stream_sync(stream_, wd_base_s_ > 0.0 ? wd_base_s_ + work_s : 0.0);
+        guarded_stream_sync(stream_, wd_base_s_ > 0.0 ? wd_base_s_ + queued_work_s_ + work_s : 0.0);
     } catch (const WatchdogTimeout&) {
         mark_dead();
         throw;
     }
+    queued_work_s_ = 0.0;
 }
 
 void Engine::debug_stall(int ms) {
@@ -104,6 +107,12 @@ Engine::~Engine() {
     if (comm_ && rccl::api().CommDestroy) {
         if (stream_) (void)hipStreamSynchronize(stream_);
         (void)rccl::api().CommDestroy(comm_);
+    }
+    for (hipEvent_t ev : up_ev_)
+        if (ev) (void)hipEventDestroy(ev);
+    if (copy_stream_) {
+        (void)hipStreamSynchronize(copy_stream_);
+        (void)hipStreamDestroy(copy_stream_);
     }
     if (stream_) {
         (void)hipStreamSynchronize(stream_);
@@ -175,8 +184,28 @@ void Engine::exchange(void* buf, int64_t bytes_per_rank) {
     if (rc != 0) throw Error(BMX_ERR_EXCHANGE, "the all-gather callback failed with code " + std::to_string(rc));
 }
 
+void Engine::ensure_uploaded(int b) {
+    if (uploaded_[b]) return;
+    const size_t bytes = (size_t)nrows_[b] * d_ * sizeof(double);
+    if (!copy_stream_) BMX_HIP(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+    if ((int)up_ev_.size() < B_) {
+        const size_t old = up_ev_.size();
+        up_ev_.resize(B_, nullptr);
+        for (size_t i = old; i < up_ev_.size(); ++i) BMX_HIP(hipEventCreateWithFlags(&up_ev_[i], hipEventDisableTiming));
+    }
+    upload_pageable(inputs_cm_[b].p, host_data_[b], bytes, copy_stream_);
+    BMX_HIP(hipEventRecord(up_ev_[b], copy_stream_));
+    uploaded_[b] = 1;
+}
+
+void Engine::prefetch_one() {
+    if (!lazy_) return;
+    while (need_pos_ < need_order_.size() && uploaded_[need_order_[need_pos_]]) ++need_pos_;
+    if (need_pos_ < need_order_.size()) ensure_uploaded(need_order_[need_pos_++]);
+}
+
 void Engine::upload(int nbatches, int d, const double* const* data, const int32_t* nrows,
-                    const int32_t* const* restrict_idx, const int32_t* n_restrict) {
+                    const int32_t* const* restrict_idx, const int32_t* n_restrict, bool lazy) {
     check_alive();
     CacheScope cache_scope(&cache_);
     BMX_HIP(hipSetDevice(device_));
@@ -193,12 +222,20 @@ void Engine::upload(int nbatches, int d, const double* const* data, const int32_
     inputs_restrict_.clear();
     inputs_restrict_.resize(nbatches);
     n_restrict_.assign(nbatches, -1);
+    lazy_ = lazy;
+    host_data_.assign(data, data + nbatches);
+    uploaded_.assign(nbatches, 0);
+    need_order_.clear();
+    need_pos_ = 0;
     for (int b = 0; b < nbatches; ++b) {
         if (nrows[b] < 1) throw Error(BMX_ERR_ARG, "every batch needs at least one cell");
         N_ += nrows[b];
         double* p = inputs_cm_[b].reserve((size_t)nrows[b] * d);
         // the caller's matrices are pageable (R-owned): through the pinned staging ring at link speed (host_xfer.hpp)
-        upload_pageable(p, data[b], (size_t)nrows[b] * d * sizeof(double), stream_);
+        if (!lazy) {
+            upload_pageable(p, data[b], (size_t)nrows[b] * d * sizeof(double), stream_);
+            uploaded_[b] = 1;
+        }
         const bool has = restrict_idx && restrict_idx[b] && n_restrict && n_restrict[b] >= 0;
         if (has) {
             const int m = n_restrict[b];
@@ -222,6 +259,7 @@ void Engine::upload(int nbatches, int d, const double* const* data, const int32_
     }
     if (N_ > std::numeric_limits<int32_t>::max() / 2) throw Error(BMX_ERR_ARG, "too many cells for int32 indices");
     BMX_HIP(hipStreamSynchronize(stream_));
+    if (!lazy) host_data_.clear();  // the caller's matrices are free again
 }
 
 void Engine::knn(const double* X, const int32_t* ref_rows, int nr, const double* Q, const int32_t* q_rows, int nq,
@@ -231,7 +269,8 @@ void Engine::knn(const double* X, const int32_t* ref_rows, int nr, const double*
     bmx_shard_range_impl(nq, rank_, world_, &b, &e);
     // watchdog budget of this search's waits: ~1e4 times what the candidate pass takes per pair evaluation (1.5e-13 s),
     // and enough for a search that falls through to the FP64 scan (1e-10 s per pair and dimension)
-    knn_ws_.wd_budget_s = wd_base_s_ > 0.0 ? wd_base_s_ + 2e-10 * (double)nq * (double)nr * (double)d_ / 50.0 : 0.0;
+    queued_work_s_ += 2e-10 * (double)nq * (double)nr * (double)d_ / 50.0;
+    knn_ws_.wd_budget_s = wd_base_s_ > 0.0 ? wd_base_s_ + queued_work_s_ : 0.0;
     try {
         knn_device(stream_, knn_ws_, X, ref_rows, nr, Q, q_rows, nq, d_, k, idx, dist, (int)b, (int)e, seed_d2, centre);
     } catch (const WatchdogTimeout&) {  // (the search's own waits go through knn_ws_.sync, not through wait())
@@ -273,7 +312,8 @@ Engine::MnnOut Engine::find_mnn(const Node& left, const Node& right, int k, doub
     select_listed_rows(stream_, scan_ws_, idxRL, (int64_t)nR * o.k1, nL, flagL, offSel, lsel);
     int32_t* pin = reinterpret_cast<int32_t*>(knn_ws_.pinned_words() + 1);  // (pinned: see KnnWorkspace::pinned_words)
     BMX_HIP(hipMemcpyAsync(pin, offSel + nL, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
-    wait(knn_ws_.wd_budget_s);
+    prefetch_one();  // (lazy upload: the host has nothing to do until the search is through -- move the next batch)
+    wait();
     const int32_t nsel = pin[0];
     o.nsel = nsel;
     if (std::getenv("BMX_DEBUG")) fprintf(stderr, "[bmx] find_mnn: %d of %d left cells are in some right cell's list\n", nsel, nL);
@@ -304,7 +344,8 @@ Engine::MnnOut Engine::find_mnn(const Node& left, const Node& right, int k, doub
     compact_mnn_cells(stream_, scan_ws_, cntR, nR, flagR, offR, second_u);
     BMX_HIP(hipMemcpyAsync(&pin[2], offL + nsel, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
     BMX_HIP(hipMemcpyAsync(&pin[3], offR + nR, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
-    wait(knn_ws_.wd_budget_s);
+    prefetch_one();
+    wait();
     o.P = pin[2];
     o.U = pin[3];
     return o;
@@ -478,17 +519,19 @@ void Engine::merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p,
                        mo.k1, averaged);
     const int vid = n_extras_;  // slot of this merge's overall.batch in the pool
     double* overall = vecs_.p + (size_t)vid * d_;
-    col_reduce(stream_, red_ws_, averaged, nullptr, 0, mo.U, d_, 0, nullptr, 1.0 / (double)mo.U, overall);
+    double* msq = vecs_.p + (size_t)(2 * B_ + 4) * d_;
+    rec.batch_size_na = std::isnan(p.min_batch_skip);
+    if (rec.batch_size_na)
+        col_reduce(stream_, red_ws_, averaged, nullptr, 0, mo.U, d_, 0, nullptr, 1.0 / (double)mo.U, overall);
+    else  // the mean squares .get_batch_magnitude wants come out of the same pass
+        col_reduce2(stream_, red_ws_, averaged, mo.U, d_, 1.0 / (double)mo.U, overall, msq);
 
     bool do_correct = true;
-    rec.batch_size_na = std::isnan(p.min_batch_skip);
     rec.skipped = false;
     rec.bs_slot = -1;
     if (!rec.batch_size_na) {
         // .get_batch_magnitude (R/fastMNN.R:582-595) on the device; the host only looks at it here when a merge can
         // actually be skipped (min.batch.skip > 0), otherwise with everything else at the end of the run
-        double* msq = vecs_.p + (size_t)(2 * B_ + 4) * d_;
-        col_reduce(stream_, red_ws_, averaged, nullptr, 0, mo.U, d_, 1, nullptr, 1.0 / (double)mo.U, msq);
         if (n_slots_ + 1 > slot_cap_) throw Error(BMX_ERR_ARG, "internal: statistics slots exhausted");
         rec.bs_slot = n_slots_++;
         batch_magnitude(stream_, overall, msq, d_, scal_.p + rec.bs_slot);
@@ -547,12 +590,12 @@ void Engine::merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p,
             }
             BMX_LAUNCH_CHECK();
             int blocks = 1, npad = 1, exact = 1;
-            double* ws = asv_ws_.reserve(std::max<size_t>(1, adjust_shift_variance_scratch(right.n, nLs, nRs, &blocks, &npad,
-                                                                                           &exact)));
+            double* ws = asv_ws_.reserve(adjust_shift_variance_scratch(right.n, nLs, nRs, &blocks, &npad, &exact) +
+                                         adjust_shift_variance_extra(d_, left.n, right.n, 1));
             double* scaling = asv_scale_.reserve(right.n);
             adjust_shift_variance_device(stream_, left.data.p, d_, left.n, right.data.p, right.n, corr, p.sigma, r1, nLs, r2,
                                          nRs, scaling, ws, /* vect_row_major */ 1);
-            run_tail_budget_s_ += 1e-6 * (double)right.n * ((double)nLs + (double)nRs);
+            queued_work_s_ += 5e-8 * (double)right.n * ((double)nLs + (double)nRs);
             add_scaled_rows(stream_, right.data.p, right.n, d_, corr, scaling);
         }
         right.stat_slot.assign(right.origin.size(), -1);  // the corrected cells moved
@@ -614,7 +657,7 @@ void Engine::run(const bmx_params_t& p, const int32_t* tree, int tree_len) {
     check_alive();
     if (B_ < 2) throw Error(BMX_ERR_ARG, "at least two batches must be specified");
     if (p.k < 1) throw Error(BMX_ERR_ARG, "'k' must be positive");
-    run_tail_budget_s_ = 0.0;
+    queued_work_s_ = 0.0;
     const int nmerges = B_ - 1;
     root_.reset();  // a run that fails half-way leaves nothing to download
     merges_.clear();
@@ -641,18 +684,23 @@ void Engine::run(const bmx_params_t& p, const int32_t* tree, int tree_len) {
     double* arena = nullptr;
     int64_t arena_rows = 0;
     if (!p.auto_merge) arena = arena_.reserve((size_t)N_ * d_);
-    auto make_leaf = [&](int b) {
+    auto make_leaf = [&](int b, int64_t arena_row) {
         auto n = std::make_unique<Node>();
         n->index = {b + 1};
         n->n = nrows_[b];
         n->origin = {Segment{b + 1, nrows_[b]}};
         double* dp;
         if (arena) {
-            n->data.alias(arena + (size_t)arena_rows * d_, (size_t)n->n * d_);
+            n->data.alias(arena + (size_t)arena_row * d_, (size_t)n->n * d_);
             dp = n->data.p;
-            arena_rows += n->n;
         } else {
             dp = n->data.reserve((size_t)n->n * d_);
+        }
+        if (lazy_) {  // the batch may still be on its way: the transpose queues behind its copy
+            if ((size_t)b >= host_data_.size() && !uploaded_[b])
+                throw Error(BMX_ERR_ARG, "internal: a lazily uploaded batch has lost its host matrix");
+            ensure_uploaded(b);
+            BMX_HIP(hipStreamWaitEvent(stream_, up_ev_[b], 0));
         }
         transpose_cm_to_rm(stream_, inputs_cm_[b].p, n->n, d_, dp);
         if (n_restrict_[b] >= 0) {
@@ -683,8 +731,10 @@ void Engine::run(const bmx_params_t& p, const int32_t* tree, int tree_len) {
             } else {
                 if (v < 1 || v > B_ || seen[v]) throw Error(BMX_ERR_TREE, "invalid leaf nodes specified in 'merge.order'");
                 seen[v] = 1;
-                TreeSlot s;
-                s.node = make_leaf(v - 1);
+                TreeSlot s;  // materialised when its merge comes up (a lazily uploaded batch arrives in the meantime)
+                s.batch = v - 1;
+                s.arena_row = arena_rows;
+                arena_rows += nrows_[v - 1];
                 slots.push_back(std::move(s));
                 stack.push_back((int)slots.size() - 1);
             }
@@ -693,28 +743,53 @@ void Engine::run(const bmx_params_t& p, const int32_t* tree, int tree_len) {
         for (int b = 1; b <= B_; ++b) nleaves += seen[b];
         if (stack.size() != 1 || nleaves != B_) throw Error(BMX_ERR_TREE, "invalid leaf nodes specified in 'merge.order'");
         const int root = stack.back();
-        for (int mdx = 0; mdx < nmerges; ++mdx) {
-            // .get_next_merge (R/MNN_tree.R:61-69): both children leaves -> merge; else descend into child 2 if it
-            // is still a list, otherwise into child 1
+        // .get_next_merge (R/MNN_tree.R:61-69): both children finished -> merge; else descend into child 2 if it is still
+        // a list, otherwise into child 1
+        auto next_merge = [&](const std::vector<char>& done) {
             int cur = root;
             for (;;) {
-                TreeSlot& s = slots[cur];
-                const bool l_leaf = (bool)slots[s.left].node, r_leaf = (bool)slots[s.right].node;
-                if (l_leaf && r_leaf) break;
+                const TreeSlot& s = slots[cur];
+                const bool l_leaf = done[s.left], r_leaf = done[s.right];
+                if (l_leaf && r_leaf) return cur;
                 cur = !r_leaf ? s.right : s.left;
             }
+        };
+        std::vector<char> done(slots.size(), 0);
+        for (size_t i = 0; i < slots.size(); ++i) done[i] = slots[i].ready();
+        if (lazy_) {  // the order in which the merges will ask for the batches: what to prefetch next
+            std::vector<char> sim = done;
+            need_order_.clear();
+            need_pos_ = 0;
+            for (int mdx = 0; mdx < nmerges; ++mdx) {
+                const int cur = next_merge(sim);
+                for (int child : {slots[cur].left, slots[cur].right})
+                    if (slots[child].batch >= 0) need_order_.push_back(slots[child].batch);
+                sim[cur] = 1;
+            }
+        }
+        auto materialise = [&](TreeSlot& t) {
+            if (!t.node) {
+                t.node = make_leaf(t.batch, t.arena_row);
+                t.batch = -1;
+            }
+        };
+        for (int mdx = 0; mdx < nmerges; ++mdx) {
+            const int cur = next_merge(done);
             TreeSlot& s = slots[cur];
+            materialise(slots[s.left]);
+            materialise(slots[s.right]);
             std::unique_ptr<Node> merged;
             merge_step(mdx, *slots[s.left].node, *slots[s.right].node, p, merged);
             slots[s.left].node.reset();
             slots[s.right].node.reset();
             s.node = std::move(merged);  // .update_tree (R/MNN_tree.R:71-77)
+            done[cur] = 1;
         }
         root_ = std::move(slots[root].node);
     } else {
         // auto-merge (R/MNN_tree.R:154-226)
         std::vector<std::unique_ptr<Node>> rem;
-        for (int b = 0; b < B_; ++b) rem.push_back(make_leaf(b));
+        for (int b = 0; b < B_; ++b) rem.push_back(make_leaf(b, 0));
         std::vector<std::vector<int64_t>> stats(B_, std::vector<int64_t>(B_, 0));
         for (int i = 0; i < B_; ++i)
             for (int j = 0; j < i; ++j) stats[i][j] = count_mnn_pairs(*rem[i], *rem[j], p);
@@ -781,8 +856,14 @@ void Engine::run(const bmx_params_t& p, const int32_t* tree, int tree_len) {
     }
     BMX_HIP(hipMemcpyAsync(scal_pin_, scal_.p, scal_host_.size() * sizeof(double), hipMemcpyDeviceToHost, stream_));
     // (with var_adj the last merge's adjust_shift_variance is still running: its budget is n2 (nr1 + nr2) pair visits)
-    wait(run_tail_budget_s_);
+    wait();
     std::memcpy(scal_host_.data(), scal_pin_, scal_host_.size() * sizeof(double));
+    if (lazy_) {  // every batch is resident now: later runs need nothing from the caller
+        for (int b = 0; b < B_; ++b) ensure_uploaded(b);
+        BMX_HIP(hipStreamSynchronize(copy_stream_));
+        host_data_.clear();
+        lazy_ = false;
+    }
     fallbacks_ = knn_ws_.exact_total;
 }
 

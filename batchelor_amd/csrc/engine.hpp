@@ -28,7 +28,10 @@ struct Node {
 
 struct TreeSlot {
     int left = -1, right = -1;  // children (indices into the slot vector), -1 for a leaf
-    std::unique_ptr<Node> node; // set for leaves (original batches or finished merges)
+    std::unique_ptr<Node> node; // set for finished nodes (materialised leaves or finished merges)
+    int batch = -1;             // a leaf that has not been materialised yet: its batch (0-based) ...
+    int64_t arena_row = 0;      // ... and its first row in the run's arena
+    bool ready() const { return (bool)node || batch >= 0; }
 };
 
 struct MergeRecord {
@@ -57,8 +60,11 @@ class Engine {
     // exchange statistics since the last run() started
     int64_t exchange_calls() const { return xchg_calls_; }
     int64_t exchange_bytes() const { return xchg_bytes_; }
+    // lazy: the matrices are NOT copied here -- the caller keeps them valid until the next run() has returned, which
+    // pulls each batch through the pinned staging ring on a copy stream when its leaf comes up and prefetches the next
+    // ones while the GPU is busy with a search (the one-shot bmx_fast_mnn: upload hidden behind the first merges)
     void upload(int nbatches, int d, const double* const* data, const int32_t* nrows,
-                const int32_t* const* restrict_idx, const int32_t* n_restrict);
+                const int32_t* const* restrict_idx, const int32_t* n_restrict, bool lazy = false);
     void run(const bmx_params_t& p, const int32_t* tree, int tree_len);
     void download(double* corrected, int32_t* batch, int32_t* merge_left, int32_t* merge_right, double* batch_size,
                   int32_t* skipped, double* lost_var);
@@ -132,10 +138,19 @@ class Engine {
     void exchange(void* buf, int64_t bytes_per_rank);
 
     void wait(double work_s = 0.0);  // guarded wait on the engine's stream: deadline wd_base_s_ + work_s
+    void ensure_uploaded(int b);   // batch b's copy is queued (lazy uploads: on the copy stream, with an event)
+    void prefetch_one();           // queue the next batch the merge order will need, if any is still on the host
+    std::vector<const double*> host_data_;  // lazy upload: the caller's matrices (valid until run() returns)
+    std::vector<char> uploaded_;
+    std::vector<hipEvent_t> up_ev_;
+    hipStream_t copy_stream_ = nullptr;
+    std::vector<int> need_order_;
+    size_t need_pos_ = 0;
+    bool lazy_ = false;
     void check_alive() const;
     void mark_dead();
     double wd_base_s_ = 60.0;
-    double run_tail_budget_s_ = 0.0;
+    double queued_work_s_ = 0.0;  // watchdog allowance of what was queued since the last wait that came back
     double* scal_pin_ = nullptr;  // pinned landing area of the end-of-run scalar read-back
     size_t scal_pin_bytes_ = 0;
     bool dead_ = false;

@@ -508,6 +508,353 @@ __global__ __launch_bounds__(T) void asv_exact_kernel(const double* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// adjust_shift_variance at scale (BASELINE.json configs[4]: every right cell of a merge against every restricted cell of
+// both batches -- 5e11 pairs at the root of the 16-batch tree).  A workgroup owns a TILE OF 16 CELLS:
+//   1. the restricted cells of both batches stream past it once, 64 at a time through the LDS; two FP64 MFMA blocks
+//      (v_mfma_f64_16x16x4_f64) per 16 x 16 sub-tile give  D = x_c . x_o  and  P = g^_c . x_o, from which the projection
+//      on the cell's line (P) and the squared distance to it  |x_c|^2 + |x_o|^2 - 2 D - (g^_c . x_c - P)^2  follow per
+//      pair (src/adjust_shift_variance.cpp:9-27 in GEMM form); projection and log-weight go to the tile's scratch rows,
+//      the per-cell maxima / projection range come out of the same pass;
+//   2. cell by cell: the own-batch probability (log-sum-exp, :74-112) and the weighted quantile of the reference batch's
+//      projections (:117-157) WITHOUT sorting them: linear histogram of the weights over the projection range (2 048
+//      bins, integer fixed-point sums: order-independent, so runs are bit-identical), the bin where the cumulative weight
+//      crosses the target is collected, sorted and walked; a bin that is still too full is subdivided again.
+// Weights are taken relative to the cell's largest one and kept to 2^-40: a reference cell 28 sigma2 further from the line
+// than the nearest contributes nothing, as in FP64 it would not either beyond 37.  Cells whose walk is decided on the last
+// bits may pick the neighbouring quantile (as with asv_kernel; asv_exact_kernel is the bit-exact form up to 131 072 cells).
+// ---------------------------------------------------------------------------------------------------
+constexpr int AT_C = 16;        // cells per tile
+constexpr int AT_R = 64;        // streamed cells per step
+constexpr int AT_KC = 32;       // dimensions staged per step
+constexpr int AT_NB = 2048;     // histogram bins
+constexpr int AT_CAP = 2048;    // collected entries of the crossing bin
+
+__host__ __device__ inline int asv_tile_gp(int g) { return (g + AT_KC - 1) / AT_KC * AT_KC + 2; }
+inline size_t asv_tile_lds_bytes(int g) {
+    return ((size_t)2 * AT_C * asv_tile_gp(g) + (size_t)AT_R * (AT_KC + 2) + 8 * AT_C + T) * sizeof(double) +
+           (size_t)AT_NB * sizeof(unsigned long long) + (size_t)AT_CAP * 16;
+}
+
+__global__ __launch_bounds__(T) void asv_tile_kernel(const double* __restrict__ data1, int g, const double* __restrict__ data2,
+                                                     int n2, const double* __restrict__ vect, double sigma2,
+                                                     const int32_t* __restrict__ r1, int nr1, const int32_t* __restrict__ r2,
+                                                     int nr2, const double* __restrict__ nrm1, const double* __restrict__ nrm2,
+                                                     double* __restrict__ out, double* __restrict__ scratch) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int GP = asv_tile_gp(g);
+    double* cx = reinterpret_cast<double*>(smem_raw);  // [16][GP] the tile's cells
+    double* cg = cx + AT_C * GP;                        // [16][GP] their unit gradients
+    double* rs = cg + AT_C * GP;                        // [64][KC + 2] a step of streamed cells
+    double* sc_proj = rs + AT_R * (AT_KC + 2);          // per cell: own projection, |x|^2, |vect|, maxima, projection range
+    double* sc_n = sc_proj + AT_C;
+    double* sc_l2 = sc_n + AT_C;
+    double* sc_mx1 = sc_l2 + AT_C;
+    double* sc_mx2 = sc_mx1 + AT_C;
+    double* sc_lo = sc_mx2 + AT_C;
+    double* sc_hi = sc_lo + AT_C;
+    double* sc_tmp = sc_hi + AT_C;
+    double* sm = sc_tmp + AT_C;                         // [T] block reductions
+    unsigned long long* hist = reinterpret_cast<unsigned long long*>(sm + T);  // [NB]
+    double* lp = reinterpret_cast<double*>(hist + AT_NB);                       // [CAP] collected projections
+    unsigned long long* lw_ = reinterpret_cast<unsigned long long*>(lp + AT_CAP);  // [CAP] and their weights
+    __shared__ int sh_cnt, sh_bin;
+    __shared__ unsigned long long sh_before;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t N = (int64_t)nr1 + nr2;  // streamed cells: the own batch's restricted cells first, then the reference's
+    double* SP = scratch + (int64_t)blockIdx.x * 2 * AT_C * N;  // [16][N] projections
+    double* SW = SP + (int64_t)AT_C * N;                         // [16][N] log-weights
+    const int ntiles = (n2 + AT_C - 1) / AT_C;
+    const double NEG = -__builtin_inf(), POS = __builtin_inf();
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int c0 = tile * AT_C;
+        // ---- the tile's cells: coordinates, unit gradient (:57-70), own projection
+        for (int e = tid; e < AT_C * GP; e += T) {
+            const int c = e / GP, x = e - c * GP;
+            const bool in = c0 + c < n2 && x < g;
+            cx[e] = in ? data2[(int64_t)(c0 + c) * g + x] : 0.0;
+            cg[e] = in ? vect[(int64_t)(c0 + c) * g + x] : 0.0;
+        }
+        __syncthreads();
+        if (tid < AT_C) {
+            double l2 = 0.0, nn = 0.0;
+            for (int x = 0; x < g; ++x) l2 += cg[tid * GP + x] * cg[tid * GP + x];
+            l2 = sqrt(l2);
+            if (l2 != 0.0)
+                for (int x = 0; x < g; ++x) cg[tid * GP + x] /= l2;
+            double p = 0.0;
+            for (int x = 0; x < g; ++x) {
+                p += cg[tid * GP + x] * cx[tid * GP + x];
+                nn += cx[tid * GP + x] * cx[tid * GP + x];
+            }
+            sc_l2[tid] = l2;
+            sc_proj[tid] = p;
+            sc_n[tid] = nn;
+        }
+        __syncthreads();
+        // ---- pass over the streamed cells: projections and log-weights of every (cell, streamed cell) pair
+        double mx1[4], mx2[4], lo[4], hi[4], cp[4], cn[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            mx1[i] = mx2[i] = NEG;
+            lo[i] = POS;
+            hi[i] = NEG;
+            cp[i] = sc_proj[(lane >> 4) + 4 * i];
+            cn[i] = sc_n[(lane >> 4) + 4 * i];
+        }
+        const int lr = tid >> 2, seg = (tid & 3) * 8;  // staging: 64 rows x 4 segments of 8 doubles
+        for (int64_t j0 = 0; j0 < N; j0 += AT_R) {
+            const int64_t jr = j0 + lr;
+            const double* src = nullptr;
+            if (jr < N) src = jr < nr2 ? data2 + (int64_t)r2[jr] * g : data1 + (int64_t)r1[jr - nr2] * g;
+            d4 D = d4{0.0, 0.0, 0.0, 0.0}, P = d4{0.0, 0.0, 0.0, 0.0};
+            for (int k0 = 0; k0 < g; k0 += AT_KC) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int k = k0 + seg + e;
+                    rs[lr * (AT_KC + 2) + seg + e] = (src && k < g) ? src[k] : 0.0;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int kk = 0; kk < AT_KC / 4; ++kk) {
+                    const double b = rs[(16 * w + (lane & 15)) * (AT_KC + 2) + 4 * kk + (lane >> 4)];
+                    const double ax = cx[(lane & 15) * GP + k0 + 4 * kk + (lane >> 4)];
+                    const double ag = cg[(lane & 15) * GP + k0 + 4 * kk + (lane >> 4)];
+                    D = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, b, D, 0, 0, 0);
+                    P = __builtin_amdgcn_mfma_f64_16x16x4f64(ag, b, P, 0, 0, 0);
+                }
+                __syncthreads();
+            }
+            // this lane: streamed cell jo, tile cells (lane >> 4) + 4 i
+            const int64_t jo = j0 + 16 * w + (lane & 15);
+            if (jo < N) {
+                const bool own = jo < nr2;
+                const int rid = own ? r2[jo] : r1[jo - nr2];
+                const double no = own ? nrm2[rid] : nrm1[rid];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = (lane >> 4) + 4 * i;
+                    double pr = P[i];
+                    const double s_ = cp[i] - pr;
+                    double d2 = (cn[i] + no) - 2.0 * D[i] - s_ * s_;
+                    d2 = d2 > 0.0 ? d2 : 0.0;
+                    double lw = -d2 / sigma2;
+                    if (own) {
+                        if (rid == c0 + c) {  // the cell itself: log-weight 0, always counted (:80-84)
+                            lw = 0.0;
+                            pr = NEG;
+                        }
+                        mx2[i] = fmax(mx2[i], lw);
+                    } else {
+                        mx1[i] = fmax(mx1[i], lw);
+                        lo[i] = fmin(lo[i], pr);
+                        hi[i] = fmax(hi[i], pr);
+                    }
+                    SP[(int64_t)c * N + jo] = pr;
+                    SW[(int64_t)c * N + jo] = lw;
+                }
+            }
+        }
+        // per-cell maxima and projection range: over the 16 lanes of a row group, then over the waves
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            for (int o = 1; o < 16; o <<= 1) {
+                mx1[i] = fmax(mx1[i], __shfl_xor(mx1[i], o));
+                mx2[i] = fmax(mx2[i], __shfl_xor(mx2[i], o));
+                lo[i] = fmin(lo[i], __shfl_xor(lo[i], o));
+                hi[i] = fmax(hi[i], __shfl_xor(hi[i], o));
+            }
+        }
+        __syncthreads();
+        if ((lane & 15) == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = (lane >> 4) + 4 * i;
+                sm[(w * AT_C + c) * 4 + 0] = mx1[i];
+                sm[(w * AT_C + c) * 4 + 1] = mx2[i];
+                sm[(w * AT_C + c) * 4 + 2] = lo[i];
+                sm[(w * AT_C + c) * 4 + 3] = hi[i];
+            }
+        }
+        __syncthreads();
+        if (tid < AT_C) {
+            double a = NEG, b = NEG, l = POS, h = NEG;
+            for (int ww = 0; ww < 4; ++ww) {
+                a = fmax(a, sm[(ww * AT_C + tid) * 4 + 0]);
+                b = fmax(b, sm[(ww * AT_C + tid) * 4 + 1]);
+                l = fmin(l, sm[(ww * AT_C + tid) * 4 + 2]);
+                h = fmax(h, sm[(ww * AT_C + tid) * 4 + 3]);
+            }
+            sc_mx1[tid] = a;
+            sc_mx2[tid] = b;
+            sc_lo[tid] = l;
+            sc_hi[tid] = h;
+        }
+        __threadfence_block();
+        __syncthreads();
+        // (the scratch rows were written by this block and are read by it: same CU, through the L2)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+        // ---- cell by cell: own-batch probability, then the weighted quantile of the reference projections
+        for (int c = 0; c < AT_C && c0 + c < n2; ++c) {
+            const double* p2 = SP + (int64_t)c * N;
+            const double* w2 = SW + (int64_t)c * N;
+            const double curproj = sc_proj[c], l2 = sc_l2[c];
+            double prob2 = 0.0;
+            if (nr2 > 0) {
+                const double mx = sc_mx2[c];
+                double below = 0.0, all = 0.0;
+                for (int s = tid; s < nr2; s += T) {
+                    const double ww = exp(w2[s] - mx);
+                    all += ww;
+                    if (!(p2[s] > curproj)) below += ww;
+                }
+                below = block_sum(below, sm);
+                all = block_sum(all, sm);
+                prob2 = (below > 0.0 ? mx + log(below) : 0.0) - (mx + log(all));
+            }
+            double ref_quan = __builtin_nan("");
+            if (nr1 > 0) {
+                const double* p1 = p2 + nr2;
+                const double* w1 = w2 + nr2;
+                const double mx = sc_mx1[c];
+                const double FIX = 1099511627776.0;  // 2^40
+                double blo = sc_lo[c], bhi = sc_hi[c];  // projections still in play: [blo, bhi]
+                unsigned long long before = 0;          // weight of the projections below blo
+                double target = -1.0;                   // in fixed-point units, known after the first histogram
+                ref_quan = sc_hi[c];                    // default: the last one (:141)
+                for (int round = 0; round < 40; ++round) {
+                    for (int b = tid; b < AT_NB; b += T) hist[b] = 0ull;
+                    if (tid == 0) sh_cnt = 0;
+                    __syncthreads();
+                    const double scale = bhi > blo ? (double)AT_NB / (bhi - blo) : 0.0;
+                    for (int o = tid; o < nr1; o += T) {
+                        const double pr = p1[o];
+                        if (pr < blo || pr > bhi) continue;
+                        int b = (int)((pr - blo) * scale);
+                        b = b < 0 ? 0 : (b > AT_NB - 1 ? AT_NB - 1 : b);
+                        atomicAdd(&hist[b], (unsigned long long)(exp(w1[o] - mx) * FIX));
+                    }
+                    __syncthreads();
+                    if (tid == 0) {
+                        if (round == 0) {
+                            unsigned long long tot = 0;
+                            for (int b = 0; b < AT_NB; ++b) tot += hist[b];
+                            sc_tmp[0] = exp(prob2) * (double)tot;  // the target (:137), fixed-point units
+                        }
+                        const double tg = sc_tmp[0];
+                        unsigned long long cum = before;
+                        int at = -1;
+                        for (int b = 0; b < AT_NB; ++b) {
+                            if ((double)(cum + hist[b]) >= tg) {
+                                at = b;
+                                break;
+                            }
+                            cum += hist[b];
+                        }
+                        sh_bin = at;
+                        sh_before = cum;
+                    }
+                    __syncthreads();
+                    target = sc_tmp[0];
+                    const int at = sh_bin;
+                    if (at < 0) {  // no prefix reaches the target: the last projection (:141)
+                        ref_quan = sc_hi[c];
+                        break;
+                    }
+                    before = sh_before;
+                    // the projections that fall into bin `at`
+                    for (int o = tid; o < nr1; o += T) {
+                        const double pr = p1[o];
+                        if (pr < blo || pr > bhi) continue;
+                        int b = (int)((pr - blo) * scale);
+                        b = b < 0 ? 0 : (b > AT_NB - 1 ? AT_NB - 1 : b);
+                        if (b != at) continue;
+                        const int pos = atomicAdd(&sh_cnt, 1);
+                        if (pos < AT_CAP) {
+                            lp[pos] = pr;
+                            lw_[pos] = (unsigned long long)(exp(w1[o] - mx) * FIX);
+                        }
+                    }
+                    __syncthreads();
+                    const int cnt = sh_cnt;
+                    if (cnt <= AT_CAP || !(bhi > blo)) {
+                        const int m = cnt < AT_CAP ? cnt : AT_CAP;
+                        int npad = 1;
+                        while (npad < m) npad <<= 1;
+                        for (int i = m + tid; i < npad; i += T) {
+                            lp[i] = POS;
+                            lw_[i] = 0ull;
+                        }
+                        __syncthreads();
+                        for (int k = 2; k <= npad; k <<= 1)
+                            for (int j = k >> 1; j > 0; j >>= 1) {
+                                for (int i = tid; i < npad; i += T) {
+                                    const int ixj = i ^ j;
+                                    if (ixj > i) {
+                                        const double a = lp[i], b2 = lp[ixj];
+                                        const unsigned long long wa = lw_[i], wb = lw_[ixj];
+                                        const bool up = (i & k) == 0;
+                                        // (projection, weight) ascending: equal projections in a fixed order
+                                        const bool gt = a > b2 || (a == b2 && wa > wb);
+                                        const bool lt = a < b2 || (a == b2 && wa < wb);
+                                        if (up ? gt : lt) {
+                                            lp[i] = b2;
+                                            lp[ixj] = a;
+                                            lw_[i] = wb;
+                                            lw_[ixj] = wa;
+                                        }
+                                    }
+                                }
+                                __syncthreads();
+                            }
+                        if (tid == 0) {
+                            unsigned long long cum = before;
+                            double q = m > 0 ? lp[m - 1] : bhi;
+                            for (int i = 0; i < m; ++i) {
+                                cum += lw_[i];
+                                if ((double)cum >= target) {
+                                    q = lp[i];
+                                    break;
+                                }
+                            }
+                            sc_tmp[1] = q;
+                        }
+                        __syncthreads();
+                        ref_quan = sc_tmp[1];
+                        break;
+                    }
+                    // still too many in one bin: its range becomes the whole histogram
+                    const double nlo = blo + (double)at / scale, nhi = blo + (double)(at + 1) / scale;
+                    // (rounding of the bin edges: widen by an ulp-ish margin and keep inside the old range; entries that
+                    // fall outside the bin but inside the widened range are binned again, which is harmless -- except that
+                    // the weight below the range must then not contain them: recompute `before` as the weight below nlo)
+                    const double margin = 4e-16 * fmax(fabs(blo), fabs(bhi));
+                    blo = fmax(blo, nlo - margin);
+                    bhi = fmin(bhi, nhi + margin);
+                    ref_quan = bhi;  // (provisional: the quantile lies in [blo, bhi]; final unless another round refines it)
+                    unsigned long long mine = 0;
+                    for (int o = tid; o < nr1; o += T)
+                        if (p1[o] < blo) mine += (unsigned long long)(exp(w1[o] - mx) * FIX);
+                    // integer sums: any order gives the same total
+                    __syncthreads();
+                    unsigned long long* smu = reinterpret_cast<unsigned long long*>(sm);
+                    smu[tid] = mine;
+                    __syncthreads();
+                    for (int o2 = T / 2; o2 > 0; o2 >>= 1) {
+                        if (tid < o2) smu[tid] += smu[tid + o2];
+                        __syncthreads();
+                    }
+                    before = smu[0];
+                    __syncthreads();
+                }
+            }
+            if (tid == 0) out[c0 + c] = (ref_quan - curproj) / l2;  // :160
+            __syncthreads();
+        }
+    }
+}
+
 }  // namespace
 
 // ws: n + U doubles (squared norms of every cell over the distance genes, densities of the MNN cells)
@@ -530,16 +877,41 @@ void smooth_gaussian_kernel_device(hipStream_t stream, const double* averaged, i
     BMX_LAUNCH_CHECK();
 }
 
+// Which form runs and what it needs.  exact = 1: asv_exact_kernel (bit-exact walk, up to 131 072 restricted cells);
+// exact = 0: the tiled FP64-MFMA form, `blocks` workgroups with 2 x 16 x (nr1 + nr2) doubles of scratch each, behind them
+// the squared norms of both batches' cells and (vect handed over column-major) a row-major copy of vect.
+// BMX_ASV_FAST=1 forces the tiled form (tests), BMX_ASV_BISECT=1 selects round 2's scalable form (asv_kernel).
 size_t adjust_shift_variance_scratch(int n2, int nr1, int nr2, int* blocks, int* npad, int* exact) {
     static const int force_fast = std::getenv("BMX_ASV_FAST") != nullptr;  // developer switch
     *exact = !force_fast && (int64_t)nr1 + nr2 <= 131072;
     int p = 1;
     while (p < std::max(nr1, 1)) p <<= 1;
     *npad = p;
-    const size_t per_block = *exact ? 2 * (size_t)nr2 + 2 * (size_t)p : 2 * (size_t)std::max(nr1, 1);
-    const size_t budget = (size_t)1 << 27;  // doubles: 1 GiB of scratch at most
-    *blocks = (int)std::max<size_t>(1, std::min<size_t>({(size_t)std::max(n2, 1), (size_t)1024, budget / std::max<size_t>(per_block, 1)}));
+    if (*exact) {
+        const size_t per_block = 2 * (size_t)nr2 + 2 * (size_t)p;
+        const size_t budget = (size_t)1 << 27;  // doubles: 1 GiB of scratch at most
+        *blocks = (int)std::max<size_t>(1, std::min<size_t>({(size_t)std::max(n2, 1), (size_t)1024, budget / std::max<size_t>(per_block, 1)}));
+        return per_block * (size_t)*blocks;
+    }
+    static const int bisect = std::getenv("BMX_ASV_BISECT") != nullptr;
+    if (bisect) {
+        const size_t per_block = 2 * (size_t)std::max(nr1, 1);
+        *blocks = (int)std::max<size_t>(1, std::min<size_t>({(size_t)std::max(n2, 1), (size_t)1024, ((size_t)1 << 27) / per_block}));
+        return per_block * (size_t)*blocks;
+    }
+    const size_t N = (size_t)nr1 + (size_t)nr2;
+    const size_t per_block = (size_t)2 * AT_C * std::max<size_t>(N, 1);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
+    const size_t budget = std::max<size_t>((size_t)1 << 27, free_b / 2 / sizeof(double));  // half of what is free
+    const size_t tiles = ((size_t)std::max(n2, 1) + AT_C - 1) / AT_C;
+    *blocks = (int)std::max<size_t>(1, std::min<size_t>({tiles, (size_t)256, budget / per_block}));
     return per_block * (size_t)*blocks;
+}
+
+// extra doubles the tiled form keeps behind its scratch: norms of both batches, and vect row-major if it is not
+size_t adjust_shift_variance_extra(int g, int n1, int n2, int vect_row_major) {
+    return (size_t)n1 + (size_t)n2 + (vect_row_major ? 0 : (size_t)n2 * g) + 16;
 }
 
 void adjust_shift_variance_device(hipStream_t stream, const double* data1, int g, int n1, const double* data2, int n2,
@@ -549,13 +921,31 @@ void adjust_shift_variance_device(hipStream_t stream, const double* data1, int g
     const int64_t vs_cell = vect_row_major ? g : 1, vs_x = vect_row_major ? 1 : n2;
     if (n2 <= 0) return;
     int blocks = 1, npad = 1, exact = 1;
-    (void)adjust_shift_variance_scratch(n2, nr1, nr2, &blocks, &npad, &exact);
-    if (exact)
+    const size_t main_doubles = adjust_shift_variance_scratch(n2, nr1, nr2, &blocks, &npad, &exact);
+    static const int bisect = std::getenv("BMX_ASV_BISECT") != nullptr;
+    if (exact) {
         hipLaunchKernelGGL(asv_exact_kernel, dim3(blocks), dim3(T), (size_t)2 * g * sizeof(double), stream, data1, g, data2,
                            n2, vect, vs_cell, vs_x, sigma2, restrict1, nr1, restrict2, nr2, npad, out, ws_pairs);
-    else
+    } else if (bisect) {
         hipLaunchKernelGGL(asv_kernel, dim3(blocks), dim3(T), (size_t)2 * g * sizeof(double), stream, data1, g, n1, data2,
                            n2, vect, vs_cell, vs_x, sigma2, restrict1, nr1, restrict2, nr2, out, ws_pairs);
+    } else {
+        if (g > 256) throw Error(BMX_ERR_ARG, "adjust_shift_variance: more than 256 dimensions at this size are not supported");
+        double* nrm1 = ws_pairs + main_doubles;
+        double* nrm2 = nrm1 + n1;
+        const double* vrm = vect;
+        if (!vect_row_major) {
+            double* t = nrm2 + n2;
+            transpose_cm_to_rm(stream, vect, n2, g, t);
+            vrm = t;
+        }
+        if (n1 > 0) hipLaunchKernelGGL(row_norms2, dim3((unsigned)cdiv(n1, 4)), dim3(256), 0, stream, data1, (int64_t)n1, g, nrm1);
+        hipLaunchKernelGGL(row_norms2, dim3((unsigned)cdiv(n2, 4)), dim3(256), 0, stream, data2, (int64_t)n2, g, nrm2);
+        const size_t lds = asv_tile_lds_bytes(g);
+        ensure_dynamic_lds(reinterpret_cast<const void*>(&asv_tile_kernel), lds);
+        hipLaunchKernelGGL(asv_tile_kernel, dim3(blocks), dim3(T), lds, stream, data1, g, data2, n2, vrm, sigma2, restrict1, nr1,
+                           restrict2, nr2, (const double*)nrm1, (const double*)nrm2, out, ws_pairs);
+    }
     BMX_LAUNCH_CHECK();
 }
 

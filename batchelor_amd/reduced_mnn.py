@@ -180,6 +180,17 @@ class MnnEngine:
             out.append(dict(zip(("nL", "nR", "U", "P", "nL_all", "nR_all"), a.tolist())))
         return out
 
+    def _pairs(self):
+        pairs = []
+        for m in range(self.nbatches - 1):
+            n = ctypes.c_int64(0)
+            _lib.check(_lib.lib().bmx_engine_pairs_into(self._h, m, None, None, ctypes.c_int64(0), ctypes.byref(n)))
+            pl, pr = np.empty(n.value, dtype=np.int32), np.empty(n.value, dtype=np.int32)  # R's integer vectors
+            _lib.check(_lib.lib().bmx_engine_pairs_into(self._h, m, _lib.i32p(pl), _lib.i32p(pr),
+                                                        ctypes.c_int64(n.value), ctypes.byref(n)))
+            pairs.append((pl, pr))
+        return pairs
+
     def download(self, with_pairs=True, c_order=True) -> MnnResult:
         """Results to the host.  The boundary writes `corrected` column-major (as R holds matrices); `c_order=False`
         returns it that way instead of converting it to numpy's row-major default."""
@@ -195,19 +206,72 @@ class MnnEngine:
         lv = np.zeros((nm, B), dtype=np.float64, order="F")
         _lib.check(_lib.lib().bmx_engine_download(self._h, _lib.f64p(corrected), _lib.i32p(batch), _lib.i32p(ml),
                                                   _lib.i32p(mr), _lib.f64p(bs), _lib.i32p(sk), _lib.f64p(lv)))
-        pairs = []
-        if with_pairs:
-            for m in range(nm):
-                n = ctypes.c_int64(0)
-                _lib.check(_lib.lib().bmx_engine_pairs_into(self._h, m, None, None, ctypes.c_int64(0), ctypes.byref(n)))
-                pl, pr = np.empty(n.value, dtype=np.int32), np.empty(n.value, dtype=np.int32)  # R's integer vectors
-                _lib.check(_lib.lib().bmx_engine_pairs_into(self._h, m, _lib.i32p(pl), _lib.i32p(pr),
-                                                            ctypes.c_int64(n.value), ctypes.byref(n)))
-                pairs.append((pl, pr))
+        pairs = self._pairs() if with_pairs else []
         info = MergeInfo(left=[[int(x) for x in row if x] for row in ml], right=[[int(x) for x in row if x] for row in mr],
                          pairs=pairs, batch_size=bs, skipped=sk.astype(bool), lost_var=np.ascontiguousarray(lv))
         return MnnResult(corrected=np.ascontiguousarray(corrected) if c_order else corrected, batch=batch, merge_info=info,
                          stats=self.merge_stats())
+
+
+def fast_mnn_one_shot(batches, restrict=None, k=20, prop_k=None, ndist=3.0, min_batch_skip=0.0, merge_tree=None,
+                      auto_merge=False, var_adj=False, sigma=0.1, with_pairs=True, c_order=True) -> MnnResult:
+    """bmx_fast_mnn(): the single call INTEGRATION.md's .Call shim makes -- host matrices in (R layout: cells x d,
+    column-major), host results out; the library pulls the batches through its pinned staging ring while the first
+    merges already run.  `merge_tree`: binary tree with 1-based integer leaves (None: 1..B progressive)."""
+    _lib.require_gpu()
+    mats = [_lib.as_f(b) for b in batches]
+    if len(mats) < 2:
+        raise ValueError("at least two batches must be specified")  # R/fastMNN.R:345
+    d = mats[0].shape[1]
+    for m in mats:
+        if m.ndim != 2 or m.shape[1] != d:
+            raise ValueError("number of columns is not the same across batches")  # R/checkInputs.R:64-71
+    B = len(mats)
+    data = (ctypes.c_void_p * B)(*[m.ctypes.data for m in mats])
+    nrows = np.asarray([m.shape[0] for m in mats], dtype=np.int32)
+    rlist, rptr, rn = [], (ctypes.c_void_p * B)(), np.full(B, -1, dtype=np.int32)
+    if restrict is not None:
+        if len(restrict) != B:
+            raise ValueError("'restrictions' must of length equal to the number of batches")
+        for b, r in enumerate(restrict):
+            if r is None:
+                continue
+            r = np.asarray(r)
+            r = (np.flatnonzero(r) + 1) if r.dtype == bool else r
+            r = np.ascontiguousarray(r, dtype=np.int32)
+            if r.size == 0:
+                raise ValueError("no cells remaining in a batch after restriction")
+            rlist.append(r)
+            rptr[b] = r.ctypes.data
+            rn[b] = r.size
+    p = BmxParams(ctypes.sizeof(BmxParams), int(k), float("nan") if prop_k is None else float(prop_k), float(ndist),
+                  float("nan") if min_batch_skip is None else float(min_batch_skip), 1 if auto_merge else 0,
+                  1 if var_adj else 0, float(sigma))
+    code = encode_postorder(merge_tree if merge_tree is not None else resolve_merge_order(B))
+    N, nm = int(nrows.sum()), B - 1
+    corrected = np.empty((N, d), dtype=np.float64, order="F")  # (every element is written by the library)
+    batch = np.empty(N, dtype=np.int32)
+    ml = np.zeros((nm, B), dtype=np.int32)
+    mr = np.zeros((nm, B), dtype=np.int32)
+    bs = np.zeros(nm, dtype=np.float64)
+    sk = np.zeros(nm, dtype=np.int32)
+    lv = np.zeros((nm, B), dtype=np.float64, order="F")
+    eng = MnnEngine.__new__(MnnEngine)
+    eng._h, eng._keep, eng._cb = ctypes.c_void_p(), (mats, rlist), None
+    eng.nbatches, eng.nrows, eng.d = B, nrows.tolist(), d
+    _lib.check(_lib.lib().bmx_fast_mnn(B, d, data, _lib.i32p(nrows), rptr if restrict is not None else None, _lib.i32p(rn),
+                                       ctypes.byref(p), _lib.i32p(code), int(code.size), _lib.f64p(corrected),
+                                       _lib.i32p(batch), _lib.i32p(ml), _lib.i32p(mr), _lib.f64p(bs), _lib.i32p(sk),
+                                       _lib.f64p(lv), ctypes.byref(eng._h)))
+    try:
+        pairs = eng._pairs() if with_pairs else []
+        stats = eng.merge_stats()
+    finally:
+        eng.close()
+    info = MergeInfo(left=[[int(x) for x in row if x] for row in ml], right=[[int(x) for x in row if x] for row in mr],
+                     pairs=pairs, batch_size=bs, skipped=sk.astype(bool), lost_var=np.ascontiguousarray(lv))
+    return MnnResult(corrected=np.ascontiguousarray(corrected) if c_order else corrected, batch=batch, merge_info=info,
+                     stats=stats)
 
 
 def _fast_mnn(batches, k, prop_k, restrict, ndist, merge_order, auto_merge, min_batch_skip, names, device=0,
@@ -215,15 +279,20 @@ def _fast_mnn(batches, k, prop_k, restrict, ndist, merge_order, auto_merge, min_
     """.fast_mnn (R/fastMNN.R:398-429)."""
     if names is not None and len(set(names)) != len(names):
         raise ValueError("names of batches should be unique")  # R/fastMNN.R:422
-    eng = MnnEngine(device)
-    try:
-        eng.upload(batches, restrict)
+    if device == 0:
         tree = None if auto_merge else resolve_merge_order(len(batches), merge_order, names)
-        eng.run(k=k, prop_k=prop_k, ndist=ndist, min_batch_skip=min_batch_skip, merge_tree=tree,
-                auto_merge=auto_merge, var_adj=var_adj, sigma=sigma)
-        out = eng.download()
-    finally:
-        eng.close()
+        out = fast_mnn_one_shot(batches, restrict, k=k, prop_k=prop_k, ndist=ndist, min_batch_skip=min_batch_skip,
+                                merge_tree=tree, auto_merge=auto_merge, var_adj=var_adj, sigma=sigma)
+    else:
+        eng = MnnEngine(device)
+        try:
+            eng.upload(batches, restrict)
+            tree = None if auto_merge else resolve_merge_order(len(batches), merge_order, names)
+            eng.run(k=k, prop_k=prop_k, ndist=ndist, min_batch_skip=min_batch_skip, merge_tree=tree,
+                    auto_merge=auto_merge, var_adj=var_adj, sigma=sigma)
+            out = eng.download()
+        finally:
+            eng.close()
     if names is not None:  # R/fastMNN.R:419-427
         nm = np.asarray(list(names), dtype=object)
         out.batch = nm[out.batch - 1]

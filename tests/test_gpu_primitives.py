@@ -172,6 +172,21 @@ for sigma, bar in ((1.0, 0.999), (0.1, 0.95)):
     ref = orc.adjust_shift_variance(data1, data2, corvect, sigma, np.arange(400), np.arange(1000))
     close = np.isclose(out, ref, rtol=1e-8, atol=1e-12)
     assert close.mean() > bar, (sigma, close.mean())
+    again = nat.adjust_shift_variance(data1, data2, corvect, sigma, np.arange(400), np.arange(1000))
+    assert np.array_equal(out, again, equal_nan=True)          # integer histogram sums: runs are bit-identical
+# the tiled form's edges: 100 dimensions (four staged steps of 32, the last ragged), cell and stream counts that are not
+# multiples of the tile sizes, restrict vectors in arbitrary order that leave cells out, a zero gradient
+d1 = rng.standard_normal((100, 1237)) / np.sqrt(1.0 + np.arange(100) / 5.0)[:, None]
+d2 = rng.standard_normal((100, 1003)) / np.sqrt(1.0 + np.arange(100) / 5.0)[:, None] + 0.3
+cv = rng.standard_normal((1003, 100)) * 0.2
+cv[17] = 0.0
+r1 = rng.permutation(1237)[:901]
+r2 = rng.permutation(1003)[:777]
+out = nat.adjust_shift_variance(d1, d2, cv, 1.0, r1, r2)
+ref = orc.adjust_shift_variance(d1, d2, cv, 1.0, r1, r2)
+close = np.isclose(out, ref, rtol=1e-8, atol=1e-12, equal_nan=True)
+assert close.mean() > 0.995, close.mean()
+assert np.isnan(out[17]) and np.isnan(ref[17])                  # 0 / 0, as the reference (:160)
 print("asv-fast-ok")
 ''' % root
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BMX_ASV_FAST="1"), capture_output=True,
