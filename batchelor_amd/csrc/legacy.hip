@@ -603,19 +603,50 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(const double* __restrict__ 
             cp[i] = sc_proj[(lane >> 4) + 4 * i];
             cn[i] = sc_n[(lane >> 4) + 4 * i];
         }
-        const int lr = tid >> 2, seg = (tid & 3) * 8;  // staging: 64 rows x 4 segments of 8 doubles
-        for (int64_t j0 = 0; j0 < N; j0 += AT_R) {
-            const int64_t jr = j0 + lr;
-            const double* src = nullptr;
-            if (jr < N) src = jr < nr2 ? data2 + (int64_t)r2[jr] * g : data1 + (int64_t)r1[jr - nr2] * g;
-            d4 D = d4{0.0, 0.0, 0.0, 0.0}, P = d4{0.0, 0.0, 0.0, 0.0};
-            for (int k0 = 0; k0 < g; k0 += AT_KC) {
+        // staging: 64 rows x 4 segments of 8 doubles per step of 32 dimensions; the step after the one being multiplied is
+        // already on its way into registers (16-byte loads where the rows allow), the row pointers one streamed block ahead
+        typedef double d2a __attribute__((ext_vector_type(2)));
+        const int lr = tid >> 2, seg = (tid & 3) * 8;
+        const bool vec = (g & 1) == 0;
+        const int nkc = (g + AT_KC - 1) / AT_KC;
+        auto row_ptr = [&](int64_t jr) -> const double* {
+            if (jr >= N) return nullptr;
+            return jr < nr2 ? data2 + (int64_t)r2[jr] * g : data1 + (int64_t)r1[jr - nr2] * g;
+        };
+        double pf[8];
+        auto fetch = [&](const double* src, int k0) __attribute__((always_inline)) {
+            if (src && vec && k0 + seg + 8 <= g) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const d2a v = *reinterpret_cast<const d2a*>(src + k0 + seg + 2 * e);
+                    pf[2 * e] = v[0];
+                    pf[2 * e + 1] = v[1];
+                }
+            } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int k = k0 + seg + e;
-                    rs[lr * (AT_KC + 2) + seg + e] = (src && k < g) ? src[k] : 0.0;
+                    pf[e] = (src && k < g) ? src[k] : 0.0;
                 }
+            }
+        };
+        const double* src = row_ptr(lr);
+        const double* src_next = row_ptr((int64_t)AT_R + lr);
+        fetch(src, 0);
+        for (int64_t j0 = 0; j0 < N; j0 += AT_R) {
+            d4 D = d4{0.0, 0.0, 0.0, 0.0}, P = d4{0.0, 0.0, 0.0, 0.0};
+            for (int kc = 0; kc < nkc; ++kc) {
+                const int k0 = kc * AT_KC;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) rs[lr * (AT_KC + 2) + seg + e] = pf[e];
                 __syncthreads();
+                if (kc + 1 < nkc) {
+                    fetch(src, k0 + AT_KC);
+                } else {  // the next streamed block's first step; its successor's row pointer starts its own round trip
+                    src = src_next;
+                    fetch(src, 0);
+                    src_next = row_ptr(j0 + 2 * AT_R + lr);
+                }
 #pragma unroll
                 for (int kk = 0; kk < AT_KC / 4; ++kk) {
                     const double b = rs[(16 * w + (lane & 15)) * (AT_KC + 2) + 4 * kk + (lane >> 4)];

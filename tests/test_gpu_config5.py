@@ -156,3 +156,32 @@ def test_full_size_config5_pairs_of_sampled_cells_match_oracle(oracle, full5, m)
     keep = np.isin(pr, gr[rows])
     got = set(zip(pl[keep].tolist(), pr[keep].tolist()))
     assert got == expect and len(expect) > 50
+
+
+def test_full_size_config5_with_variance_adjustment(full5):
+    """BASELINE.json configs[4] as named, on one GPU: the full 16-batch tree WITH adjust_shift_variance on (5e11 cell pairs
+    at the root; the tiled FP64-MFMA form of legacy.hip).  No oracle at this size (it would take days): what must hold is
+    that the run finishes (about a minute), every coordinate is finite, the merge sets are the tree's, and the eight
+    leaf-leaf merges -- upstream of any adjusted cell -- pair exactly as without the switch.  Parity of the kernel itself
+    is in tests/test_gpu_primitives.py (vs the oracle) and, through the tree, in the scaled test above."""
+    import batchelor_amd as bx
+    from bench import WORKLOADS
+    from batchelor_amd.merge_tree import resolve_merge_order
+    sizes, d, k, runs = full5
+    plain = runs[14][0]
+    cfg, _, _, _, tree = WORKLOADS["config5"]
+    B = synth_batches(cfg, sizes, d)
+    eng = bx.MnnEngine()
+    eng.upload(B)
+    eng.run(k=k, merge_tree=resolve_merge_order(len(sizes), tree), var_adj=True, sigma=1.0)
+    out = eng.download()
+    eng.close()
+    assert np.all(np.isfinite(out.corrected)) and len(out.merge_info.pairs) == 15
+    assert out.merge_info.left == plain.merge_info.left and out.merge_info.right == plain.merge_info.right
+    leaf_merges = [m for m in range(15) if len(plain.merge_info.left[m]) == 1 and len(plain.merge_info.right[m]) == 1]
+    assert len(leaf_merges) == 8
+    start = np.concatenate([[0], np.cumsum(sizes)])
+    for m in leaf_merges:
+        assert np.array_equal(out.merge_info.pairs[m][0], plain.merge_info.pairs[m][0])
+        assert np.array_equal(out.merge_info.pairs[m][1], plain.merge_info.pairs[m][1])
+    assert not np.array_equal(out.corrected, plain.corrected)
