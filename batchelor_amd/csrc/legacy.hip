@@ -526,16 +526,19 @@ __global__ __launch_bounds__(T) void asv_exact_kernel(const double* __restrict__
 // ---------------------------------------------------------------------------------------------------
 constexpr int AT_C = 16;        // cells per tile
 constexpr int AT_R = 64;        // streamed cells per step
-constexpr int AT_KC = 32;       // dimensions staged per step
 constexpr int AT_NB = 2048;     // histogram bins
 constexpr int AT_CAP = 2048;    // collected entries of the crossing bin
 
-__host__ __device__ inline int asv_tile_gp(int g) { return (g + AT_KC - 1) / AT_KC * AT_KC + 2; }
+// dimensions staged per step: a whole row (<= 128 dimensions) where the LDS allows -- the next streamed block's rows are then
+// one long prefetch ahead, which is what hides the HBM latency at four waves per CU -- else 32
+__host__ __device__ inline int asv_tile_kc(int g) { return g <= 128 ? 128 : 32; }
+__host__ __device__ inline int asv_tile_gp(int g) { const int kc = asv_tile_kc(g); return (g + kc - 1) / kc * kc + 2; }
 inline size_t asv_tile_lds_bytes(int g) {
-    return ((size_t)2 * AT_C * asv_tile_gp(g) + (size_t)AT_R * (AT_KC + 2) + 8 * AT_C + T) * sizeof(double) +
+    return ((size_t)2 * AT_C * asv_tile_gp(g) + (size_t)AT_R * (asv_tile_kc(g) + 2) + 8 * AT_C + T) * sizeof(double) +
            (size_t)AT_NB * sizeof(unsigned long long) + (size_t)AT_CAP * 16;
 }
 
+template <int AT_KC>
 __global__ __launch_bounds__(T) void asv_tile_kernel(const double* __restrict__ data1, int g, const double* __restrict__ data2,
                                                      int n2, const double* __restrict__ vect, double sigma2,
                                                      const int32_t* __restrict__ r1, int nr1, const int32_t* __restrict__ r2,
@@ -606,26 +609,31 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(const double* __restrict__ 
         // staging: 64 rows x 4 segments of 8 doubles per step of 32 dimensions; the step after the one being multiplied is
         // already on its way into registers (16-byte loads where the rows allow), the row pointers one streamed block ahead
         typedef double d2a __attribute__((ext_vector_type(2)));
-        const int lr = tid >> 2, seg = (tid & 3) * 8;
+        constexpr int EPT = AT_KC / 4;  // doubles per thread and step
+        const int lr = tid >> 2, q = tid & 3;  // four lanes share a row: their 16-byte pieces interleave (64 B per row and load)
         const bool vec = (g & 1) == 0;
         const int nkc = (g + AT_KC - 1) / AT_KC;
         auto row_ptr = [&](int64_t jr) -> const double* {
             if (jr >= N) return nullptr;
             return jr < nr2 ? data2 + (int64_t)r2[jr] * g : data1 + (int64_t)r1[jr - nr2] * g;
         };
-        double pf[8];
+        double pf[EPT];
+        // element e of the thread's registers is column col(e) of the step
+        auto col = [&](int e) { return vec ? 2 * (q + 4 * (e >> 1)) + (e & 1) : q + 4 * e; };
         auto fetch = [&](const double* src, int k0) __attribute__((always_inline)) {
-            if (src && vec && k0 + seg + 8 <= g) {
+            if (vec) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const d2a v = *reinterpret_cast<const d2a*>(src + k0 + seg + 2 * e);
+                for (int e = 0; e < EPT / 2; ++e) {
+                    const int k = k0 + 2 * (q + 4 * e);
+                    d2a v = d2a{0.0, 0.0};
+                    if (src && k < g) v = *reinterpret_cast<const d2a*>(src + k);
                     pf[2 * e] = v[0];
                     pf[2 * e + 1] = v[1];
                 }
             } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int k = k0 + seg + e;
+                for (int e = 0; e < EPT; ++e) {
+                    const int k = k0 + q + 4 * e;
                     pf[e] = (src && k < g) ? src[k] : 0.0;
                 }
             }
@@ -633,12 +641,16 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(const double* __restrict__ 
         const double* src = row_ptr(lr);
         const double* src_next = row_ptr((int64_t)AT_R + lr);
         fetch(src, 0);
+#ifdef BMX_ASV_EXP_NOSTREAM
+        for (int64_t j0 = 0; j0 < 0; j0 += AT_R) {  // timing experiment: the per-cell phase alone (on stale scratch)
+#else
         for (int64_t j0 = 0; j0 < N; j0 += AT_R) {
+#endif
             d4 D = d4{0.0, 0.0, 0.0, 0.0}, P = d4{0.0, 0.0, 0.0, 0.0};
             for (int kc = 0; kc < nkc; ++kc) {
                 const int k0 = kc * AT_KC;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) rs[lr * (AT_KC + 2) + seg + e] = pf[e];
+                for (int e = 0; e < EPT; ++e) rs[lr * (AT_KC + 2) + col(e)] = pf[e];
                 __syncthreads();
                 if (kc + 1 < nkc) {
                     fetch(src, k0 + AT_KC);
@@ -647,8 +659,8 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(const double* __restrict__ 
                     fetch(src, 0);
                     src_next = row_ptr(j0 + 2 * AT_R + lr);
                 }
-#pragma unroll
-                for (int kk = 0; kk < AT_KC / 4; ++kk) {
+                const int nkk = min(AT_KC / 4, (g - k0 + 3) / 4);  // (zero padding beyond g is not multiplied)
+                for (int kk = 0; kk < nkk; ++kk) {
                     const double b = rs[(16 * w + (lane & 15)) * (AT_KC + 2) + 4 * kk + (lane >> 4)];
                     const double ax = cx[(lane & 15) * GP + k0 + 4 * kk + (lane >> 4)];
                     const double ag = cg[(lane & 15) * GP + k0 + 4 * kk + (lane >> 4)];
@@ -727,6 +739,9 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(const double* __restrict__ 
         // (the scratch rows were written by this block and are read by it: same CU, through the L2)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
         // ---- cell by cell: own-batch probability, then the weighted quantile of the reference projections
+#ifdef BMX_ASV_EXP_NOCELL
+        if (n2 >= 0) continue;  // timing experiment: the stream pass alone (results are garbage)
+#endif
         for (int c = 0; c < AT_C && c0 + c < n2; ++c) {
             const double* p2 = SP + (int64_t)c * N;
             const double* w2 = SW + (int64_t)c * N;
@@ -973,9 +988,15 @@ void adjust_shift_variance_device(hipStream_t stream, const double* data1, int g
         if (n1 > 0) hipLaunchKernelGGL(row_norms2, dim3((unsigned)cdiv(n1, 4)), dim3(256), 0, stream, data1, (int64_t)n1, g, nrm1);
         hipLaunchKernelGGL(row_norms2, dim3((unsigned)cdiv(n2, 4)), dim3(256), 0, stream, data2, (int64_t)n2, g, nrm2);
         const size_t lds = asv_tile_lds_bytes(g);
-        ensure_dynamic_lds(reinterpret_cast<const void*>(&asv_tile_kernel), lds);
-        hipLaunchKernelGGL(asv_tile_kernel, dim3(blocks), dim3(T), lds, stream, data1, g, data2, n2, vrm, sigma2, restrict1, nr1,
-                           restrict2, nr2, (const double*)nrm1, (const double*)nrm2, out, ws_pairs);
+        if (asv_tile_kc(g) == 128) {
+            ensure_dynamic_lds(reinterpret_cast<const void*>(&asv_tile_kernel<128>), lds);
+            hipLaunchKernelGGL(asv_tile_kernel<128>, dim3(blocks), dim3(T), lds, stream, data1, g, data2, n2, vrm, sigma2,
+                               restrict1, nr1, restrict2, nr2, (const double*)nrm1, (const double*)nrm2, out, ws_pairs);
+        } else {
+            ensure_dynamic_lds(reinterpret_cast<const void*>(&asv_tile_kernel<32>), lds);
+            hipLaunchKernelGGL(asv_tile_kernel<32>, dim3(blocks), dim3(T), lds, stream, data1, g, data2, n2, vrm, sigma2,
+                               restrict1, nr1, restrict2, nr2, (const double*)nrm1, (const double*)nrm2, out, ws_pairs);
+        }
     }
     BMX_LAUNCH_CHECK();
 }

@@ -81,10 +81,14 @@ def measured_traffic(workload, kernel):
     for gfx950 (FETCH_SIZE x 2).  PMC counters cannot be read from inside the timed process, so the number is the
     last committed measurement -- and it is only reported when it was taken on the very kernel (template arguments
     included) this run has just launched; otherwise None plus the reason."""
-    path = os.path.join(ROOT, "profiles", f"r02_traffic_{workload}.json")
-    try:
-        rec = json.load(open(path))
-    except (OSError, ValueError):
+    rec = None
+    for rnd in ("r03", "r02"):  # the latest committed measurement
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_traffic_{workload}.json")))
+            break
+        except (OSError, ValueError):
+            continue
+    if rec is None:
         return None, f"no committed PMC measurement for {workload}"
     if rec.get("workload") != workload or not str(rec.get("kernel", "")).startswith(kernel):
         return None, f"committed PMC measurement is for {rec.get('kernel')!r}, this run launched {kernel!r}"
