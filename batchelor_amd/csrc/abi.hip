@@ -430,7 +430,7 @@ int32_t bmx_adjust_shift_variance(const double* data1, int32_t g1, int32_t n1, c
         double* po = dO.reserve(n2);
         int asv_blocks = 1, asv_npad = 1, asv_exact = 1;
         double* pw = dW.reserve(bmx::adjust_shift_variance_scratch(n2, nr1, nr2, &asv_blocks, &asv_npad, &asv_exact) +
-                                bmx::adjust_shift_variance_extra(g, n1, n2, 0));
+                                bmx::adjust_shift_variance_extra(g, nr1, nr2, n2, 0));
         bmx::adjust_shift_variance_device(s, p1, g, n1, p2, n2, pv, sigma2, q1, nr1, q2, nr2, po, pw);
         BMX_HIP(hipMemcpyAsync(out, po, (size_t)n2 * sizeof(double), hipMemcpyDeviceToHost, s));
         BMX_HIP(hipStreamSynchronize(s));

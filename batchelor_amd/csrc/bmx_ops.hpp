@@ -119,7 +119,7 @@ void smooth_gaussian_kernel_device(hipStream_t stream, const double* averaged, i
 // doubles of scratch adjust_shift_variance_device needs (and the launch shape it will use)
 size_t adjust_shift_variance_scratch(int n2, int nr1, int nr2, int* blocks, int* npad, int* exact);
 // doubles needed BEHIND that scratch (norms of the cells, a row-major copy of vect): reserve scratch + extra
-size_t adjust_shift_variance_extra(int g, int n1, int n2, int vect_row_major);
+size_t adjust_shift_variance_extra(int g, int nr1, int nr2, int n2, int vect_row_major);
 void adjust_shift_variance_device(hipStream_t stream, const double* data1, int g, int n1, const double* data2, int n2,
                                   const double* vect, double sigma2, const int32_t* restrict1, int nr1,
                                   const int32_t* restrict2, int nr2, double* out, double* ws_pairs,

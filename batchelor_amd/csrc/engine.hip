@@ -591,7 +591,7 @@ void Engine::merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p,
             BMX_LAUNCH_CHECK();
             int blocks = 1, npad = 1, exact = 1;
             double* ws = asv_ws_.reserve(adjust_shift_variance_scratch(right.n, nLs, nRs, &blocks, &npad, &exact) +
-                                         adjust_shift_variance_extra(d_, left.n, right.n, 1));
+                                         adjust_shift_variance_extra(d_, nLs, nRs, right.n, 1));
             double* scaling = asv_scale_.reserve(right.n);
             adjust_shift_variance_device(stream_, left.data.p, d_, left.n, right.data.p, right.n, corr, p.sigma, r1, nLs, r2,
                                          nRs, scaling, ws, /* vect_row_major */ 1);

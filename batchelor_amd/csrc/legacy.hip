@@ -526,24 +526,47 @@ __global__ __launch_bounds__(T) void asv_exact_kernel(const double* __restrict__
 // ---------------------------------------------------------------------------------------------------
 constexpr int AT_C = 16;        // cells per tile
 constexpr int AT_R = 64;        // streamed cells per step
+constexpr int AT_KC = 32;       // dimensions staged per step
 constexpr int AT_NB = 2048;     // histogram bins
 constexpr int AT_CAP = 2048;    // collected entries of the crossing bin
 
-// dimensions staged per step: a whole row (<= 128 dimensions) where the LDS allows -- the next streamed block's rows are then
-// one long prefetch ahead, which is what hides the HBM latency at four waves per CU -- else 32
-__host__ __device__ inline int asv_tile_kc(int g) { return g <= 128 ? 128 : 32; }
-__host__ __device__ inline int asv_tile_gp(int g) { const int kc = asv_tile_kc(g); return (g + kc - 1) / kc * kc + 2; }
+__host__ __device__ inline int asv_tile_gp(int g) { return (g + AT_KC - 1) / AT_KC * AT_KC + 2; }
 inline size_t asv_tile_lds_bytes(int g) {
-    return ((size_t)2 * AT_C * asv_tile_gp(g) + (size_t)AT_R * (asv_tile_kc(g) + 2) + 8 * AT_C + T) * sizeof(double) +
+    return ((size_t)2 * AT_C * asv_tile_gp(g) + (size_t)AT_R * (AT_KC + 2) + 8 * AT_C + T) * sizeof(double) +
            (size_t)AT_NB * sizeof(unsigned long long) + (size_t)AT_CAP * 16;
 }
 
-template <int AT_KC>
-__global__ __launch_bounds__(T) void asv_tile_kernel(const double* __restrict__ data1, int g, const double* __restrict__ data2,
-                                                     int n2, const double* __restrict__ vect, double sigma2,
-                                                     const int32_t* __restrict__ r1, int nr1, const int32_t* __restrict__ r2,
-                                                     int nr2, const double* __restrict__ nrm1, const double* __restrict__ nrm2,
-                                                     double* __restrict__ out, double* __restrict__ scratch) {
+// The streamed cells of one call, in stream order (the own batch's restricted cells, then the reference's), as ONE
+// contiguous matrix with their squared norms and -- for the own batch -- their cell ids: the tile kernel then reads plain
+// consecutive rows (coalesced, prefetchable any distance ahead) instead of chasing restrict[] -> row -> norm per step.
+__global__ __launch_bounds__(256) void asv_gather_stream(const double* __restrict__ data1, const double* __restrict__ data2,
+                                                         int g, const int32_t* __restrict__ r1, int nr1,
+                                                         const int32_t* __restrict__ r2, int nr2, double* __restrict__ S,
+                                                         double* __restrict__ snrm, int32_t* __restrict__ sid) {
+    const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (j >= (int64_t)nr1 + nr2) return;
+    const bool own = j < nr2;
+    const int rid = own ? r2[j] : r1[j - nr2];
+    const double* src = (own ? data2 : data1) + (int64_t)rid * g;
+    double sq = 0.0;
+    for (int k = lane; k < g; k += 64) {
+        const double v = src[k];
+        S[j * g + k] = v;
+        sq += v * v;
+    }
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    if (lane == 0) {
+        snrm[j] = sq;
+        sid[j] = own ? rid : -1;
+    }
+}
+
+__global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __restrict__ data2, int n2,
+                                                     const double* __restrict__ vect, double sigma2, int nr1, int nr2,
+                                                     const double* __restrict__ S, const double* __restrict__ snrm,
+                                                     const int32_t* __restrict__ sid, double* __restrict__ out,
+                                                     double* __restrict__ scratch) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int GP = asv_tile_gp(g);
     double* cx = reinterpret_cast<double*>(smem_raw);  // [16][GP] the tile's cells
@@ -609,31 +632,23 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(const double* __restrict__ 
         // staging: 64 rows x 4 segments of 8 doubles per step of 32 dimensions; the step after the one being multiplied is
         // already on its way into registers (16-byte loads where the rows allow), the row pointers one streamed block ahead
         typedef double d2a __attribute__((ext_vector_type(2)));
-        constexpr int EPT = AT_KC / 4;  // doubles per thread and step
-        const int lr = tid >> 2, q = tid & 3;  // four lanes share a row: their 16-byte pieces interleave (64 B per row and load)
+        const int lr = tid >> 2, seg = (tid & 3) * 8;
         const bool vec = (g & 1) == 0;
         const int nkc = (g + AT_KC - 1) / AT_KC;
-        auto row_ptr = [&](int64_t jr) -> const double* {
-            if (jr >= N) return nullptr;
-            return jr < nr2 ? data2 + (int64_t)r2[jr] * g : data1 + (int64_t)r1[jr - nr2] * g;
-        };
-        double pf[EPT];
-        // element e of the thread's registers is column col(e) of the step
-        auto col = [&](int e) { return vec ? 2 * (q + 4 * (e >> 1)) + (e & 1) : q + 4 * e; };
+        auto row_ptr = [&](int64_t jr) -> const double* { return jr < N ? S + jr * g : nullptr; };
+        double pf[8];
         auto fetch = [&](const double* src, int k0) __attribute__((always_inline)) {
-            if (vec) {
+            if (src && vec && k0 + seg + 8 <= g) {
 #pragma unroll
-                for (int e = 0; e < EPT / 2; ++e) {
-                    const int k = k0 + 2 * (q + 4 * e);
-                    d2a v = d2a{0.0, 0.0};
-                    if (src && k < g) v = *reinterpret_cast<const d2a*>(src + k);
+                for (int e = 0; e < 4; ++e) {
+                    const d2a v = *reinterpret_cast<const d2a*>(src + k0 + seg + 2 * e);
                     pf[2 * e] = v[0];
                     pf[2 * e + 1] = v[1];
                 }
             } else {
 #pragma unroll
-                for (int e = 0; e < EPT; ++e) {
-                    const int k = k0 + q + 4 * e;
+                for (int e = 0; e < 8; ++e) {
+                    const int k = k0 + seg + e;
                     pf[e] = (src && k < g) ? src[k] : 0.0;
                 }
             }
@@ -641,16 +656,16 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(const double* __restrict__ 
         const double* src = row_ptr(lr);
         const double* src_next = row_ptr((int64_t)AT_R + lr);
         fetch(src, 0);
-#ifdef BMX_ASV_EXP_NOSTREAM
-        for (int64_t j0 = 0; j0 < 0; j0 += AT_R) {  // timing experiment: the per-cell phase alone (on stale scratch)
-#else
         for (int64_t j0 = 0; j0 < N; j0 += AT_R) {
-#endif
             d4 D = d4{0.0, 0.0, 0.0, 0.0}, P = d4{0.0, 0.0, 0.0, 0.0};
+            // this lane's streamed cell of the step: its norm and id are asked for now and used after the products
+            const int64_t jo = j0 + 16 * w + (lane & 15);
+            const double no = jo < N ? snrm[jo] : 0.0;
+            const int rid = jo < N ? sid[jo] : -1;
             for (int kc = 0; kc < nkc; ++kc) {
                 const int k0 = kc * AT_KC;
 #pragma unroll
-                for (int e = 0; e < EPT; ++e) rs[lr * (AT_KC + 2) + col(e)] = pf[e];
+                for (int e = 0; e < 8; ++e) rs[lr * (AT_KC + 2) + seg + e] = pf[e];
                 __syncthreads();
                 if (kc + 1 < nkc) {
                     fetch(src, k0 + AT_KC);
@@ -658,9 +673,10 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(const double* __restrict__ 
                     src = src_next;
                     fetch(src, 0);
                     src_next = row_ptr(j0 + 2 * AT_R + lr);
+                    (void)src_next;
                 }
-                const int nkk = min(AT_KC / 4, (g - k0 + 3) / 4);  // (zero padding beyond g is not multiplied)
-                for (int kk = 0; kk < nkk; ++kk) {
+#pragma unroll
+                for (int kk = 0; kk < AT_KC / 4; ++kk) {
                     const double b = rs[(16 * w + (lane & 15)) * (AT_KC + 2) + 4 * kk + (lane >> 4)];
                     const double ax = cx[(lane & 15) * GP + k0 + 4 * kk + (lane >> 4)];
                     const double ag = cg[(lane & 15) * GP + k0 + 4 * kk + (lane >> 4)];
@@ -670,11 +686,8 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(const double* __restrict__ 
                 __syncthreads();
             }
             // this lane: streamed cell jo, tile cells (lane >> 4) + 4 i
-            const int64_t jo = j0 + 16 * w + (lane & 15);
             if (jo < N) {
                 const bool own = jo < nr2;
-                const int rid = own ? r2[jo] : r1[jo - nr2];
-                const double no = own ? nrm2[rid] : nrm1[rid];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int c = (lane >> 4) + 4 * i;
@@ -739,9 +752,6 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(const double* __restrict__ 
         // (the scratch rows were written by this block and are read by it: same CU, through the L2)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
         // ---- cell by cell: own-batch probability, then the weighted quantile of the reference projections
-#ifdef BMX_ASV_EXP_NOCELL
-        if (n2 >= 0) continue;  // timing experiment: the stream pass alone (results are garbage)
-#endif
         for (int c = 0; c < AT_C && c0 + c < n2; ++c) {
             const double* p2 = SP + (int64_t)c * N;
             const double* w2 = SW + (int64_t)c * N;
@@ -956,8 +966,10 @@ size_t adjust_shift_variance_scratch(int n2, int nr1, int nr2, int* blocks, int*
 }
 
 // extra doubles the tiled form keeps behind its scratch: norms of both batches, and vect row-major if it is not
-size_t adjust_shift_variance_extra(int g, int n1, int n2, int vect_row_major) {
-    return (size_t)n1 + (size_t)n2 + (vect_row_major ? 0 : (size_t)n2 * g) + 16;
+size_t adjust_shift_variance_extra(int g, int nr1, int nr2, int n2, int vect_row_major) {
+    // (the nr1 + nr2 streamed cells: their rows, norms, ids; a row-major copy of vect if it came column-major)
+    const size_t N = (size_t)nr1 + (size_t)nr2;
+    return N * g + N + (N + 1) / 2 + 2 + (vect_row_major ? 0 : (size_t)n2 * g) + 16;
 }
 
 void adjust_shift_variance_device(hipStream_t stream, const double* data1, int g, int n1, const double* data2, int n2,
@@ -977,26 +989,24 @@ void adjust_shift_variance_device(hipStream_t stream, const double* data1, int g
                            n2, vect, vs_cell, vs_x, sigma2, restrict1, nr1, restrict2, nr2, out, ws_pairs);
     } else {
         if (g > 256) throw Error(BMX_ERR_ARG, "adjust_shift_variance: more than 256 dimensions at this size are not supported");
-        double* nrm1 = ws_pairs + main_doubles;
-        double* nrm2 = nrm1 + n1;
+        double* extra = ws_pairs + main_doubles;
+        const int64_t N = (int64_t)nr1 + nr2;
+        double* S = extra;                      // [N][g] the streamed cells
+        double* snrm = S + N * g;               // [N]
+        int32_t* sid = reinterpret_cast<int32_t*>(snrm + N);  // [N]
         const double* vrm = vect;
         if (!vect_row_major) {
-            double* t = nrm2 + n2;
+            double* t = snrm + N + (N + 1) / 2 + 2;
             transpose_cm_to_rm(stream, vect, n2, g, t);
             vrm = t;
         }
-        if (n1 > 0) hipLaunchKernelGGL(row_norms2, dim3((unsigned)cdiv(n1, 4)), dim3(256), 0, stream, data1, (int64_t)n1, g, nrm1);
-        hipLaunchKernelGGL(row_norms2, dim3((unsigned)cdiv(n2, 4)), dim3(256), 0, stream, data2, (int64_t)n2, g, nrm2);
+        if (N > 0)
+            hipLaunchKernelGGL(asv_gather_stream, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, stream, data1, data2, g, restrict1, nr1,
+                               restrict2, nr2, S, snrm, sid);
         const size_t lds = asv_tile_lds_bytes(g);
-        if (asv_tile_kc(g) == 128) {
-            ensure_dynamic_lds(reinterpret_cast<const void*>(&asv_tile_kernel<128>), lds);
-            hipLaunchKernelGGL(asv_tile_kernel<128>, dim3(blocks), dim3(T), lds, stream, data1, g, data2, n2, vrm, sigma2,
-                               restrict1, nr1, restrict2, nr2, (const double*)nrm1, (const double*)nrm2, out, ws_pairs);
-        } else {
-            ensure_dynamic_lds(reinterpret_cast<const void*>(&asv_tile_kernel<32>), lds);
-            hipLaunchKernelGGL(asv_tile_kernel<32>, dim3(blocks), dim3(T), lds, stream, data1, g, data2, n2, vrm, sigma2,
-                               restrict1, nr1, restrict2, nr2, (const double*)nrm1, (const double*)nrm2, out, ws_pairs);
-        }
+        ensure_dynamic_lds(reinterpret_cast<const void*>(&asv_tile_kernel), lds);
+        hipLaunchKernelGGL(asv_tile_kernel, dim3(blocks), dim3(T), lds, stream, g, data2, n2, vrm, sigma2, nr1, nr2,
+                           (const double*)S, (const double*)snrm, (const int32_t*)sid, out, ws_pairs);
     }
     BMX_LAUNCH_CHECK();
 }
