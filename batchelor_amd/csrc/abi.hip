@@ -437,6 +437,17 @@ int32_t bmx_adjust_shift_variance(const double* data1, int32_t g1, int32_t n1, c
     });
 }
 
+int32_t bmx_adjust_shift_variance_form(int32_t n2, int32_t nr1, int32_t nr2) {
+    int blocks = 1, npad = 1, exact = 1;
+    try {
+        (void)bmx::adjust_shift_variance_scratch(n2, nr1, nr2, &blocks, &npad, &exact);
+    } catch (...) {
+        return 0;
+    }
+    if (exact) return 1;
+    return std::getenv("BMX_ASV_BISECT") ? 3 : 2;
+}
+
 int32_t bmx_cosine_norm(const double* x, int32_t G, int32_t n, double* l2, double* normalized) {
     return guarded([&] {
         if (G < 0 || n < 0) throw bmx::Error(BMX_ERR_ARG, "negative dimension");

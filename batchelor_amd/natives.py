@@ -49,6 +49,12 @@ def adjust_shift_variance(data1, data2, vect, sigma2, restrict1, restrict2):
     return out
 
 
+def adjust_shift_variance_form(n2, nr1, nr2):
+    """Which form a call of these sizes takes: "exact" (bit-equal to the CPU restatement) or "tiled" (FP64-MFMA tiles +
+    histogram quantile; may pick a neighbouring quantile in ill-conditioned cells) -- bmx_adjust_shift_variance_form."""
+    return {1: "exact", 2: "tiled", 3: "bisect"}[int(_lib.lib().bmx_adjust_shift_variance_form(int(n2), int(nr1), int(nr2)))]
+
+
 def find_mutual_nn(data1, data2, k1, k2):
     """findMutualNN(data1, data2, k1, k2) -> (first, second), 1-based."""
     _lib.require_gpu()

@@ -58,6 +58,13 @@ int32_t bmx_adjust_shift_variance(const double* data1, int32_t g1, int32_t n1, c
                                   const int32_t* restrict1, int32_t nr1, const int32_t* restrict2, int32_t nr2,
                                   double* out);
 
+/* Which form of adjust_shift_variance a call of these sizes takes: 1 = the reference's order of operations literally
+ * (bit-equal to the CPU restatement, every cell; up to 4e7 (cell, restricted cell) pairs), 2 = 16-cell tiles on the FP64
+ * matrix cores with a histogram quantile (beyond that: a cell whose quantile walk is decided on the last bits may land on
+ * the neighbouring quantile; >= 99.5 % of cells agree at sigma = 1, >= 95 % at 0.1), 3 = round 2's bisection form
+ * (BMX_ASV_BISECT=1).  The engine's var_adj merges go through the same switch. */
+int32_t bmx_adjust_shift_variance_form(int32_t n2, int32_t nr1, int32_t nr2);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Third-party contract on the path: BiocNeighbors::queryKNN / findMutualNN (re-export R/findMutualNN.R:1-3; call
  * sites R/MNN_tree.R:129, R/fastMNN.R:605).  Exact Euclidean search, ascending distance, ties by lowest index.

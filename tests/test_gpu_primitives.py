@@ -194,6 +194,13 @@ print("asv-fast-ok")
     assert out.returncode == 0 and "asv-fast-ok" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
 
 
+def test_adjust_shift_variance_form_is_reported(nat):
+    # the switch between the bit-exact and the scalable form is visible to the caller
+    assert nat.adjust_shift_variance_form(1000, 400, 1000) == "exact"          # the reference's own test shapes
+    assert nat.adjust_shift_variance_form(180000, 850000, 180000) == "tiled"   # the root of BASELINE config 5's tree
+    assert nat.adjust_shift_variance_form(50000, 60000, 50000) == "tiled"      # few restricted cells, many pairs
+
+
 def test_adjust_shift_variance_errors(nat):
     z = np.zeros
     with pytest.raises(RuntimeError, match="number of genes do not match up between matrices"):
