@@ -522,7 +522,7 @@ __global__ __launch_bounds__(T) void asv_exact_kernel(const double* __restrict__
 //      crosses the target is collected, sorted and walked; a bin that is still too full is subdivided again.
 // Weights are taken relative to the cell's largest one and kept to 2^-40: a reference cell 28 sigma2 further from the line
 // than the nearest contributes nothing, as in FP64 it would not either beyond 37.  Cells whose walk is decided on the last
-// bits may pick the neighbouring quantile (as with asv_kernel; asv_exact_kernel is the bit-exact form up to 131 072 cells).
+// bits may pick the neighbouring quantile (as with asv_kernel; asv_exact_kernel is the bit-exact form, taken up to 4e7 pairs).
 // ---------------------------------------------------------------------------------------------------
 constexpr int AT_C = 16;        // cells per tile
 constexpr int AT_R = 64;        // streamed cells per step
@@ -933,7 +933,7 @@ void smooth_gaussian_kernel_device(hipStream_t stream, const double* averaged, i
     BMX_LAUNCH_CHECK();
 }
 
-// Which form runs and what it needs.  exact = 1: asv_exact_kernel (bit-exact walk, up to 131 072 restricted cells);
+// Which form runs and what it needs.  exact = 1: asv_exact_kernel (bit-exact walk; up to 131 072 restricted cells and 4e7 pairs);
 // exact = 0: the tiled FP64-MFMA form, `blocks` workgroups with 2 x 16 x (nr1 + nr2) doubles of scratch each, behind them
 // the squared norms of both batches' cells and (vect handed over column-major) a row-major copy of vect.
 // BMX_ASV_FAST=1 forces the tiled form (tests), BMX_ASV_BISECT=1 selects round 2's scalable form (asv_kernel).
