@@ -10,9 +10,11 @@
 // rounded value.  asv_exact_kernel therefore repeats the reference's order of operations literally (distances in
 // parallel, then the sequential logspace_add chains in restrict order, a lexicographic sort of (projection, weight),
 // the sequential walk), with the bit-reproducible exp / log1p of portable_math.hpp: bit for bit what a CPU
-// following the same order of operations with the same arithmetic gets (the tests' checker does).  Its sequential chains cost O(cells x (nr1 + nr2)) dependent steps, fine up to ~1e5 restricted cells;
-// beyond that asv_kernel (parallel sums + sort-free weighted-quantile bisection) takes over and agrees except on those
-// ill-conditioned cells (tests/testthat/test-mnn-correct.R:141,396-399 acknowledge the effect upstream).
+// following the same order of operations with the same arithmetic gets (the tests' checker does).  Its sequential chains
+// cost O(cells x (nr1 + nr2)) dependent steps (1.6 ns per pair): it is taken up to 4e7 pairs per call; beyond that
+// asv_tile_kernel (16-cell tiles on the FP64 matrix cores + a sort-free histogram quantile, 0.04 ns per pair) takes over and
+// agrees except on those ill-conditioned cells (tests/testthat/test-mnn-correct.R:141,396-399 acknowledge the effect
+// upstream).  asv_kernel is round 2's scalable form, kept behind BMX_ASV_BISECT=1.
 #include "bmx_ops.hpp"
 #include "portable_math.hpp"
 
