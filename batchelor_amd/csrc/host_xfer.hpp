@@ -56,7 +56,7 @@ class HostPool {
   private:
     HostPool() {
         unsigned hw = std::thread::hardware_concurrency();
-        int n = hw >= 32 ? 12 : (hw >= 8 ? 6 : (hw >= 4 ? 3 : 0));
+        int n = hw >= 96 ? 24 : (hw >= 32 ? 12 : (hw >= 8 ? 6 : (hw >= 4 ? 3 : 0)));
         if (const char* v = std::getenv("BMX_HOST_THREADS")) n = std::max(0, std::atoi(v) - 1);
         for (int i = 0; i < n; ++i) threads_.emplace_back([this] { loop(); });
         for (auto& t : threads_) t.detach();
@@ -98,7 +98,7 @@ class HostPool {
 };
 
 inline void host_parallel_memcpy(void* dst, const void* src, size_t bytes) {
-    constexpr size_t kPiece = (size_t)2 << 20;
+    constexpr size_t kPiece = (size_t)1 << 20;
     if (bytes <= 2 * kPiece) {
         std::memcpy(dst, src, bytes);
         return;

@@ -533,9 +533,11 @@ constexpr int AT_NB = 2048;     // histogram bins
 constexpr int AT_CAP = 2048;    // collected entries of the crossing bin
 
 __host__ __device__ inline int asv_tile_gp(int g) { return (g + AT_KC - 1) / AT_KC * AT_KC + 2; }
+inline int asv_tile_nkc(int g) { return g <= 128 ? (g + AT_KC - 1) / AT_KC : 0; }  // 0: the staged form
 inline size_t asv_tile_lds_bytes(int g) {
     return ((size_t)2 * AT_C * asv_tile_gp(g) + (size_t)AT_R * (AT_KC + 2) + 8 * AT_C + T) * sizeof(double) +
-           (size_t)AT_NB * sizeof(unsigned long long) + (size_t)AT_CAP * 16;
+           (size_t)AT_NB * sizeof(unsigned long long) + (size_t)AT_CAP * 16 +
+           (size_t)2 * asv_tile_nkc(g) * 8 * 64 * sizeof(double);
 }
 
 // The streamed cells of one call, in stream order (the own batch's restricted cells, then the reference's), as ONE
@@ -564,6 +566,11 @@ __global__ __launch_bounds__(256) void asv_gather_stream(const double* __restric
     }
 }
 
+// NKC > 0: the streamed cells go from global memory straight into the B-operand registers (g <= 32 NKC even): with the k
+// index of an MFMA step permuted so that a lane's eight values of a 32-dimension block are 64 contiguous bytes, every wave
+// runs its 16 streamed cells on its own -- no staging through the LDS, no barrier in the stream, the next step's rows in
+// flight while the current ones multiply.  NKC = 0: the staged form (any g <= 256).
+template <int NKC>
 __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __restrict__ data2, int n2,
                                                      const double* __restrict__ vect, double sigma2, int nr1, int nr2,
                                                      const double* __restrict__ S, const double* __restrict__ snrm,
@@ -586,6 +593,8 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
     unsigned long long* hist = reinterpret_cast<unsigned long long*>(sm + T);  // [NB]
     double* lp = reinterpret_cast<double*>(hist + AT_NB);                       // [CAP] collected projections
     unsigned long long* lw_ = reinterpret_cast<unsigned long long*>(lp + AT_CAP);  // [CAP] and their weights
+    double* cxp = reinterpret_cast<double*>(lw_ + AT_CAP);  // [NKC * 8][64] the cells' coordinates as the lanes read them
+    double* cgp = cxp + (NKC > 0 ? NKC * 8 * 64 : 0);       // [NKC * 8][64] the unit gradients likewise
     __shared__ int sh_cnt, sh_bin;
     __shared__ unsigned long long sh_before;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -631,6 +640,85 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
             cp[i] = sc_proj[(lane >> 4) + 4 * i];
             cn[i] = sc_n[(lane >> 4) + 4 * i];
         }
+        if constexpr (NKC > 0) {
+            typedef double d2a __attribute__((ext_vector_type(2)));
+            // the A operands in the order the lanes read them: step (kc, kk), lane l -> cell l & 15, dimension
+            // 32 kc + 8 (l >> 4) + kk (the same permutation of k as the B registers below)
+            for (int e = tid; e < NKC * 8 * 64; e += T) {
+                const int st = e >> 6, ln = e & 63;
+                const int k = 32 * (st >> 3) + 8 * (ln >> 4) + (st & 7);
+                cxp[e] = cx[(ln & 15) * GP + k];
+                cgp[e] = cg[(ln & 15) * GP + k];
+            }
+            __syncthreads();
+            const int kq = lane >> 4;
+            const bool vec = (g & 1) == 0;
+            auto load_rows = [&](double (&b)[NKC][8], int64_t jrow) __attribute__((always_inline)) {
+                const double* src = jrow < N ? S + jrow * g : nullptr;
+#pragma unroll
+                for (int kc = 0; kc < NKC; ++kc) {
+                    const int kb = 32 * kc + 8 * kq;
+                    if (src && vec && kb + 8 <= g) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const d2a v = *reinterpret_cast<const d2a*>(src + kb + 2 * e);
+                            b[kc][2 * e] = v[0];
+                            b[kc][2 * e + 1] = v[1];
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) b[kc][e] = (src && kb + e < g) ? src[kb + e] : 0.0;
+                    }
+                }
+            };
+            auto step = [&](const double (&b)[NKC][8], double (&bn)[NKC][8], int64_t j0) __attribute__((always_inline)) {
+                const int64_t jo = j0 + 16 * w + (lane & 15);
+                load_rows(bn, jo + AT_R);  // the next step's rows are on their way while this one multiplies
+                const double no = jo < N ? snrm[jo] : 0.0;
+                const int rid = jo < N ? sid[jo] : -1;
+                d4 D = d4{0.0, 0.0, 0.0, 0.0}, P = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kc = 0; kc < NKC; ++kc) {
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) {
+                        const double ax = cxp[(kc * 8 + kk) * 64 + lane];
+                        const double ag = cgp[(kc * 8 + kk) * 64 + lane];
+                        D = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, b[kc][kk], D, 0, 0, 0);
+                        P = __builtin_amdgcn_mfma_f64_16x16x4f64(ag, b[kc][kk], P, 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);  // (keeps the A operands of one block of 32 dimensions live at a time)
+                }
+                if (jo < N) {
+                    const bool own = jo < nr2;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int c = (lane >> 4) + 4 * i;
+                        double pr = P[i];
+                        const double s_ = cp[i] - pr;
+                        double d2 = (cn[i] + no) - 2.0 * D[i] - s_ * s_;
+                        d2 = d2 > 0.0 ? d2 : 0.0;
+                        double lw = -d2 / sigma2;
+                        if (own && rid == c0 + c) {  // the cell itself: log-weight 0, always counted (:80-84)
+                            lw = 0.0;
+                            pr = NEG;
+                        }
+                        // (selects, not branches between the arrays: they stay in registers)
+                        mx2[i] = fmax(mx2[i], own ? lw : NEG);
+                        mx1[i] = fmax(mx1[i], own ? NEG : lw);
+                        lo[i] = fmin(lo[i], own ? POS : pr);
+                        hi[i] = fmax(hi[i], own ? NEG : pr);
+                        SP[(int64_t)c * N + jo] = pr;
+                        SW[(int64_t)c * N + jo] = lw;
+                    }
+                }
+            };
+            double ba[NKC][8], bb[NKC][8];
+            load_rows(ba, (int64_t)16 * w + (lane & 15));
+            for (int64_t j0 = 0; j0 < N; j0 += 2 * AT_R) {
+                step(ba, bb, j0);
+                if (j0 + AT_R < N) step(bb, ba, j0 + AT_R);
+            }
+        } else {
         // staging: 64 rows x 4 segments of 8 doubles per step of 32 dimensions; the step after the one being multiplied is
         // already on its way into registers (16-byte loads where the rows allow), the row pointers one streamed block ahead
         typedef double d2a __attribute__((ext_vector_type(2)));
@@ -698,21 +786,19 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                     double d2 = (cn[i] + no) - 2.0 * D[i] - s_ * s_;
                     d2 = d2 > 0.0 ? d2 : 0.0;
                     double lw = -d2 / sigma2;
-                    if (own) {
-                        if (rid == c0 + c) {  // the cell itself: log-weight 0, always counted (:80-84)
-                            lw = 0.0;
-                            pr = NEG;
-                        }
-                        mx2[i] = fmax(mx2[i], lw);
-                    } else {
-                        mx1[i] = fmax(mx1[i], lw);
-                        lo[i] = fmin(lo[i], pr);
-                        hi[i] = fmax(hi[i], pr);
+                    if (own && rid == c0 + c) {  // the cell itself: log-weight 0, always counted (:80-84)
+                        lw = 0.0;
+                        pr = NEG;
                     }
+                    mx2[i] = fmax(mx2[i], own ? lw : NEG);
+                    mx1[i] = fmax(mx1[i], own ? NEG : lw);
+                    lo[i] = fmin(lo[i], own ? POS : pr);
+                    hi[i] = fmax(hi[i], own ? NEG : pr);
                     SP[(int64_t)c * N + jo] = pr;
                     SW[(int64_t)c * N + jo] = lw;
                 }
             }
+        }
         }
         // per-cell maxima and projection range: over the 16 lanes of a row group, then over the waves
 #pragma unroll
@@ -1008,9 +1094,20 @@ void adjust_shift_variance_device(hipStream_t stream, const double* data1, int g
             hipLaunchKernelGGL(asv_gather_stream, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, stream, data1, data2, g, restrict1, nr1,
                                restrict2, nr2, S, snrm, sid);
         const size_t lds = asv_tile_lds_bytes(g);
-        ensure_dynamic_lds(reinterpret_cast<const void*>(&asv_tile_kernel), lds);
-        hipLaunchKernelGGL(asv_tile_kernel, dim3(blocks), dim3(T), lds, stream, g, data2, n2, vrm, sigma2, nr1, nr2,
-                           (const double*)S, (const double*)snrm, (const int32_t*)sid, out, ws_pairs);
+#define BMX_ASV_TILE(NKC)                                                                                                    \
+    do {                                                                                                                     \
+        ensure_dynamic_lds(reinterpret_cast<const void*>(&asv_tile_kernel<NKC>), lds);                                       \
+        hipLaunchKernelGGL(asv_tile_kernel<NKC>, dim3(blocks), dim3(T), lds, stream, g, data2, n2, vrm, sigma2, nr1, nr2,     \
+                           (const double*)S, (const double*)snrm, (const int32_t*)sid, out, ws_pairs);                       \
+    } while (0)
+        switch (asv_tile_nkc(g)) {
+            case 1: BMX_ASV_TILE(1); break;
+            case 2: BMX_ASV_TILE(2); break;
+            case 3: BMX_ASV_TILE(3); break;
+            case 4: BMX_ASV_TILE(4); break;
+            default: BMX_ASV_TILE(0); break;
+        }
+#undef BMX_ASV_TILE
     }
     BMX_LAUNCH_CHECK();
 }
