@@ -676,17 +676,27 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                 load_rows(bn, jo + AT_R);  // the next step's rows are on their way while this one multiplies
                 const double no = jo < N ? snrm[jo] : 0.0;
                 const int rid = jo < N ? sid[jo] : -1;
-                d4 D = d4{0.0, 0.0, 0.0, 0.0}, P = d4{0.0, 0.0, 0.0, 0.0};
+                // four independent accumulator pairs (k-steps round robin): a dependent v_mfma_f64_16x16x4_f64 waits for its
+                // predecessor's result, two chains left the matrix pipe idle most of the time
+                d4 Dq[4], Pq[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) Dq[a] = Pq[a] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int kc = 0; kc < NKC; ++kc) {
 #pragma unroll
                     for (int kk = 0; kk < 8; ++kk) {
                         const double ax = cxp[(kc * 8 + kk) * 64 + lane];
                         const double ag = cgp[(kc * 8 + kk) * 64 + lane];
-                        D = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, b[kc][kk], D, 0, 0, 0);
-                        P = __builtin_amdgcn_mfma_f64_16x16x4f64(ag, b[kc][kk], P, 0, 0, 0);
+                        Dq[kk & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, b[kc][kk], Dq[kk & 3], 0, 0, 0);
+                        Pq[kk & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(ag, b[kc][kk], Pq[kk & 3], 0, 0, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);  // (keeps the A operands of one block of 32 dimensions live at a time)
+                }
+                d4 D, P;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    D[i] = (Dq[0][i] + Dq[1][i]) + (Dq[2][i] + Dq[3][i]);
+                    P[i] = (Pq[0][i] + Pq[1][i]) + (Pq[2][i] + Pq[3][i]);
                 }
                 if (jo < N) {
                     const bool own = jo < nr2;
