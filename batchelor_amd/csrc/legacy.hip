@@ -599,8 +599,13 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
     __shared__ unsigned long long sh_before;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t N = (int64_t)nr1 + nr2;  // streamed cells: the own batch's restricted cells first, then the reference's
-    double* SP = scratch + (int64_t)blockIdx.x * 2 * AT_C * N;  // [16][N] projections
-    double* SW = SP + (int64_t)AT_C * N;                         // [16][N] log-weights
+    // the tile's scratch: per block of 64 streamed cells, 16 rows (cells) of 64 values -- a step of the stream writes ONE
+    // contiguous 8 KB piece of each array (the [cell][N] layout of the first version wrote 32 rows 8 MB apart per step and
+    // spent its time in address translation), and a cell's row is 512-byte pieces 8 KB apart, read by whole waves
+    const int64_t Npad = (N + AT_R - 1) / AT_R * AT_R;
+    double* SP = scratch + (int64_t)blockIdx.x * 2 * AT_C * Npad;  // projections
+    double* SW = SP + (int64_t)AT_C * Npad;                         // log-weights
+    auto at = [](int c, int64_t j) { return (((j >> 6) * AT_C + c) << 6) + (j & 63); };
     const int ntiles = (n2 + AT_C - 1) / AT_C;
     const double NEG = -__builtin_inf(), POS = __builtin_inf();
 
@@ -717,8 +722,8 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                         mx1[i] = fmax(mx1[i], own ? NEG : lw);
                         lo[i] = fmin(lo[i], own ? POS : pr);
                         hi[i] = fmax(hi[i], own ? NEG : pr);
-                        SP[(int64_t)c * N + jo] = pr;
-                        SW[(int64_t)c * N + jo] = lw;
+                        SP[at(c, jo)] = pr;
+                        SW[at(c, jo)] = lw;
                     }
                 }
             };
@@ -804,8 +809,8 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                     mx1[i] = fmax(mx1[i], own ? NEG : lw);
                     lo[i] = fmin(lo[i], own ? POS : pr);
                     hi[i] = fmax(hi[i], own ? NEG : pr);
-                    SP[(int64_t)c * N + jo] = pr;
-                    SW[(int64_t)c * N + jo] = lw;
+                    SP[at(c, jo)] = pr;
+                    SW[at(c, jo)] = lw;
                 }
             }
         }
@@ -851,17 +856,19 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
         // ---- cell by cell: own-batch probability, then the weighted quantile of the reference projections
         for (int c = 0; c < AT_C && c0 + c < n2; ++c) {
-            const double* p2 = SP + (int64_t)c * N;
-            const double* w2 = SW + (int64_t)c * N;
+            auto p2 = [&](int64_t s_) { return SP[at(c, s_)]; };        // own batch: streamed cells [0, nr2)
+            auto w2 = [&](int64_t s_) { return SW[at(c, s_)]; };
+            auto p1 = [&](int64_t o_) { return SP[at(c, nr2 + o_)]; };  // reference batch: [nr2, N)
+            auto w1 = [&](int64_t o_) { return SW[at(c, nr2 + o_)]; };
             const double curproj = sc_proj[c], l2 = sc_l2[c];
             double prob2 = 0.0;
             if (nr2 > 0) {
                 const double mx = sc_mx2[c];
                 double below = 0.0, all = 0.0;
                 for (int s = tid; s < nr2; s += T) {
-                    const double ww = exp(w2[s] - mx);
+                    const double ww = exp(w2(s) - mx);
                     all += ww;
-                    if (!(p2[s] > curproj)) below += ww;
+                    if (!(p2(s) > curproj)) below += ww;
                 }
                 below = block_sum(below, sm);
                 all = block_sum(all, sm);
@@ -869,8 +876,6 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
             }
             double ref_quan = __builtin_nan("");
             if (nr1 > 0) {
-                const double* p1 = p2 + nr2;
-                const double* w1 = w2 + nr2;
                 const double mx = sc_mx1[c];
                 const double FIX = 1099511627776.0;  // 2^40
                 double blo = sc_lo[c], bhi = sc_hi[c];  // projections still in play: [blo, bhi]
@@ -883,11 +888,11 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                     __syncthreads();
                     const double scale = bhi > blo ? (double)AT_NB / (bhi - blo) : 0.0;
                     for (int o = tid; o < nr1; o += T) {
-                        const double pr = p1[o];
+                        const double pr = p1(o);
                         if (pr < blo || pr > bhi) continue;
                         int b = (int)((pr - blo) * scale);
                         b = b < 0 ? 0 : (b > AT_NB - 1 ? AT_NB - 1 : b);
-                        atomicAdd(&hist[b], (unsigned long long)(exp(w1[o] - mx) * FIX));
+                        atomicAdd(&hist[b], (unsigned long long)(exp(w1(o) - mx) * FIX));
                     }
                     __syncthreads();
                     if (tid == 0) {
@@ -919,7 +924,7 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                     before = sh_before;
                     // the projections that fall into bin `at`
                     for (int o = tid; o < nr1; o += T) {
-                        const double pr = p1[o];
+                        const double pr = p1(o);
                         if (pr < blo || pr > bhi) continue;
                         int b = (int)((pr - blo) * scale);
                         b = b < 0 ? 0 : (b > AT_NB - 1 ? AT_NB - 1 : b);
@@ -927,7 +932,7 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                         const int pos = atomicAdd(&sh_cnt, 1);
                         if (pos < AT_CAP) {
                             lp[pos] = pr;
-                            lw_[pos] = (unsigned long long)(exp(w1[o] - mx) * FIX);
+                            lw_[pos] = (unsigned long long)(exp(w1(o) - mx) * FIX);
                         }
                     }
                     __syncthreads();
@@ -989,7 +994,7 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                     ref_quan = bhi;  // (provisional: the quantile lies in [blo, bhi]; final unless another round refines it)
                     unsigned long long mine = 0;
                     for (int o = tid; o < nr1; o += T)
-                        if (p1[o] < blo) mine += (unsigned long long)(exp(w1[o] - mx) * FIX);
+                        if (p1(o) < blo) mine += (unsigned long long)(exp(w1(o) - mx) * FIX);
                     // integer sums: any order gives the same total
                     __syncthreads();
                     unsigned long long* smu = reinterpret_cast<unsigned long long*>(sm);
@@ -1055,8 +1060,8 @@ size_t adjust_shift_variance_scratch(int n2, int nr1, int nr2, int* blocks, int*
         *blocks = (int)std::max<size_t>(1, std::min<size_t>({(size_t)std::max(n2, 1), (size_t)1024, ((size_t)1 << 27) / per_block}));
         return per_block * (size_t)*blocks;
     }
-    const size_t N = (size_t)nr1 + (size_t)nr2;
-    const size_t per_block = (size_t)2 * AT_C * std::max<size_t>(N, 1);
+    const size_t N = ((size_t)nr1 + (size_t)nr2 + AT_R - 1) / AT_R * AT_R;  // (padded to whole steps of the stream)
+    const size_t per_block = (size_t)2 * AT_C * std::max<size_t>(N, AT_R);
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
     const size_t budget = std::max<size_t>((size_t)1 << 27, free_b / 2 / sizeof(double));  // half of what is free
