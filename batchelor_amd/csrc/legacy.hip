@@ -865,10 +865,22 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
             if (nr2 > 0) {
                 const double mx = sc_mx2[c];
                 double below = 0.0, all = 0.0;
-                for (int s = tid; s < nr2; s += T) {
-                    const double ww = exp(w2(s) - mx);
-                    all += ww;
-                    if (!(p2(s) > curproj)) below += ww;
+                // (eight elements per thread in flight: one at a time, every visit waits a full round trip to the scratch)
+                for (int s0 = tid; s0 < nr2; s0 += 8 * T) {
+                    double pr[8], lw[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int s_ = s0 + u * T;
+                        const bool ok = s_ < nr2;
+                        pr[u] = ok ? p2(s_) : POS;
+                        lw[u] = ok ? w2(s_) : NEG;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const double ww = exp(lw[u] - mx);  // exp(-inf) = 0 for the padding
+                        all += ww;
+                        if (!(pr[u] > curproj)) below += ww;
+                    }
                 }
                 below = block_sum(below, sm);
                 all = block_sum(all, sm);
@@ -887,12 +899,22 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                     if (tid == 0) sh_cnt = 0;
                     __syncthreads();
                     const double scale = bhi > blo ? (double)AT_NB / (bhi - blo) : 0.0;
-                    for (int o = tid; o < nr1; o += T) {
-                        const double pr = p1(o);
-                        if (pr < blo || pr > bhi) continue;
-                        int b = (int)((pr - blo) * scale);
-                        b = b < 0 ? 0 : (b > AT_NB - 1 ? AT_NB - 1 : b);
-                        atomicAdd(&hist[b], (unsigned long long)(exp(w1(o) - mx) * FIX));
+                    for (int o0 = tid; o0 < nr1; o0 += 8 * T) {
+                        double pr[8], lw[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int o = o0 + u * T;
+                            const bool ok = o < nr1;
+                            pr[u] = ok ? p1(o) : __builtin_nan("");
+                            lw[u] = ok ? w1(o) : NEG;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            if (!(pr[u] >= blo && pr[u] <= bhi)) continue;  // (a NaN pad fails both)
+                            int b = (int)((pr[u] - blo) * scale);
+                            b = b < 0 ? 0 : (b > AT_NB - 1 ? AT_NB - 1 : b);
+                            atomicAdd(&hist[b], (unsigned long long)(exp(lw[u] - mx) * FIX));
+                        }
                     }
                     __syncthreads();
                     if (tid == 0) {
@@ -923,16 +945,24 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                     }
                     before = sh_before;
                     // the projections that fall into bin `at`
-                    for (int o = tid; o < nr1; o += T) {
-                        const double pr = p1(o);
-                        if (pr < blo || pr > bhi) continue;
-                        int b = (int)((pr - blo) * scale);
-                        b = b < 0 ? 0 : (b > AT_NB - 1 ? AT_NB - 1 : b);
-                        if (b != at) continue;
-                        const int pos = atomicAdd(&sh_cnt, 1);
-                        if (pos < AT_CAP) {
-                            lp[pos] = pr;
-                            lw_[pos] = (unsigned long long)(exp(w1(o) - mx) * FIX);
+                    for (int o0 = tid; o0 < nr1; o0 += 8 * T) {
+                        double pr[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int o = o0 + u * T;
+                            pr[u] = o < nr1 ? p1(o) : __builtin_nan("");
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            if (!(pr[u] >= blo && pr[u] <= bhi)) continue;
+                            int b = (int)((pr[u] - blo) * scale);
+                            b = b < 0 ? 0 : (b > AT_NB - 1 ? AT_NB - 1 : b);
+                            if (b != at) continue;
+                            const int pos = atomicAdd(&sh_cnt, 1);
+                            if (pos < AT_CAP) {
+                                lp[pos] = pr[u];
+                                lw_[pos] = (unsigned long long)(exp(w1(o0 + u * T) - mx) * FIX);
+                            }
                         }
                     }
                     __syncthreads();
@@ -993,8 +1023,19 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                     bhi = fmin(bhi, nhi + margin);
                     ref_quan = bhi;  // (provisional: the quantile lies in [blo, bhi]; final unless another round refines it)
                     unsigned long long mine = 0;
-                    for (int o = tid; o < nr1; o += T)
-                        if (p1(o) < blo) mine += (unsigned long long)(exp(w1(o) - mx) * FIX);
+                    for (int o0 = tid; o0 < nr1; o0 += 8 * T) {
+                        double pr[8], lw[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int o = o0 + u * T;
+                            const bool ok = o < nr1;
+                            pr[u] = ok ? p1(o) : POS;
+                            lw[u] = ok ? w1(o) : NEG;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (pr[u] < blo) mine += (unsigned long long)(exp(lw[u] - mx) * FIX);
+                    }
                     // integer sums: any order gives the same total
                     __syncthreads();
                     unsigned long long* smu = reinterpret_cast<unsigned long long*>(sm);
