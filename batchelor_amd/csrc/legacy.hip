@@ -532,31 +532,38 @@ constexpr int AT_KC = 32;       // dimensions staged per step
 constexpr int AT_NB = 2048;     // histogram bins
 constexpr int AT_CAP = 2048;    // collected entries of the crossing bin
 
+constexpr int AT_NP = 2 * AT_R; // the stream is padded to whole pairs of steps (zero rows)
+
 __host__ __device__ inline int asv_tile_gp(int g) { return (g + AT_KC - 1) / AT_KC * AT_KC + 2; }
 inline int asv_tile_nkc(int g) { return g <= 128 ? (g + AT_KC - 1) / AT_KC : 0; }  // 0: the staged form
+// row stride of the gathered stream: whole 32-dimension blocks (zero filled) for the register-streamed form
+inline int asv_tile_gs(int g) { return g <= 128 ? asv_tile_nkc(g) * AT_KC : g; }
+inline size_t asv_tile_npad(size_t N) { return std::max<size_t>((N + AT_NP - 1) / AT_NP * AT_NP, AT_NP); }
 inline size_t asv_tile_lds_bytes(int g) {
-    return ((size_t)2 * AT_C * asv_tile_gp(g) + (size_t)AT_R * (AT_KC + 2) + 8 * AT_C + T) * sizeof(double) +
+    const int nkc = asv_tile_nkc(g);
+    return ((size_t)2 * AT_C * asv_tile_gp(g) + (nkc == 0 ? (size_t)AT_R * (AT_KC + 2) : 0) + 8 * AT_C + T) * sizeof(double) +
            (size_t)AT_NB * sizeof(unsigned long long) + (size_t)AT_CAP * 16 +
-           (size_t)2 * asv_tile_nkc(g) * 8 * 64 * sizeof(double);
+           (nkc > 2 ? (size_t)2 * nkc * 8 * 64 * sizeof(double) : 0);
 }
 
 // The streamed cells of one call, in stream order (the own batch's restricted cells, then the reference's), as ONE
 // contiguous matrix with their squared norms and -- for the own batch -- their cell ids: the tile kernel then reads plain
 // consecutive rows (coalesced, prefetchable any distance ahead) instead of chasing restrict[] -> row -> norm per step.
 __global__ __launch_bounds__(256) void asv_gather_stream(const double* __restrict__ data1, const double* __restrict__ data2,
-                                                         int g, const int32_t* __restrict__ r1, int nr1,
-                                                         const int32_t* __restrict__ r2, int nr2, double* __restrict__ S,
-                                                         double* __restrict__ snrm, int32_t* __restrict__ sid) {
+                                                         int g, int gs, const int32_t* __restrict__ r1, int nr1,
+                                                         const int32_t* __restrict__ r2, int nr2, int64_t npad,
+                                                         double* __restrict__ S, double* __restrict__ snrm,
+                                                         int32_t* __restrict__ sid) {
     const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (j >= (int64_t)nr1 + nr2) return;
-    const bool own = j < nr2;
-    const int rid = own ? r2[j] : r1[j - nr2];
-    const double* src = (own ? data2 : data1) + (int64_t)rid * g;
+    if (j >= npad) return;
+    const bool live = j < (int64_t)nr1 + nr2, own = j < nr2;
+    const int rid = !live ? -1 : (own ? r2[j] : r1[j - nr2]);
+    const double* src = live ? (own ? data2 : data1) + (int64_t)rid * g : nullptr;
     double sq = 0.0;
-    for (int k = lane; k < g; k += 64) {
-        const double v = src[k];
-        S[j * g + k] = v;
+    for (int k = lane; k < gs; k += 64) {  // (rows of gs >= g values and npad >= nr1 + nr2 rows: zeros beyond the data)
+        const double v = live && k < g ? src[k] : 0.0;
+        S[j * gs + k] = v;
         sq += v * v;
     }
     for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
@@ -580,8 +587,8 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
     const int GP = asv_tile_gp(g);
     double* cx = reinterpret_cast<double*>(smem_raw);  // [16][GP] the tile's cells
     double* cg = cx + AT_C * GP;                        // [16][GP] their unit gradients
-    double* rs = cg + AT_C * GP;                        // [64][KC + 2] a step of streamed cells
-    double* sc_proj = rs + AT_R * (AT_KC + 2);          // per cell: own projection, |x|^2, |vect|, maxima, projection range
+    double* rs = cg + AT_C * GP;                        // [64][KC + 2] a step of streamed cells (staged form only)
+    double* sc_proj = rs + (NKC == 0 ? AT_R * (AT_KC + 2) : 0);  // per cell: own projection, |x|^2, |vect|, maxima, projection range
     double* sc_n = sc_proj + AT_C;
     double* sc_l2 = sc_n + AT_C;
     double* sc_mx1 = sc_l2 + AT_C;
@@ -594,7 +601,7 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
     double* lp = reinterpret_cast<double*>(hist + AT_NB);                       // [CAP] collected projections
     unsigned long long* lw_ = reinterpret_cast<unsigned long long*>(lp + AT_CAP);  // [CAP] and their weights
     double* cxp = reinterpret_cast<double*>(lw_ + AT_CAP);  // [NKC * 8][64] the cells' coordinates as the lanes read them
-    double* cgp = cxp + (NKC > 0 ? NKC * 8 * 64 : 0);       // [NKC * 8][64] the unit gradients likewise
+    double* cgp = cxp + (NKC > 2 ? NKC * 8 * 64 : 0);       // [NKC * 8][64] the unit gradients likewise (NKC > 2)
     __shared__ int sh_cnt, sh_bin;
     __shared__ unsigned long long sh_before;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -602,7 +609,7 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
     // the tile's scratch: per block of 64 streamed cells, 16 rows (cells) of 64 values -- a step of the stream writes ONE
     // contiguous 8 KB piece of each array (the [cell][N] layout of the first version wrote 32 rows 8 MB apart per step and
     // spent its time in address translation), and a cell's row is 512-byte pieces 8 KB apart, read by whole waves
-    const int64_t Npad = (N + AT_R - 1) / AT_R * AT_R;
+    const int64_t Npad = N <= AT_NP ? AT_NP : (N + AT_NP - 1) / AT_NP * AT_NP;
     double* SP = scratch + (int64_t)blockIdx.x * 2 * AT_C * Npad;  // projections
     double* SW = SP + (int64_t)AT_C * Npad;                         // log-weights
     auto at = [](int c, int64_t j) { return (((j >> 6) * AT_C + c) << 6) + (j & 63); };
@@ -647,91 +654,100 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
         }
         if constexpr (NKC > 0) {
             typedef double d2a __attribute__((ext_vector_type(2)));
-            // the A operands in the order the lanes read them: step (kc, kk), lane l -> cell l & 15, dimension
-            // 32 kc + 8 (l >> 4) + kk (the same permutation of k as the B registers below)
-            for (int e = tid; e < NKC * 8 * 64; e += T) {
-                const int st = e >> 6, ln = e & 63;
-                const int k = 32 * (st >> 3) + 8 * (ln >> 4) + (st & 7);
-                cxp[e] = cx[(ln & 15) * GP + k];
-                cgp[e] = cg[(ln & 15) * GP + k];
-            }
-            __syncthreads();
+            constexpr int GS = NKC * AT_KC;  // row stride of the stream (zero filled beyond g)
             const int kq = lane >> 4;
-            const bool vec = (g & 1) == 0;
-            auto load_rows = [&](double (&b)[NKC][8], int64_t jrow) __attribute__((always_inline)) {
-                const double* src = jrow < N ? S + jrow * g : nullptr;
+            // the A operands of MFMA step (kc, kk): lane l holds cell l & 15, dimension 32 kc + 8 (l >> 4) + kk -- the k
+            // index of a step is permuted so that the B operands of a 32-dimension block are 64 contiguous bytes of a row.
+            // Up to 64 dimensions they live in registers for the whole stream, beyond that in the LDS in lane order.
+            double axr[NKC <= 2 ? NKC * 8 : 1], agr[NKC <= 2 ? NKC * 8 : 1];
+            if constexpr (NKC <= 2) {
 #pragma unroll
-                for (int kc = 0; kc < NKC; ++kc) {
-                    const int kb = 32 * kc + 8 * kq;
-                    if (src && vec && kb + 8 <= g) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const d2a v = *reinterpret_cast<const d2a*>(src + kb + 2 * e);
-                            b[kc][2 * e] = v[0];
-                            b[kc][2 * e + 1] = v[1];
-                        }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) b[kc][e] = (src && kb + e < g) ? src[kb + e] : 0.0;
-                    }
+                for (int st = 0; st < NKC * 8; ++st) {
+                    const int k = 32 * (st >> 3) + 8 * kq + (st & 7);
+                    axr[st] = cx[(lane & 15) * GP + k];
+                    agr[st] = cg[(lane & 15) * GP + k];
                 }
+            } else {
+                for (int e = tid; e < NKC * 8 * 64; e += T) {
+                    const int st = e >> 6, ln = e & 63;
+                    const int k = 32 * (st >> 3) + 8 * (ln >> 4) + (st & 7);
+                    cxp[e] = cx[(ln & 15) * GP + k];
+                    cgp[e] = cg[(ln & 15) * GP + k];
+                }
+                __syncthreads();
+            }
+            // this lane's streamed cell of step j0 is j0 + jl; rows, norms, ids and scratch are padded to whole pairs of
+            // steps: no bounds checks (and no divergent branches) in the stream
+            const int jl = 16 * w + (lane & 15);
+            const double* srow = S + (int64_t)jl * GS + 8 * kq;
+            double* spo = SP + at(kq, jl);
+            double* swo = SW + at(kq, jl);
+            auto load_rows = [&](double (&b)[NKC][8], const double* src) __attribute__((always_inline)) {
+#pragma unroll
+                for (int kc = 0; kc < NKC; ++kc)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const d2a v = *reinterpret_cast<const d2a*>(src + 32 * kc + 2 * e);
+                        b[kc][2 * e] = v[0];
+                        b[kc][2 * e + 1] = v[1];
+                    }
             };
             auto step = [&](const double (&b)[NKC][8], double (&bn)[NKC][8], int64_t j0) __attribute__((always_inline)) {
-                const int64_t jo = j0 + 16 * w + (lane & 15);
-                load_rows(bn, jo + AT_R);  // the next step's rows are on their way while this one multiplies
-                const double no = jo < N ? snrm[jo] : 0.0;
-                const int rid = jo < N ? sid[jo] : -1;
-                // four independent accumulator pairs (k-steps round robin): a dependent v_mfma_f64_16x16x4_f64 waits for its
-                // predecessor's result, two chains left the matrix pipe idle most of the time
-                d4 Dq[4], Pq[4];
+                const int64_t jo = j0 + jl;
+                // the next step's rows are on their way while this one multiplies (the last step asks for its own again)
+                load_rows(bn, srow + (j0 + AT_R < Npad ? (j0 + AT_R) : j0) * GS);
+                const double no = snrm[jo];
+                const int rid = sid[jo];
+                // two accumulator pairs (k-steps alternate): D and P chains are independent of each other as well
+                d4 Dq[2], Pq[2];
 #pragma unroll
-                for (int a = 0; a < 4; ++a) Dq[a] = Pq[a] = d4{0.0, 0.0, 0.0, 0.0};
+                for (int a = 0; a < 2; ++a) Dq[a] = Pq[a] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int kc = 0; kc < NKC; ++kc) {
 #pragma unroll
                     for (int kk = 0; kk < 8; ++kk) {
-                        const double ax = cxp[(kc * 8 + kk) * 64 + lane];
-                        const double ag = cgp[(kc * 8 + kk) * 64 + lane];
-                        Dq[kk & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, b[kc][kk], Dq[kk & 3], 0, 0, 0);
-                        Pq[kk & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(ag, b[kc][kk], Pq[kk & 3], 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);  // (keeps the A operands of one block of 32 dimensions live at a time)
-                }
-                d4 D, P;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    D[i] = (Dq[0][i] + Dq[1][i]) + (Dq[2][i] + Dq[3][i]);
-                    P[i] = (Pq[0][i] + Pq[1][i]) + (Pq[2][i] + Pq[3][i]);
-                }
-                if (jo < N) {
-                    const bool own = jo < nr2;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int c = (lane >> 4) + 4 * i;
-                        double pr = P[i];
-                        const double s_ = cp[i] - pr;
-                        double d2 = (cn[i] + no) - 2.0 * D[i] - s_ * s_;
-                        d2 = d2 > 0.0 ? d2 : 0.0;
-                        double lw = -d2 / sigma2;
-                        if (own && rid == c0 + c) {  // the cell itself: log-weight 0, always counted (:80-84)
-                            lw = 0.0;
-                            pr = NEG;
+                        double ax, ag;
+                        if constexpr (NKC <= 2) {
+                            ax = axr[kc * 8 + kk];
+                            ag = agr[kc * 8 + kk];
+                        } else {
+                            ax = cxp[(kc * 8 + kk) * 64 + lane];
+                            ag = cgp[(kc * 8 + kk) * 64 + lane];
                         }
-                        // (selects, not branches between the arrays: they stay in registers)
-                        mx2[i] = fmax(mx2[i], own ? lw : NEG);
-                        mx1[i] = fmax(mx1[i], own ? NEG : lw);
-                        lo[i] = fmin(lo[i], own ? POS : pr);
-                        hi[i] = fmax(hi[i], own ? NEG : pr);
-                        SP[at(c, jo)] = pr;
-                        SW[at(c, jo)] = lw;
+                        Dq[kk & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, b[kc][kk], Dq[kk & 1], 0, 0, 0);
+                        Pq[kk & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ag, b[kc][kk], Pq[kk & 1], 0, 0, 0);
                     }
+                    if constexpr (NKC > 2)
+                        __builtin_amdgcn_sched_barrier(0);  // (keeps the A operands of one block of 32 dimensions live at a time)
+                }
+                const bool own = jo < nr2, ref = !own && jo < N;
+                double* sp_ = spo + (j0 >> 6) * (AT_C * 64);
+                double* sw_ = swo + (j0 >> 6) * (AT_C * 64);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {  // this lane: streamed cell jo, tile cells (lane >> 4) + 4 i
+                    double pr = Pq[0][i] + Pq[1][i];
+                    const double dd = Dq[0][i] + Dq[1][i];
+                    const double s_ = cp[i] - pr;
+                    double d2 = (cn[i] + no) - 2.0 * dd - s_ * s_;
+                    d2 = d2 > 0.0 ? d2 : 0.0;
+                    double lw = -d2 / sigma2;
+                    const bool self = rid == c0 + kq + 4 * i;  // the cell itself: log-weight 0, always counted (:80-84)
+                    lw = self ? 0.0 : lw;
+                    pr = self ? NEG : pr;
+                    // (selects, not branches: the padding rows of the stream belong to neither batch)
+                    mx2[i] = fmax(mx2[i], own ? lw : NEG);
+                    mx1[i] = fmax(mx1[i], ref ? lw : NEG);
+                    lo[i] = fmin(lo[i], ref ? pr : POS);
+                    hi[i] = fmax(hi[i], ref ? pr : NEG);
+                    sp_[i * 4 * 64] = pr;
+                    sw_[i * 4 * 64] = lw;
                 }
             };
             double ba[NKC][8], bb[NKC][8];
-            load_rows(ba, (int64_t)16 * w + (lane & 15));
-            for (int64_t j0 = 0; j0 < N; j0 += 2 * AT_R) {
+            load_rows(ba, srow);
+            for (int64_t j0 = 0; j0 < Npad; j0 += 2 * AT_R) {
                 step(ba, bb, j0);
-                if (j0 + AT_R < N) step(bb, ba, j0 + AT_R);
+                step(bb, ba, j0 + AT_R);
             }
         } else {
         // staging: 64 rows x 4 segments of 8 doubles per step of 32 dimensions; the step after the one being multiplied is
@@ -855,6 +871,9 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
         // (the scratch rows were written by this block and are read by it: same CU, through the L2)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
         // ---- cell by cell: own-batch probability, then the weighted quantile of the reference projections
+#ifdef BMX_ASV_EXP_NOCELL
+        if (g < 0)
+#endif
         for (int c = 0; c < AT_C && c0 + c < n2; ++c) {
             auto p2 = [&](int64_t s_) { return SP[at(c, s_)]; };        // own batch: streamed cells [0, nr2)
             auto w2 = [&](int64_t s_) { return SW[at(c, s_)]; };
@@ -887,7 +906,11 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                 prob2 = (below > 0.0 ? mx + log(below) : 0.0) - (mx + log(all));
             }
             double ref_quan = __builtin_nan("");
+#ifdef BMX_ASV_EXP_NOQUANT
+            if (g < 0) {
+#else
             if (nr1 > 0) {
+#endif
                 const double mx = sc_mx1[c];
                 const double FIX = 1099511627776.0;  // 2^40
                 double blo = sc_lo[c], bhi = sc_hi[c];  // projections still in play: [blo, bhi]
@@ -1101,8 +1124,8 @@ size_t adjust_shift_variance_scratch(int n2, int nr1, int nr2, int* blocks, int*
         *blocks = (int)std::max<size_t>(1, std::min<size_t>({(size_t)std::max(n2, 1), (size_t)1024, ((size_t)1 << 27) / per_block}));
         return per_block * (size_t)*blocks;
     }
-    const size_t N = ((size_t)nr1 + (size_t)nr2 + AT_R - 1) / AT_R * AT_R;  // (padded to whole steps of the stream)
-    const size_t per_block = (size_t)2 * AT_C * std::max<size_t>(N, AT_R);
+    const size_t N = asv_tile_npad((size_t)nr1 + (size_t)nr2);  // (padded to whole pairs of steps of the stream)
+    const size_t per_block = (size_t)2 * AT_C * N;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
     const size_t budget = std::max<size_t>((size_t)1 << 27, free_b / 2 / sizeof(double));  // half of what is free
@@ -1114,8 +1137,8 @@ size_t adjust_shift_variance_scratch(int n2, int nr1, int nr2, int* blocks, int*
 // extra doubles the tiled form keeps behind its scratch: norms of both batches, and vect row-major if it is not
 size_t adjust_shift_variance_extra(int g, int nr1, int nr2, int n2, int vect_row_major) {
     // (the nr1 + nr2 streamed cells: their rows, norms, ids; a row-major copy of vect if it came column-major)
-    const size_t N = (size_t)nr1 + (size_t)nr2;
-    return N * g + N + (N + 1) / 2 + 2 + (vect_row_major ? 0 : (size_t)n2 * g) + 16;
+    const size_t N = asv_tile_npad((size_t)nr1 + (size_t)nr2);
+    return N * asv_tile_gs(g) + N + (N + 1) / 2 + 2 + (vect_row_major ? 0 : (size_t)n2 * g) + 16;
 }
 
 void adjust_shift_variance_device(hipStream_t stream, const double* data1, int g, int n1, const double* data2, int n2,
@@ -1136,9 +1159,10 @@ void adjust_shift_variance_device(hipStream_t stream, const double* data1, int g
     } else {
         if (g > 256) throw Error(BMX_ERR_ARG, "adjust_shift_variance: more than 256 dimensions at this size are not supported");
         double* extra = ws_pairs + main_doubles;
-        const int64_t N = (int64_t)nr1 + nr2;
-        double* S = extra;                      // [N][g] the streamed cells
-        double* snrm = S + N * g;               // [N]
+        const int64_t N = (int64_t)asv_tile_npad((size_t)nr1 + (size_t)nr2);
+        const int gs = asv_tile_gs(g);
+        double* S = extra;                      // [N][gs] the streamed cells, zero rows up to whole pairs of steps
+        double* snrm = S + N * gs;              // [N]
         int32_t* sid = reinterpret_cast<int32_t*>(snrm + N);  // [N]
         const double* vrm = vect;
         if (!vect_row_major) {
@@ -1146,9 +1170,8 @@ void adjust_shift_variance_device(hipStream_t stream, const double* data1, int g
             transpose_cm_to_rm(stream, vect, n2, g, t);
             vrm = t;
         }
-        if (N > 0)
-            hipLaunchKernelGGL(asv_gather_stream, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, stream, data1, data2, g, restrict1, nr1,
-                               restrict2, nr2, S, snrm, sid);
+        hipLaunchKernelGGL(asv_gather_stream, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, stream, data1, data2, g, gs, restrict1,
+                           nr1, restrict2, nr2, N, S, snrm, sid);
         const size_t lds = asv_tile_lds_bytes(g);
 #define BMX_ASV_TILE(NKC)                                                                                                    \
     do {                                                                                                                     \
