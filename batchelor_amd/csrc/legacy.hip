@@ -531,6 +531,7 @@ constexpr int AT_R = 64;        // streamed cells per step
 constexpr int AT_KC = 32;       // dimensions staged per step
 constexpr int AT_NB = 2048;     // histogram bins
 constexpr int AT_CAP = 2048;    // collected entries of the crossing bin
+constexpr int AT_U = 8;         // scratch elements per thread and batch in the per-cell passes (two batches in flight)
 
 constexpr int AT_NP = 2 * AT_R; // the stream is padded to whole pairs of steps (zero rows)
 
@@ -544,6 +545,43 @@ inline size_t asv_tile_lds_bytes(int g) {
     return ((size_t)2 * AT_C * asv_tile_gp(g) + (nkc == 0 ? (size_t)AT_R * (AT_KC + 2) : 0) + 8 * AT_C + T) * sizeof(double) +
            (size_t)AT_NB * sizeof(unsigned long long) + (size_t)AT_CAP * 16 +
            (nkc > 2 ? (size_t)2 * nkc * 8 * 64 * sizeof(double) : 0);
+}
+
+// One cell's scratch row, elements [jstart, jstart + n) of the stream, past the block: thread t visits jstart + t,
+// + T, ... in batches of AT_U, the next batch on its way while the current one is consumed (one wave per SIMD: nothing
+// else hides the round trip to the scratch).  Straight-line code: every load is issued (block numbers clamped to the
+// row's last block) and `proc` gets the element number to tell the ones beyond n -- with the loads or their first use
+// under per-element branches the compiler waited for ALL outstanding loads before the first use: no overlap at all.
+// So `proc` should select, not branch, on what it was given.
+// Layout (see asv_tile_kernel): element j of cell slot c sits at (j >> 6) * 1024 + ((c + (j >> 6) + rot) & 15) * 64 + (j & 63).
+template <bool WITH_W, class Proc>
+__device__ __forceinline__ void asv_row_scan(const double* __restrict__ P, const double* __restrict__ W, int64_t jstart,
+                                             int n, int crot, int last_block, int tid, Proc proc) {
+    const int64_t jt = jstart + tid;
+    const int jlow = (int)(jt & 63), jb_t = (int)(jt >> 6);
+    double pa[AT_U], wa[AT_U], pb[AT_U], wb[AT_U];
+    auto fetch = [&](double (&p)[AT_U], double (&w)[AT_U], int o0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < AT_U; ++u) {
+            const int o = o0 + u * T;  // (o - tid is a multiple of T = 4 blocks)
+            int jb = jb_t + ((o - tid) >> 6);
+            jb = jb < last_block ? jb : last_block;
+            const int64_t off = (int64_t)jb * (AT_C * 64) + (((crot + jb) & (AT_C - 1)) << 6) + jlow;
+            p[u] = P[off];
+            w[u] = WITH_W ? W[off] : 0.0;
+        }
+    };
+    auto consume = [&](const double (&p)[AT_U], const double (&w)[AT_U], int o0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < AT_U; ++u) proc(p[u], w[u], o0 + u * T);
+    };
+    fetch(pa, wa, tid);
+    for (int o0 = tid; o0 < n; o0 += 2 * AT_U * T) {
+        fetch(pb, wb, o0 + AT_U * T);
+        consume(pa, wa, o0);
+        fetch(pa, wa, o0 + 2 * AT_U * T);
+        consume(pb, wb, o0 + AT_U * T);
+    }
 }
 
 // The streamed cells of one call, in stream order (the own batch's restricted cells, then the reference's), as ONE
@@ -612,7 +650,10 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
     const int64_t Npad = N <= AT_NP ? AT_NP : (N + AT_NP - 1) / AT_NP * AT_NP;
     double* SP = scratch + (int64_t)blockIdx.x * 2 * AT_C * Npad;  // projections
     double* SW = SP + (int64_t)AT_C * Npad;                         // log-weights
-    auto at = [](int c, int64_t j) { return (((j >> 6) * AT_C + c) << 6) + (j & 63); };
+    // -- and a cell's slot inside a block's piece rotates with the block number: with a fixed slot the per-cell passes
+    // walked the scratch at a stride of exactly 8 KB, i.e. through a handful of the memory channels
+    const int rot0 = blockIdx.x;
+    auto at = [rot0](int c, int64_t j) { return (((j >> 6) * AT_C + ((c + (int)(j >> 6) + rot0) & (AT_C - 1))) << 6) + (j & 63); };
     const int ntiles = (n2 + AT_C - 1) / AT_C;
     const double NEG = -__builtin_inf(), POS = __builtin_inf();
 
@@ -680,8 +721,8 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
             // steps: no bounds checks (and no divergent branches) in the stream
             const int jl = 16 * w + (lane & 15);
             const double* srow = S + (int64_t)jl * GS + 8 * kq;
-            double* spo = SP + at(kq, jl);
-            double* swo = SW + at(kq, jl);
+            double* spo = SP + jl;
+            double* swo = SW + jl;
             auto load_rows = [&](double (&b)[NKC][8], const double* src) __attribute__((always_inline)) {
 #pragma unroll
                 for (int kc = 0; kc < NKC; ++kc)
@@ -721,8 +762,9 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                         __builtin_amdgcn_sched_barrier(0);  // (keeps the A operands of one block of 32 dimensions live at a time)
                 }
                 const bool own = jo < nr2, ref = !own && jo < N;
-                double* sp_ = spo + (j0 >> 6) * (AT_C * 64);
-                double* sw_ = swo + (j0 >> 6) * (AT_C * 64);
+                const int blk = (int)(j0 >> 6);
+                double* sp_ = spo + (int64_t)blk * (AT_C * 64);
+                double* sw_ = swo + (int64_t)blk * (AT_C * 64);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {  // this lane: streamed cell jo, tile cells (lane >> 4) + 4 i
                     double pr = Pq[0][i] + Pq[1][i];
@@ -739,8 +781,9 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                     mx1[i] = fmax(mx1[i], ref ? lw : NEG);
                     lo[i] = fmin(lo[i], ref ? pr : POS);
                     hi[i] = fmax(hi[i], ref ? pr : NEG);
-                    sp_[i * 4 * 64] = pr;
-                    sw_[i * 4 * 64] = lw;
+                    const int slot = (kq + 4 * i + blk + rot0) & (AT_C - 1);  // == at(kq + 4 i, jo)
+                    sp_[slot * 64] = pr;
+                    sw_[slot * 64] = lw;
                 }
             };
             double ba[NKC][8], bb[NKC][8];
@@ -871,46 +914,26 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
         // (the scratch rows were written by this block and are read by it: same CU, through the L2)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
         // ---- cell by cell: own-batch probability, then the weighted quantile of the reference projections
-#ifdef BMX_ASV_EXP_NOCELL
-        if (g < 0)
-#endif
         for (int c = 0; c < AT_C && c0 + c < n2; ++c) {
-            auto p2 = [&](int64_t s_) { return SP[at(c, s_)]; };        // own batch: streamed cells [0, nr2)
-            auto w2 = [&](int64_t s_) { return SW[at(c, s_)]; };
-            auto p1 = [&](int64_t o_) { return SP[at(c, nr2 + o_)]; };  // reference batch: [nr2, N)
+            // (own batch: streamed cells [0, nr2); reference batch: [nr2, N))
             auto w1 = [&](int64_t o_) { return SW[at(c, nr2 + o_)]; };
+            const int last_block = (int)(Npad >> 6) - 1;
             const double curproj = sc_proj[c], l2 = sc_l2[c];
             double prob2 = 0.0;
             if (nr2 > 0) {
                 const double mx = sc_mx2[c];
                 double below = 0.0, all = 0.0;
-                // (eight elements per thread in flight: one at a time, every visit waits a full round trip to the scratch)
-                for (int s0 = tid; s0 < nr2; s0 += 8 * T) {
-                    double pr[8], lw[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int s_ = s0 + u * T;
-                        const bool ok = s_ < nr2;
-                        pr[u] = ok ? p2(s_) : POS;
-                        lw[u] = ok ? w2(s_) : NEG;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const double ww = exp(lw[u] - mx);  // exp(-inf) = 0 for the padding
-                        all += ww;
-                        if (!(pr[u] > curproj)) below += ww;
-                    }
-                }
+                asv_row_scan<true>(SP, SW, 0, nr2, c + rot0, last_block, tid, [&](double pr, double lw, int s_) {
+                    const double ww = s_ < nr2 ? exp(lw - mx) : 0.0;
+                    all += ww;
+                    below += !(pr > curproj) ? ww : 0.0;
+                });
                 below = block_sum(below, sm);
                 all = block_sum(all, sm);
                 prob2 = (below > 0.0 ? mx + log(below) : 0.0) - (mx + log(all));
             }
             double ref_quan = __builtin_nan("");
-#ifdef BMX_ASV_EXP_NOQUANT
-            if (g < 0) {
-#else
             if (nr1 > 0) {
-#endif
                 const double mx = sc_mx1[c];
                 const double FIX = 1099511627776.0;  // 2^40
                 double blo = sc_lo[c], bhi = sc_hi[c];  // projections still in play: [blo, bhi]
@@ -922,23 +945,14 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                     if (tid == 0) sh_cnt = 0;
                     __syncthreads();
                     const double scale = bhi > blo ? (double)AT_NB / (bhi - blo) : 0.0;
-                    for (int o0 = tid; o0 < nr1; o0 += 8 * T) {
-                        double pr[8], lw[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const int o = o0 + u * T;
-                            const bool ok = o < nr1;
-                            pr[u] = ok ? p1(o) : __builtin_nan("");
-                            lw[u] = ok ? w1(o) : NEG;
-                        }
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            if (!(pr[u] >= blo && pr[u] <= bhi)) continue;  // (a NaN pad fails both)
-                            int b = (int)((pr[u] - blo) * scale);
-                            b = b < 0 ? 0 : (b > AT_NB - 1 ? AT_NB - 1 : b);
-                            atomicAdd(&hist[b], (unsigned long long)(exp(lw[u] - mx) * FIX));
-                        }
-                    }
+                    asv_row_scan<true>(SP, SW, nr2, nr1, c + rot0, last_block, tid, [&](double pr, double lw, int o) {
+                        const bool in = o < nr1 && pr >= blo && pr <= bhi;
+                        int b = (int)((pr - blo) * scale);
+                        b = b < 0 ? 0 : (b > AT_NB - 1 ? AT_NB - 1 : b);
+                        const double wv = exp(lw - mx) * FIX;
+                        // (an element out of play adds nothing to a bin of the thread's own: no branch, no pile-up on one bin)
+                        atomicAdd(&hist[in ? b : (tid & (AT_NB - 1))], in ? (unsigned long long)wv : 0ull);
+                    });
                     __syncthreads();
                     if (tid == 0) {
                         if (round == 0) {
@@ -968,26 +982,16 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                     }
                     before = sh_before;
                     // the projections that fall into bin `at`
-                    for (int o0 = tid; o0 < nr1; o0 += 8 * T) {
-                        double pr[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const int o = o0 + u * T;
-                            pr[u] = o < nr1 ? p1(o) : __builtin_nan("");
+                    asv_row_scan<false>(SP, SW, nr2, nr1, c + rot0, last_block, tid, [&](double pr, double, int o) {
+                        int b = (int)((pr - blo) * scale);
+                        b = b < 0 ? 0 : (b > AT_NB - 1 ? AT_NB - 1 : b);
+                        if (!(o < nr1 && pr >= blo && pr <= bhi && b == at)) return;  // (rare: one bin of 2 048)
+                        const int pos = atomicAdd(&sh_cnt, 1);
+                        if (pos < AT_CAP) {
+                            lp[pos] = pr;
+                            lw_[pos] = (unsigned long long)(exp(w1(o) - mx) * FIX);
                         }
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            if (!(pr[u] >= blo && pr[u] <= bhi)) continue;
-                            int b = (int)((pr[u] - blo) * scale);
-                            b = b < 0 ? 0 : (b > AT_NB - 1 ? AT_NB - 1 : b);
-                            if (b != at) continue;
-                            const int pos = atomicAdd(&sh_cnt, 1);
-                            if (pos < AT_CAP) {
-                                lp[pos] = pr[u];
-                                lw_[pos] = (unsigned long long)(exp(w1(o0 + u * T) - mx) * FIX);
-                            }
-                        }
-                    }
+                    });
                     __syncthreads();
                     const int cnt = sh_cnt;
                     if (cnt <= AT_CAP || !(bhi > blo)) {
@@ -1046,19 +1050,10 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                     bhi = fmin(bhi, nhi + margin);
                     ref_quan = bhi;  // (provisional: the quantile lies in [blo, bhi]; final unless another round refines it)
                     unsigned long long mine = 0;
-                    for (int o0 = tid; o0 < nr1; o0 += 8 * T) {
-                        double pr[8], lw[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const int o = o0 + u * T;
-                            const bool ok = o < nr1;
-                            pr[u] = ok ? p1(o) : POS;
-                            lw[u] = ok ? w1(o) : NEG;
-                        }
-#pragma unroll
-                        for (int u = 0; u < 8; ++u)
-                            if (pr[u] < blo) mine += (unsigned long long)(exp(lw[u] - mx) * FIX);
-                    }
+                    asv_row_scan<true>(SP, SW, nr2, nr1, c + rot0, last_block, tid, [&](double pr, double lw, int o) {
+                        const double wv = exp(lw - mx) * FIX;
+                        mine += o < nr1 && pr < blo ? (unsigned long long)wv : 0ull;
+                    });
                     // integer sums: any order gives the same total
                     __syncthreads();
                     unsigned long long* smu = reinterpret_cast<unsigned long long*>(sm);
