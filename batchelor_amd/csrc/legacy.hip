@@ -547,6 +547,55 @@ inline size_t asv_tile_lds_bytes(int g) {
            (nkc > 2 ? (size_t)2 * nkc * 8 * 64 * sizeof(double) : 0);
 }
 
+// The weighted-quantile walk (src/adjust_shift_variance.cpp:137-157: the first entry at which the cumulative weight reaches
+// the target) over up to 8 T integer weights in the LDS, by the whole block instead of one thread going entry by entry:
+// every thread sums its eight consecutive entries, a scan over the threads gives each its starting weight, the thread whose
+// stretch holds the first crossing reports it.  Integer sums: the result is what the sequential walk finds.
+// target_of(total weight of v) -> target.  Returns the index (-1: never reached), *cum_before = base + weight before it.
+template <class TargetOf>
+__device__ __forceinline__ int asv_first_crossing(const unsigned long long* v, int n, unsigned long long base,
+                                                  TargetOf target_of, unsigned long long* smu, int* sh_idx,
+                                                  unsigned long long* sh_cum, double* target_out) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i0 = tid * 8;
+    unsigned long long mine[8], loc = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        mine[k] = i0 + k < n ? v[i0 + k] : 0ull;
+        loc += mine[k];
+    }
+    unsigned long long inc = loc;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    __syncthreads();  // (smu may still be read as something else)
+    if (lane == 63) smu[w] = inc;
+    if (tid == 0) *sh_idx = 0x7fffffff;
+    __syncthreads();
+    unsigned long long woff = 0, total = 0;
+    for (int ww = 0; ww < T / 64; ++ww) {
+        const unsigned long long t = smu[ww];
+        total += t;
+        if (ww < w) woff += t;
+    }
+    const double target = target_of(total);
+    unsigned long long cum = base + woff + (inc - loc), cbefore = 0;
+    int cand = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const bool hit = cand == 0x7fffffff && i0 + k < n && (double)(cum + mine[k]) >= target;
+        cbefore = hit ? cum : cbefore;
+        cand = hit ? i0 + k : cand;
+        cum += mine[k];
+    }
+    if (cand != 0x7fffffff) atomicMin(sh_idx, cand);
+    __syncthreads();
+    if (cand == *sh_idx && cand != 0x7fffffff) *sh_cum = cbefore;
+    __syncthreads();
+    *target_out = target;
+    return *sh_idx == 0x7fffffff ? -1 : *sh_idx;
+}
+
 // One cell's scratch row, elements [jstart, jstart + n) of the stream, past the block: thread t visits jstart + t,
 // + T, ... in batches of AT_U, the next batch on its way while the current one is consumed (one wave per SIMD: nothing
 // else hides the round trip to the scratch).  Straight-line code: every load is issued (block numbers clamped to the
@@ -954,28 +1003,11 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                         atomicAdd(&hist[in ? b : (tid & (AT_NB - 1))], in ? (unsigned long long)wv : 0ull);
                     });
                     __syncthreads();
-                    if (tid == 0) {
-                        if (round == 0) {
-                            unsigned long long tot = 0;
-                            for (int b = 0; b < AT_NB; ++b) tot += hist[b];
-                            sc_tmp[0] = exp(prob2) * (double)tot;  // the target (:137), fixed-point units
-                        }
-                        const double tg = sc_tmp[0];
-                        unsigned long long cum = before;
-                        int at = -1;
-                        for (int b = 0; b < AT_NB; ++b) {
-                            if ((double)(cum + hist[b]) >= tg) {
-                                at = b;
-                                break;
-                            }
-                            cum += hist[b];
-                        }
-                        sh_bin = at;
-                        sh_before = cum;
-                    }
-                    __syncthreads();
-                    target = sc_tmp[0];
-                    const int at = sh_bin;
+                    const double ep2 = exp(prob2);
+                    const int at = asv_first_crossing(
+                        hist, AT_NB, before,
+                        [&](unsigned long long tot) { return round == 0 ? ep2 * (double)tot : target; },  // the target (:137), fixed-point units
+                        reinterpret_cast<unsigned long long*>(sm), &sh_bin, &sh_before, &target);
                     if (at < 0) {  // no prefix reaches the target: the last projection (:141)
                         ref_quan = sc_hi[c];
                         break;
@@ -1024,18 +1056,11 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                                 }
                                 __syncthreads();
                             }
-                        if (tid == 0) {
-                            unsigned long long cum = before;
-                            double q = m > 0 ? lp[m - 1] : bhi;
-                            for (int i = 0; i < m; ++i) {
-                                cum += lw_[i];
-                                if ((double)cum >= target) {
-                                    q = lp[i];
-                                    break;
-                                }
-                            }
-                            sc_tmp[1] = q;
-                        }
+                        double tg2;
+                        const int hit = asv_first_crossing(
+                            lw_, m, before, [&](unsigned long long) { return target; },
+                            reinterpret_cast<unsigned long long*>(sm), &sh_bin, &sh_before, &tg2);
+                        if (tid == 0) sc_tmp[1] = hit >= 0 ? lp[hit] : (m > 0 ? lp[m - 1] : bhi);
                         __syncthreads();
                         ref_quan = sc_tmp[1];
                         break;
