@@ -243,6 +243,7 @@ struct KnnWorkspace {
     DevBuf<float> tau;             // [nq][C]
     DevBuf<float> cand_v;          // [nq][C][KS] approximate values of the candidates (refine pre-ranks by them)
     DevBuf<uint32_t> tau_g;        // [nq] per-query thresholds shared across reference ranges
+    DevBuf<float> margin;          // [nq] twice the fp16 pass's error bound per query, in the pass's own units
     DevBuf<unsigned long long> maxslots;  // 64 x 16 words: per-slot maxima of the reference norms (prep kernels)
     // per candidate tier: [count + 1] compact list of the queries it could not certify (+ counter in word 0), their
     // k-th candidate distances, and the scratch of the sub-search the next tier runs on them
@@ -336,6 +337,10 @@ struct Bf16Launch {
     float* cand_v;          // approximate values of the candidates
     float* tau;
     int n_full = 0;         // the first n_full query blocks sweep [first_begin, r_limit) as ONE range; the others split it
+    // fp16 tier: with margin[q] = twice the pass's error bound for query q (its own units) a list is cut at
+    // (k-th best value + margin) instead of at its KS-th best -- what lies beyond cannot be among the k nearest
+    const float* margin = nullptr;
+    int k = 0;
 };
 int bf16_pick_ns(int d);         // MFMA k-steps (16 bf16 each) for 3 d + 3 columns; 0 = unsupported
 int bf16_ncons(int NS, int KS);  // consumer waves (32 queries each) per workgroup

@@ -173,6 +173,25 @@ __global__ void seed_tau_kernel(const float* __restrict__ seed_d2, const double*
     tau_g[q] = q < nq ? min(tau_g[q], o) : o;  // the image is order-preserving: min of images = image of the min
 }
 
+// Twice the candidate pass's error bound per query, in the pass's own (scaled) units, rounded up: a reference whose
+// approximate value exceeds the k-th best approximate value by more than this is farther, exactly, than each of those
+// k -- the cut knn_refine applies to the candidates (below), handed to the pass itself so that it stops collecting them.
+__global__ void margin_kernel(const double* __restrict__ qn2, const unsigned long long* __restrict__ max_rn2_bits, int nq,
+                              int nq_pad, double eps_k, double eps_qr, double eps_split, double eps_den, int scaled,
+                              float* __restrict__ margin) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq_pad) return;
+    float m = 0.f;
+    if (q < nq) {
+        const double max_rn2 = __longlong_as_double((long long)*max_rn2_bits);
+        const double s = scaled ? pass_scale(max_rn2) : 1.0;
+        const double eps = pass_eps(sqrt(qn2[q]), sqrt(max_rn2), s, eps_k, eps_qr, eps_split, eps_den);
+        const double x = 2.0 * eps * (s * s) * 1.0000002 + 1e-30;
+        m = (float)(x * 1.000001);  // (the f32 rounding cannot land below x)
+    }
+    margin[q] = m;
+}
+
 template <int REFINE_NC>  // pieces of 8 doubles (one 16-byte load per lane of a quad) a row may have; 0: lane-per-row gather
 __global__ __launch_bounds__(256) void knn_refine(const double* __restrict__ X, const int32_t* __restrict__ ref_rows,
                                                   const double* __restrict__ Q, const int32_t* __restrict__ q_rows,
@@ -581,7 +600,7 @@ void candidate_pass(hipStream_t stream, KnnWorkspace& ws, const Tier& T, const d
     // (a seeded search samples too, but a sixth of the rows: the odd query whose seed is loose -- a left cell listed by
     // one far-away right cell -- then starts from a sampled threshold instead of none; the tighter of the two counts)
     if (seed_d2 && T.id == 1) S_auto = std::min(S_auto, BMX_SEEDED_SAMPLE);
-    const int S = (int)round_up(std::getenv("BMX_SAMPLE") ? std::atoi(std::getenv("BMX_SAMPLE")) : S_auto, 64);
+    int S = (int)round_up(std::getenv("BMX_SAMPLE") ? std::atoi(std::getenv("BMX_SAMPLE")) : S_auto, 64);
     int C = 1, n_full = 0;
     {
         const int a = nqb / 256, b = nqb % 256;
@@ -608,6 +627,7 @@ void candidate_pass(hipStream_t stream, KnnWorkspace& ws, const Tier& T, const d
     C = std::max(1, cdiv(nr, chunk_len));
     const int nr_pad = chunk_len * C;
     const int nchunks = C;
+    S = std::min(S, nr_pad / 64 * 64);  // (a forced sample size beyond the reference: the prepared image ends at nr_pad)
     if (std::getenv("BMX_DEBUG"))
         fprintf(stderr, "[bmx] knn tier %d: nq=%d nr=%d d=%d NS=%d KS=%d S=%d C=%d chunk=%d full-range blocks=%d of %d\n", T.id,
                 nq, nr, d, NS, KS, S, C, chunk_len, C > 1 ? n_full : nqb, nqb);
@@ -668,6 +688,15 @@ void candidate_pass(hipStream_t stream, KnnWorkspace& ws, const Tier& T, const d
     }
     Bf16Launch L{reinterpret_cast<const uint16_t*>(pq), reinterpret_cast<const uint16_t*>(pr), nqb, 0, S, 1, S, 0, nchunks,
                  tau_g, 1, cand, cand_v, tau};
+    static const bool no_margin = std::getenv("BMX_NO_MARGIN") != nullptr;  // developer switch: the KS-th-best cut only
+    if (T.id == 1 && !no_margin) {
+        float* margin = ws.margin.reserve(nq_pad);
+        hipLaunchKernelGGL(margin_kernel, dim3(cdiv(nq_pad, 256)), dim3(256), 0, stream, qn2, maxbits, nq, nq_pad, eps_k,
+                           eps_qr, eps_split, eps_den, 1, margin);
+        BMX_LAUNCH_CHECK();
+        L.margin = margin;
+        L.k = k;
+    }
     auto go = [&](const Bf16Launch& l) {
         return T.id == 1 ? f16_launch(stream, ws, NS, KS, l) : bf16_launch(stream, ws, NS, KS, l);
     };

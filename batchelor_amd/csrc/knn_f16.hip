@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void knn_prep_f16(const double* __restrict__ X
 // LDS budget: ring of reference tiles | per-query lists | per-wave spill queues | list counters | published
 // thresholds | hand-over words
 // ---------------------------------------------------------------------------------------------------
-__host__ __device__ constexpr int lds_fixed_bytes() { return NCONS * QCAP * 20 + NQ * 4 + NQ * 4 + 512; }
+__host__ __device__ constexpr int lds_fixed_bytes() { return NCONS * QCAP * 20 + NQ * 4 + NQ * 4 + NQ * 4 + 512; }
 // A ring slot holds TWO reference tiles (64 rows): the consumers wait, hand back and poll once per two tiles.
 __host__ __device__ constexpr int ring_slots_for(int NS, int LCAP) {
     const int rest = 160 * 1024 - lds_fixed_bytes() - NQ * LCAP * 8;
@@ -251,7 +251,7 @@ template <int NS, int KS, int LCAP, bool SAMPLE>
 __global__ __launch_bounds__((NCONS + NPROD + serv_waves(NS)) * 64) void knn_topk_f16(
     const uint16_t* __restrict__ Pq, const uint16_t* __restrict__ PrF, int first_begin, int range_len, int r_limit,
     int n_full, int nranges, int out_chunk0, int out_nchunks, uint32_t* __restrict__ tau_g, int32_t* __restrict__ cand,
-    float* __restrict__ cand_v, float* __restrict__ tau_out) {
+    float* __restrict__ cand_v, float* __restrict__ tau_out, const float* __restrict__ margin_g, int kq) {
     constexpr int TILE_BYTES = NS * 1024;
     constexpr int SLOT_BYTES = 2 * TILE_BYTES;
     constexpr int NSLOT = ring_slots_for(NS, LCAP);
@@ -268,7 +268,8 @@ __global__ __launch_bounds__((NCONS + NPROD + serv_waves(NS)) * 64) void knn_top
     uint32_t* qtags = reinterpret_cast<uint32_t*>(qvals + NCONS * QCAP * 4);                      // [NCONS][QCAP]
     int* cnt = reinterpret_cast<int*>(qtags + NCONS * QCAP);                                      // [NQ]
     float* tauL = reinterpret_cast<float*>(cnt + NQ);  // [NQ] thresholds as the service waves last published them
-    int* ready = reinterpret_cast<int*>(tauL + NQ);    // [NSLOT]
+    float* mgL = tauL + NQ;  // [NQ] twice the pass's error bound of each query (0: the KS-th-best cut only)
+    int* ready = reinterpret_cast<int*>(mgL + NQ);     // [NSLOT]
     int* done = ready + NSLOT;  // [NSLOT] hand-backs of the position so far (every consumer adds one per slot read)
     int* wrL = done + NSLOT;    // [NCONS] records pushed so far (written by the consumer)
     int* rdL = wrL + NCONS;                            // [NCONS] records worked off so far (written by its service wave)
@@ -294,6 +295,7 @@ __global__ __launch_bounds__((NCONS + NPROD + serv_waves(NS)) * 64) void knn_top
     if (tid < NQ) {
         cnt[tid] = 0;
         tauL[tid] = (!SAMPLE && tau_g) ? orderable_f32(tau_g[qblock * NQ + tid]) : __builtin_inff();
+        mgL[tid] = (!SAMPLE && margin_g) ? margin_g[qblock * NQ + tid] : 0.f;
     }
     __syncthreads();
     const bool shared_tau = !SAMPLE && tau_g != nullptr && nrng > 1;
@@ -316,7 +318,7 @@ __global__ __launch_bounds__((NCONS + NPROD + serv_waves(NS)) * 64) void knn_top
         int* mycnt = cnt + c * 32;
         const int n_raw = __builtin_amdgcn_readfirstlane(lds_load_volatile(&mycnt[jj]));
         const int n = n_raw < LCAP ? n_raw : LCAP;
-        if (n <= KS) return;
+        if (n <= KS && (n < kq || margin_g == nullptr)) return;
 #ifdef BMX_STAMPS
         const unsigned long long c0 = STAMP();
         ++dbg_ncomp;
@@ -327,26 +329,13 @@ __global__ __launch_bounds__((NCONS + NPROD + serv_waves(NS)) * 64) void knn_top
         const uint32_t key =
             lane < n ? (((f32_orderable(__uint_as_float((uint32_t)(raw >> 32))) >> 1) & ~63u) | (uint32_t)lane)
                      : 0x7FFFFFFFu;
-        unsigned long long M = 0;
-        int pl = 0, kept = 0x7FFFFFFF;
+        unsigned long long M = 0, keep = 0;
+        int pl = 0, kept = 0x7FFFFFFF, nkeep = 0;
         uint32_t pk = 0;
-#pragma unroll
-        for (int i = 0; i < BMX_NPIV; ++i) {
-            const int pv = ((2 * i + 1) * n) / (2 * BMX_NPIV);  // < n
-            const uint32_t k_i = (uint32_t)__builtin_amdgcn_readlane((int)key, pv);
-            const unsigned long long m_i = __builtin_amdgcn_ballot_w64(key < k_i);
-            const int c_i = __builtin_popcountll(m_i);
-            if (c_i >= KS - 1 && c_i < kept) {
-                kept = c_i;
-                M = m_i;
-                pl = pv;
-                pk = k_i;
-            }
-        }
-        if (exact ? kept != KS - 1 : kept > KS + 11) {
-            // quickselect for the key with exactly KS - 1 smaller keys; B = lanes that can still be it
-            unsigned long long B = n == 64 ? ~0ull : ((1ull << n) - 1ull);
-            if (kept != 0x7FFFFFFF) B &= M;  // below the best pivot found
+        float newtau = 0.f;
+        bool cut_done = false;
+        // quickselect: the key with exactly `target` smaller keys among the lanes of B; leaves it in (pl, pk, M)
+        auto select_rank = [&](unsigned long long B, const int target) __attribute__((always_inline)) {
             int it = 0;
             for (;;) {
                 const int rot = (it * 29 + jj * 7) & 63;  // pivots from changing places
@@ -356,25 +345,71 @@ __global__ __launch_bounds__((NCONS + NPROD + serv_waves(NS)) * 64) void knn_top
                 pk = (uint32_t)__builtin_amdgcn_readlane((int)key, pl);
                 M = __builtin_amdgcn_ballot_w64(key < pk);
                 const int cc = __builtin_popcountll(M);
-                if (cc == KS - 1) break;
-                if (cc > KS - 1)
+                if (cc == target) break;
+                if (cc > target)
                     B &= M;
                 else
                     B &= ~M & ~(1ull << pl);
             }
-            kept = KS - 1;
 #ifdef BMX_STAMPS
             dbg_rounds += it;
 #endif
+        };
+        const unsigned long long all_lanes = n == 64 ? ~0ull : ((1ull << n) - 1ull);
+        // The margin cut: everything above (k-th best value + twice the error bound) is farther, exactly, than k others
+        // of the list whatever the rounding did, so it can go -- typically a handful of entries beyond the k-th stay
+        // instead of KS - k, and the threshold (what the consumers filter with) sits that much lower.  It applies when
+        // the list has k entries and what it keeps fits; otherwise the rank cut below.
+        const float mg = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(mgL[c * 32 + jj])));
+        if (mg > 0.f && n >= kq) {
+            select_rank(all_lanes, kq - 1);
+            const float vk = orderable_f32((pk & ~63u) << 1);  // the k-th best value, low bits cleared (within 2^-17 of it)
+            const float tm = vk + mg + fabsf(vk) * 6.103515625e-05f;  // (+ 2^-14: the cleared bits of vk and of the cut)
+            const uint32_t ck = (f32_orderable(tm) >> 1) & ~63u;  // as a key with its lane bits cleared: <= tm
+            const unsigned long long Mm = __builtin_amdgcn_ballot_w64(key < ck);
+            const int cc = __builtin_popcountll(Mm);
+            if (cc >= kq && cc <= (exact ? KS : KS + 11)) {
+                keep = Mm;
+                nkeep = cc;
+                newtau = orderable_f32(ck << 1);  // <= the value of everything dropped
+                cut_done = true;
+            }
         }
-        const unsigned long long keep = M | (1ull << pl);  // kept + 1 lanes, at least KS
-        // the new threshold: the cut key with its lane bits cleared, which is <= the value of everything
-        // dropped, so "rejected => value >= threshold" holds exactly
-        const float newtau = orderable_f32((pk & ~63u) << 1);
+        if (!cut_done) {
+            if (n <= KS) return;
+            M = 0;
+            pl = 0;
+            pk = 0;
+#pragma unroll
+            for (int i = 0; i < BMX_NPIV; ++i) {
+                const int pv = ((2 * i + 1) * n) / (2 * BMX_NPIV);  // < n
+                const uint32_t k_i = (uint32_t)__builtin_amdgcn_readlane((int)key, pv);
+                const unsigned long long m_i = __builtin_amdgcn_ballot_w64(key < k_i);
+                const int c_i = __builtin_popcountll(m_i);
+                if (c_i >= KS - 1 && c_i < kept) {
+                    kept = c_i;
+                    M = m_i;
+                    pl = pv;
+                    pk = k_i;
+                }
+            }
+            if (exact ? kept != KS - 1 : kept > KS + 11) {
+                // quickselect for the key with exactly KS - 1 smaller keys; B = lanes that can still be it
+                unsigned long long B = all_lanes;
+                if (kept != 0x7FFFFFFF) B &= M;  // below the best pivot found
+                select_rank(B, KS - 1);
+                kept = KS - 1;
+            }
+            keep = M | (1ull << pl);  // kept + 1 lanes, at least KS
+            nkeep = kept + 1;
+            // the new threshold: the cut key with its lane bits cleared, which is <= the value of everything
+            // dropped, so "rejected => value >= threshold" holds exactly
+            newtau = orderable_f32((pk & ~63u) << 1);
+        }
         const int pos = mbcnt64(keep);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // every lane holds its entry before slots are rewritten
         if ((keep >> lane) & 1ull) mylists[jj * LCAP + pos] = raw;
-        if (lane == 0) mycnt[jj] = kept + 1;
+        if (lane == 0) mycnt[jj] = nkeep;
         if (lane == jj) {
             const float told = tauL[c * 32 + jj];
             tauL[c * 32 + jj] = newtau < told ? newtau : told;  // the consumer picks it up at its next slot
@@ -925,7 +960,29 @@ __global__ __launch_bounds__((NCONS + NPROD + serv_waves(NS)) * 64) void knn_top
 
     if constexpr (SAMPLE) {
         const uint32_t mine = f32_orderable(best[KS / 2 - 1]), other = __shfl_xor(mine, 32);
-        if (h == 0) tau_g[q] = max(mine, other);
+        uint32_t start = max(mine, other);
+        if constexpr (KS / 2 <= 24) {
+            if (margin_g && kq >= 1 && kq <= KS) {
+                // the margin form (see `compact`): the k-th smallest of the 2 x KS / 2 values the query's two lanes hold --
+                // distinct references, so k references lie at or below it -- plus twice the error bound.  Each entry's
+                // rank in the union = its place in its own (sorted) list + the partner's entries in front of it.
+                float part[KS / 2];
+#pragma unroll
+                for (int e = 0; e < KS / 2; ++e) part[e] = __shfl_xor(best[e], 32);
+                float uk = __builtin_inff();
+#pragma unroll
+                for (int i = 0; i < KS / 2; ++i) {
+                    int r = i;
+#pragma unroll
+                    for (int e = 0; e < KS / 2; ++e) r += (part[e] < best[i] || (part[e] == best[i] && h == 1)) ? 1 : 0;
+                    uk = r == kq - 1 ? best[i] : uk;
+                }
+                uk = fminf(uk, __shfl_xor(uk, 32));
+                const float tm = uk + margin_g[q] + fabsf(uk) * 2.384185791015625e-07f;  // (the f32 sum rounded up)
+                if (tm == tm) start = min(start, f32_orderable(tm));  // (no k-th value yet: inf, nothing changes)
+            }
+        }
+        if (h == 0) tau_g[q] = start;
 #ifdef BMX_STAMPS
         if (lane == 0) {
             atomicAdd(&bmx_dbg16[0], STAMP() - dbg_t0);
@@ -976,11 +1033,11 @@ void launch(hipStream_t stream, KnnWorkspace& ws, const Bf16Launch& L) {
     if (L.sample)
         hipLaunchKernelGGL((knn_topk_f16<NS, KS, LCAP, true>), dim3(items), dim3((NCONS + NPROD + serv_waves(NS)) * 64), lds, stream,
                            L.pq, L.pr, L.first_begin, L.range_len, L.r_limit, L.n_full, L.nranges, L.out_chunk0,
-                           L.out_nchunks, L.tau_g, L.cand, L.cand_v, L.tau);
+                           L.out_nchunks, L.tau_g, L.cand, L.cand_v, L.tau, L.margin, L.k);
     else
         hipLaunchKernelGGL((knn_topk_f16<NS, KS, LCAP, false>), dim3(items), dim3((NCONS + NPROD + serv_waves(NS)) * 64), lds, stream,
                            L.pq, L.pr, L.first_begin, L.range_len, L.r_limit, L.n_full, L.nranges, L.out_chunk0,
-                           L.out_nchunks, L.tau_g, L.cand, L.cand_v, L.tau);
+                           L.out_nchunks, L.tau_g, L.cand, L.cand_v, L.tau, L.margin, L.k);
     BMX_LAUNCH_CHECK();
     if (ws.profile) BMX_HIP(hipEventRecord(ev.second, stream));
 #ifdef BMX_STAMPS
