@@ -12,7 +12,7 @@
 // the sequential walk), with the bit-reproducible exp / log1p of portable_math.hpp: bit for bit what a CPU
 // following the same order of operations with the same arithmetic gets (the tests' checker does).  Its sequential chains
 // cost O(cells x (nr1 + nr2)) dependent steps (1.6 ns per pair): it is taken up to 4e7 pairs per call; beyond that
-// asv_tile_kernel (16-cell tiles on the FP64 matrix cores + a sort-free histogram quantile, 0.04 ns per pair) takes over and
+// asv_tile_kernel (16-cell tiles on the FP64 matrix cores + a sort-free histogram quantile, 0.015 ns per pair) takes over and
 // agrees except on those ill-conditioned cells (tests/testthat/test-mnn-correct.R:141,396-399 acknowledge the effect
 // upstream).  asv_kernel is round 2's scalable form, kept behind BMX_ASV_BISECT=1.
 #include "bmx_ops.hpp"
@@ -513,11 +513,12 @@ __global__ __launch_bounds__(T) void asv_exact_kernel(const double* __restrict__
 // ---------------------------------------------------------------------------------------------------
 // adjust_shift_variance at scale (BASELINE.json configs[4]: every right cell of a merge against every restricted cell of
 // both batches -- 5e11 pairs at the root of the 16-batch tree).  A workgroup owns a TILE OF 16 CELLS:
-//   1. the restricted cells of both batches stream past it once, 64 at a time through the LDS; two FP64 MFMA blocks
-//      (v_mfma_f64_16x16x4_f64) per 16 x 16 sub-tile give  D = x_c . x_o  and  P = g^_c . x_o, from which the projection
-//      on the cell's line (P) and the squared distance to it  |x_c|^2 + |x_o|^2 - 2 D - (g^_c . x_c - P)^2  follow per
-//      pair (src/adjust_shift_variance.cpp:9-27 in GEMM form); projection and log-weight go to the tile's scratch rows,
-//      the per-cell maxima / projection range come out of the same pass;
+//   1. the restricted cells of both batches, gathered into one zero-padded matrix (asv_gather_stream), stream past it once:
+//      every wave loads its 16 rows of a 64-row step straight into MFMA operand registers (LDS-staged beyond 128
+//      dimensions); two FP64 MFMA chains (v_mfma_f64_16x16x4_f64) per 16 x 16 sub-tile give  D = x_c . x_o  and
+//      P = g^_c . x_o, from which the projection on the cell's line (P) and the squared distance to it
+//      |x_c|^2 + |x_o|^2 - 2 D - (g^_c . x_c - P)^2  follow per pair (src/adjust_shift_variance.cpp:9-27 in GEMM form);
+//      projection and log-weight go to the tile's scratch, the per-cell maxima / projection range come out of the same pass;
 //   2. cell by cell: the own-batch probability (log-sum-exp, :74-112) and the weighted quantile of the reference batch's
 //      projections (:117-157) WITHOUT sorting them: linear histogram of the weights over the projection range (2 048
 //      bins, integer fixed-point sums: order-independent, so runs are bit-identical), the bin where the cumulative weight
@@ -1126,7 +1127,7 @@ void smooth_gaussian_kernel_device(hipStream_t stream, const double* averaged, i
 // BMX_ASV_FAST=1 forces the tiled form (tests), BMX_ASV_BISECT=1 selects round 2's scalable form (asv_kernel).
 size_t adjust_shift_variance_scratch(int n2, int nr1, int nr2, int* blocks, int* npad, int* exact) {
     static const int force_fast = std::getenv("BMX_ASV_FAST") != nullptr;  // developer switch
-    // the bit-exact form's sequential log-sum chains cost ~1.6 ns per (cell, restricted cell) pair, the tiled form 0.03:
+    // the bit-exact form's sequential log-sum chains cost ~1.6 ns per (cell, restricted cell) pair, the tiled form 0.015:
     // exact up to 4e7 pairs (the reference's own test shapes and anything a test can check against the CPU), tiled beyond
     *exact = !force_fast && (int64_t)nr1 + nr2 <= 131072 && (double)std::max(n2, 1) * ((double)nr1 + nr2) <= 4e7;
     int p = 1;
