@@ -257,6 +257,10 @@ __global__ __launch_bounds__((NCONS + NPROD + serv_waves(NS)) * 64) void knn_top
     constexpr int NSLOT = ring_slots_for(NS, LCAP);
     static_assert(NSLOT >= 2, "LDS ring");
     static_assert(LCAP <= 64 && LCAP > KS, "one list entry per lane during compaction");
+    // what a cut in mid-sweep may keep: a full list must come out with room again (the appends that found it full retry
+    // until they fit), and a cut that frees next to nothing would be back at once
+    constexpr int KEEP_MAX = KS + 11 < LCAP - 4 ? KS + 11 : LCAP - 4;
+    static_assert(KEEP_MAX >= KS, "list capacity");
     constexpr int NSERV = serv_waves(NS);
     static_assert(NCONS % NSERV == 0 && (NCONS / NSERV) % 2 == 0, "a service wave's consumers: whole groups of 64 queries");
     static_assert((QCAP & (QCAP - 1)) == 0 && QCAP >= 64, "queue positions wrap by masking; one group can hold 64 records");
@@ -368,7 +372,7 @@ __global__ __launch_bounds__((NCONS + NPROD + serv_waves(NS)) * 64) void knn_top
             const uint32_t ck = (f32_orderable(tm) >> 1) & ~63u;  // as a key with its lane bits cleared: <= tm
             const unsigned long long Mm = __builtin_amdgcn_ballot_w64(key < ck);
             const int cc = __builtin_popcountll(Mm);
-            if (cc >= kq && cc <= (exact ? KS : KS + 11)) {
+            if (cc >= kq && cc <= (exact ? KS : KEEP_MAX)) {
                 keep = Mm;
                 nkeep = cc;
                 newtau = orderable_f32(ck << 1);  // <= the value of everything dropped
@@ -393,7 +397,7 @@ __global__ __launch_bounds__((NCONS + NPROD + serv_waves(NS)) * 64) void knn_top
                     pk = k_i;
                 }
             }
-            if (exact ? kept != KS - 1 : kept > KS + 11) {
+            if (exact ? kept != KS - 1 : kept + 1 > KEEP_MAX) {
                 // quickselect for the key with exactly KS - 1 smaller keys; B = lanes that can still be it
                 unsigned long long B = all_lanes;
                 if (kept != 0x7FFFFFFF) B &= M;  // below the best pivot found
