@@ -537,15 +537,15 @@ constexpr int AT_U = 8;         // scratch elements per thread and batch in the 
 constexpr int AT_NP = 2 * AT_R; // the stream is padded to whole pairs of steps (zero rows)
 
 __host__ __device__ inline int asv_tile_gp(int g) { return (g + AT_KC - 1) / AT_KC * AT_KC + 2; }
-inline int asv_tile_nkc(int g) { return g <= 128 ? (g + AT_KC - 1) / AT_KC : 0; }  // 0: the staged form
-// row stride of the gathered stream: whole 32-dimension blocks (zero filled) for the register-streamed form
-inline int asv_tile_gs(int g) { return g <= 128 ? asv_tile_nkc(g) * AT_KC : g; }
+inline int asv_tile_nb8(int g) { return g <= 128 ? (g + 7) / 8 : 0; }  // 8-dimension blocks of a row; 0: the staged form
+// row stride of the gathered stream: whole 8-dimension blocks (zero filled) for the register-streamed form
+inline int asv_tile_gs(int g) { return g <= 128 ? asv_tile_nb8(g) * 8 : g; }
 inline size_t asv_tile_npad(size_t N) { return std::max<size_t>((N + AT_NP - 1) / AT_NP * AT_NP, AT_NP); }
 inline size_t asv_tile_lds_bytes(int g) {
-    const int nkc = asv_tile_nkc(g);
-    return ((size_t)2 * AT_C * asv_tile_gp(g) + (nkc == 0 ? (size_t)AT_R * (AT_KC + 2) : 0) + 8 * AT_C + T) * sizeof(double) +
+    const int nb8 = asv_tile_nb8(g);
+    return ((size_t)2 * AT_C * asv_tile_gp(g) + (nb8 == 0 ? (size_t)AT_R * (AT_KC + 2) : 0) + 8 * AT_C + T) * sizeof(double) +
            (size_t)AT_NB * sizeof(unsigned long long) + (size_t)AT_CAP * 16 +
-           (nkc > 2 ? (size_t)2 * nkc * 8 * 64 * sizeof(double) : 0);
+           (nb8 > 8 ? (size_t)2 * nb8 * 2 * 64 * sizeof(double) : 0);
 }
 
 // The weighted-quantile walk (src/adjust_shift_variance.cpp:137-157: the first entry at which the cumulative weight reaches
@@ -661,11 +661,13 @@ __global__ __launch_bounds__(256) void asv_gather_stream(const double* __restric
     }
 }
 
-// NKC > 0: the streamed cells go from global memory straight into the B-operand registers (g <= 32 NKC even): with the k
-// index of an MFMA step permuted so that a lane's eight values of a 32-dimension block are 64 contiguous bytes, every wave
-// runs its 16 streamed cells on its own -- no staging through the LDS, no barrier in the stream, the next step's rows in
-// flight while the current ones multiply.  NKC = 0: the staged form (any g <= 256).
-template <int NKC>
+// NB8 > 0 (= ceil(g / 8), g <= 128): the streamed cells go from global memory straight into the B-operand registers.  A row
+// is taken in blocks of 8 dimensions, each two MFMA steps: step (q, t) multiplies dimensions 8 q + 2 (lane >> 4) + t, so the
+// two values a lane needs of a block are 16 contiguous bytes of its row and a row costs ceil(g / 8) * 8 dimensions of
+// matrix work (104 at 100 PCs; blocks of 32 dimensions, the first form, paid for 128).  Every wave runs its 16 streamed
+// cells on its own -- no staging through the LDS, no barrier in the stream, the next step's rows in flight while the
+// current ones multiply.  NB8 = 0: the staged form (any g <= 256).
+template <int NB8>
 __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __restrict__ data2, int n2,
                                                      const double* __restrict__ vect, double sigma2, int nr1, int nr2,
                                                      const double* __restrict__ S, const double* __restrict__ snrm,
@@ -676,7 +678,7 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
     double* cx = reinterpret_cast<double*>(smem_raw);  // [16][GP] the tile's cells
     double* cg = cx + AT_C * GP;                        // [16][GP] their unit gradients
     double* rs = cg + AT_C * GP;                        // [64][KC + 2] a step of streamed cells (staged form only)
-    double* sc_proj = rs + (NKC == 0 ? AT_R * (AT_KC + 2) : 0);  // per cell: own projection, |x|^2, |vect|, maxima, projection range
+    double* sc_proj = rs + (NB8 == 0 ? AT_R * (AT_KC + 2) : 0);  // per cell: own projection, |x|^2, |vect|, maxima, projection range
     double* sc_n = sc_proj + AT_C;
     double* sc_l2 = sc_n + AT_C;
     double* sc_mx1 = sc_l2 + AT_C;
@@ -688,8 +690,8 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
     unsigned long long* hist = reinterpret_cast<unsigned long long*>(sm + T);  // [NB]
     double* lp = reinterpret_cast<double*>(hist + AT_NB);                       // [CAP] collected projections
     unsigned long long* lw_ = reinterpret_cast<unsigned long long*>(lp + AT_CAP);  // [CAP] and their weights
-    double* cxp = reinterpret_cast<double*>(lw_ + AT_CAP);  // [NKC * 8][64] the cells' coordinates as the lanes read them
-    double* cgp = cxp + (NKC > 2 ? NKC * 8 * 64 : 0);       // [NKC * 8][64] the unit gradients likewise (NKC > 2)
+    double* cxp = reinterpret_cast<double*>(lw_ + AT_CAP);  // [2 NB8][64] the cells' coordinates as the lanes read them
+    double* cgp = cxp + (NB8 > 8 ? NB8 * 2 * 64 : 0);       // [2 NB8][64] the unit gradients likewise (NB8 > 8)
     __shared__ int sh_cnt, sh_bin;
     __shared__ unsigned long long sh_before;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -743,25 +745,25 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
             cp[i] = sc_proj[(lane >> 4) + 4 * i];
             cn[i] = sc_n[(lane >> 4) + 4 * i];
         }
-        if constexpr (NKC > 0) {
+        if constexpr (NB8 > 0) {
             typedef double d2a __attribute__((ext_vector_type(2)));
-            constexpr int GS = NKC * AT_KC;  // row stride of the stream (zero filled beyond g)
+            constexpr int GS = NB8 * 8;  // row stride of the stream (zero filled beyond g)
+            constexpr int NST = 2 * NB8;  // MFMA steps per product
             const int kq = lane >> 4;
-            // the A operands of MFMA step (kc, kk): lane l holds cell l & 15, dimension 32 kc + 8 (l >> 4) + kk -- the k
-            // index of a step is permuted so that the B operands of a 32-dimension block are 64 contiguous bytes of a row.
-            // Up to 64 dimensions they live in registers for the whole stream, beyond that in the LDS in lane order.
-            double axr[NKC <= 2 ? NKC * 8 : 1], agr[NKC <= 2 ? NKC * 8 : 1];
-            if constexpr (NKC <= 2) {
+            // the A operands of MFMA step st = 2 q + t: lane l holds cell l & 15, dimension 8 q + 2 (l >> 4) + t.  Up to 64
+            // dimensions they live in registers for the whole stream, beyond that in the LDS in lane order.
+            double axr[NB8 <= 8 ? NST : 1], agr[NB8 <= 8 ? NST : 1];
+            if constexpr (NB8 <= 8) {
 #pragma unroll
-                for (int st = 0; st < NKC * 8; ++st) {
-                    const int k = 32 * (st >> 3) + 8 * kq + (st & 7);
+                for (int st = 0; st < NST; ++st) {
+                    const int k = 8 * (st >> 1) + 2 * kq + (st & 1);
                     axr[st] = cx[(lane & 15) * GP + k];
                     agr[st] = cg[(lane & 15) * GP + k];
                 }
             } else {
-                for (int e = tid; e < NKC * 8 * 64; e += T) {
+                for (int e = tid; e < NST * 64; e += T) {
                     const int st = e >> 6, ln = e & 63;
-                    const int k = 32 * (st >> 3) + 8 * (ln >> 4) + (st & 7);
+                    const int k = 8 * (st >> 1) + 2 * (ln >> 4) + (st & 1);
                     cxp[e] = cx[(ln & 15) * GP + k];
                     cgp[e] = cg[(ln & 15) * GP + k];
                 }
@@ -770,20 +772,18 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
             // this lane's streamed cell of step j0 is j0 + jl; rows, norms, ids and scratch are padded to whole pairs of
             // steps: no bounds checks (and no divergent branches) in the stream
             const int jl = 16 * w + (lane & 15);
-            const double* srow = S + (int64_t)jl * GS + 8 * kq;
+            const double* srow = S + (int64_t)jl * GS + 2 * kq;
             double* spo = SP + jl;
             double* swo = SW + jl;
-            auto load_rows = [&](double (&b)[NKC][8], const double* src) __attribute__((always_inline)) {
+            auto load_rows = [&](double (&b)[NST], const double* src) __attribute__((always_inline)) {
 #pragma unroll
-                for (int kc = 0; kc < NKC; ++kc)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const d2a v = *reinterpret_cast<const d2a*>(src + 32 * kc + 2 * e);
-                        b[kc][2 * e] = v[0];
-                        b[kc][2 * e + 1] = v[1];
-                    }
+                for (int q = 0; q < NB8; ++q) {
+                    const d2a v = *reinterpret_cast<const d2a*>(src + 8 * q);
+                    b[2 * q] = v[0];
+                    b[2 * q + 1] = v[1];
+                }
             };
-            auto step = [&](const double (&b)[NKC][8], double (&bn)[NKC][8], int64_t j0) __attribute__((always_inline)) {
+            auto step = [&](const double (&b)[NST], double (&bn)[NST], int64_t j0) __attribute__((always_inline)) {
                 const int64_t jo = j0 + jl;
                 // the next step's rows are on their way while this one multiplies (the last step asks for its own again)
                 load_rows(bn, srow + (j0 + AT_R < Npad ? (j0 + AT_R) : j0) * GS);
@@ -794,22 +794,20 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
 #pragma unroll
                 for (int a = 0; a < 2; ++a) Dq[a] = Pq[a] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int kc = 0; kc < NKC; ++kc) {
-#pragma unroll
-                    for (int kk = 0; kk < 8; ++kk) {
-                        double ax, ag;
-                        if constexpr (NKC <= 2) {
-                            ax = axr[kc * 8 + kk];
-                            ag = agr[kc * 8 + kk];
-                        } else {
-                            ax = cxp[(kc * 8 + kk) * 64 + lane];
-                            ag = cgp[(kc * 8 + kk) * 64 + lane];
-                        }
-                        Dq[kk & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, b[kc][kk], Dq[kk & 1], 0, 0, 0);
-                        Pq[kk & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ag, b[kc][kk], Pq[kk & 1], 0, 0, 0);
+                for (int st = 0; st < NST; ++st) {
+                    double ax, ag;
+                    if constexpr (NB8 <= 8) {
+                        ax = axr[st];
+                        ag = agr[st];
+                    } else {
+                        ax = cxp[st * 64 + lane];
+                        ag = cgp[st * 64 + lane];
                     }
-                    if constexpr (NKC > 2)
-                        __builtin_amdgcn_sched_barrier(0);  // (keeps the A operands of one block of 32 dimensions live at a time)
+                    Dq[st & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, b[st], Dq[st & 1], 0, 0, 0);
+                    Pq[st & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ag, b[st], Pq[st & 1], 0, 0, 0);
+                    if constexpr (NB8 > 8)
+                        if ((st & 7) == 7)
+                            __builtin_amdgcn_sched_barrier(0);  // (keeps the A operands of 32 dimensions live at a time)
                 }
                 const bool own = jo < nr2, ref = !own && jo < N;
                 const int blk = (int)(j0 >> 6);
@@ -836,7 +834,7 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                     sw_[slot * 64] = lw;
                 }
             };
-            double ba[NKC][8], bb[NKC][8];
+            double ba[NST], bb[NST];
             load_rows(ba, srow);
             for (int64_t j0 = 0; j0 < Npad; j0 += 2 * AT_R) {
                 step(ba, bb, j0);
@@ -1194,18 +1192,31 @@ void adjust_shift_variance_device(hipStream_t stream, const double* data1, int g
         hipLaunchKernelGGL(asv_gather_stream, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, stream, data1, data2, g, gs, restrict1,
                            nr1, restrict2, nr2, N, S, snrm, sid);
         const size_t lds = asv_tile_lds_bytes(g);
-#define BMX_ASV_TILE(NKC)                                                                                                    \
-    do {                                                                                                                     \
-        ensure_dynamic_lds(reinterpret_cast<const void*>(&asv_tile_kernel<NKC>), lds);                                       \
-        hipLaunchKernelGGL(asv_tile_kernel<NKC>, dim3(blocks), dim3(T), lds, stream, g, data2, n2, vrm, sigma2, nr1, nr2,     \
+#define BMX_ASV_TILE(NB8)                                                                                                    \
+    case NB8:                                                                                                                \
+        ensure_dynamic_lds(reinterpret_cast<const void*>(&asv_tile_kernel<NB8>), lds);                                       \
+        hipLaunchKernelGGL(asv_tile_kernel<NB8>, dim3(blocks), dim3(T), lds, stream, g, data2, n2, vrm, sigma2, nr1, nr2,     \
                            (const double*)S, (const double*)snrm, (const int32_t*)sid, out, ws_pairs);                       \
-    } while (0)
-        switch (asv_tile_nkc(g)) {
-            case 1: BMX_ASV_TILE(1); break;
-            case 2: BMX_ASV_TILE(2); break;
-            case 3: BMX_ASV_TILE(3); break;
-            case 4: BMX_ASV_TILE(4); break;
-            default: BMX_ASV_TILE(0); break;
+        break
+        switch (asv_tile_nb8(g)) {
+            BMX_ASV_TILE(1);
+            BMX_ASV_TILE(2);
+            BMX_ASV_TILE(3);
+            BMX_ASV_TILE(4);
+            BMX_ASV_TILE(5);
+            BMX_ASV_TILE(6);
+            BMX_ASV_TILE(7);
+            BMX_ASV_TILE(8);
+            BMX_ASV_TILE(9);
+            BMX_ASV_TILE(10);
+            BMX_ASV_TILE(11);
+            BMX_ASV_TILE(12);
+            BMX_ASV_TILE(13);
+            BMX_ASV_TILE(14);
+            BMX_ASV_TILE(15);
+            BMX_ASV_TILE(16);
+            default:
+                BMX_ASV_TILE(0);
         }
 #undef BMX_ASV_TILE
     }

@@ -144,3 +144,38 @@ def test_query_knn_second_tier_shapes(oracle, nb, monkeypatch, nx, nq, d, k, tie
     idx, dist = nb.query_knn(X, Q, k)
     oi, od = oracle.query_knn(X, Q, k)
     assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+
+
+def test_rank_cut_without_the_margin_and_near_ties(oracle, nb):
+    """Round 3: the fp16 pass cuts its lists at (k-th best + twice the error bound); the round-2 rule (the KS-th best) is
+    what remains when that keeps too much.  Both must give the oracle's rows: (a) the rank cut alone, in a subprocess
+    with the developer switch BMX_NO_MARGIN=1; (b) the margin cut on data where thousands of references sit within the
+    margin of each query's k-th neighbour (clusters of near-duplicates: the margin keeps more than a list holds and the
+    rank cut has to take over in mid-sweep)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from tests.conftest import synth_batches
+from batchelor_amd import neighbors as nb
+from oracle import fastmnn_oracle as orc
+for nx, nq, d, k in ((9000, 2500, 50, 20), (20000, 900, 100, 20), (6000, 700, 30, 5)):
+    X, Q = synth_batches(77, [nx, nq], d)
+    idx, dist = nb.query_knn(X, Q, k)
+    oi, od = orc.query_knn(X, Q, k)
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od), (nx, nq, d, k)
+print("rank-cut-ok")
+''' % root
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BMX_NO_MARGIN="1"), capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0 and "rank-cut-ok" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
+    rng = np.random.default_rng(5150)
+    centres = rng.standard_normal((40, 50)) * 2.0
+    X = np.repeat(centres, 200, axis=0) + 1e-4 * rng.standard_normal((8000, 50))  # 200 near-duplicates per centre
+    Q = centres[rng.integers(0, 40, 600)] + 1e-4 * rng.standard_normal((600, 50))
+    idx, dist = nb.query_knn(X, Q, 20)
+    oi, od = oracle.query_knn(X, Q, 20)
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od)
