@@ -543,9 +543,10 @@ inline int asv_tile_gs(int g) { return g <= 128 ? asv_tile_nb8(g) * 8 : g; }
 inline size_t asv_tile_npad(size_t N) { return std::max<size_t>((N + AT_NP - 1) / AT_NP * AT_NP, AT_NP); }
 inline size_t asv_tile_lds_bytes(int g) {
     const int nb8 = asv_tile_nb8(g);
-    return ((size_t)2 * AT_C * asv_tile_gp(g) + (nb8 == 0 ? (size_t)AT_R * (AT_KC + 2) : 0) + 8 * AT_C + T) * sizeof(double) +
-           (size_t)AT_NB * sizeof(unsigned long long) + (size_t)AT_CAP * 16 +
-           (nb8 > 8 ? (size_t)2 * nb8 * 2 * 64 * sizeof(double) : 0);
+    // (the tile's cells / gradients and the collected bin share a region: the one is dead before the other is written)
+    return (std::max<size_t>((size_t)2 * AT_C * asv_tile_gp(g), (size_t)2 * AT_CAP) +
+            (nb8 == 0 ? (size_t)AT_R * (AT_KC + 2) : 0) + 8 * AT_C + T) * sizeof(double) +
+           (size_t)AT_NB * sizeof(unsigned long long) + (nb8 > 8 ? (size_t)2 * nb8 * 2 * 64 * sizeof(double) : 0);
 }
 
 // The weighted-quantile walk (src/adjust_shift_variance.cpp:137-157: the first entry at which the cumulative weight reaches
@@ -677,7 +678,10 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
     const int GP = asv_tile_gp(g);
     double* cx = reinterpret_cast<double*>(smem_raw);  // [16][GP] the tile's cells
     double* cg = cx + AT_C * GP;                        // [16][GP] their unit gradients
-    double* rs = cg + AT_C * GP;                        // [64][KC + 2] a step of streamed cells (staged form only)
+    // (cx / cg are read for the last time before a tile's per-cell phase starts, lp / lw_ only inside it: same region)
+    double* lp = cx;                                                             // [CAP] collected projections
+    unsigned long long* lw_ = reinterpret_cast<unsigned long long*>(lp + AT_CAP);  // [CAP] and their weights
+    double* rs = cx + (2 * AT_C * GP > 2 * AT_CAP ? 2 * AT_C * GP : 2 * AT_CAP);  // [64][KC + 2] a step of streamed cells (staged form only)
     double* sc_proj = rs + (NB8 == 0 ? AT_R * (AT_KC + 2) : 0);  // per cell: own projection, |x|^2, |vect|, maxima, projection range
     double* sc_n = sc_proj + AT_C;
     double* sc_l2 = sc_n + AT_C;
@@ -688,9 +692,7 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
     double* sc_tmp = sc_hi + AT_C;
     double* sm = sc_tmp + AT_C;                         // [T] block reductions
     unsigned long long* hist = reinterpret_cast<unsigned long long*>(sm + T);  // [NB]
-    double* lp = reinterpret_cast<double*>(hist + AT_NB);                       // [CAP] collected projections
-    unsigned long long* lw_ = reinterpret_cast<unsigned long long*>(lp + AT_CAP);  // [CAP] and their weights
-    double* cxp = reinterpret_cast<double*>(lw_ + AT_CAP);  // [2 NB8][64] the cells' coordinates as the lanes read them
+    double* cxp = reinterpret_cast<double*>(hist + AT_NB);  // [2 NB8][64] the cells' coordinates as the lanes read them
     double* cgp = cxp + (NB8 > 8 ? NB8 * 2 * 64 : 0);       // [2 NB8][64] the unit gradients likewise (NB8 > 8)
     __shared__ int sh_cnt, sh_bin;
     __shared__ unsigned long long sh_before;
