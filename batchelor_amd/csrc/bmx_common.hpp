@@ -348,6 +348,7 @@ void bf16_prep(hipStream_t stream, const double* X, const int32_t* rows, int n, 
                const double* mean, int is_query, uint16_t* P, double* n2, unsigned long long* maxbits,
                unsigned long long* slots);  // slots: 64 x 16 words of scratch for the reference-norm maximum
 bool bf16_launch(hipStream_t stream, KnnWorkspace& ws, int NS, int KS, const Bf16Launch& L);
+int f16_rows_per_slot(int NS, int KS);  // reference rows a ring slot of the fp16 tier holds (ranges are multiples of it)
 
 // For rows q in [q_begin, q_end) of the query list: the k nearest rows of the reference list (exact, FP64 Euclidean,
 // ties by lowest position).  X/Q are row-major [*, d]; ref_rows / q_rows (0-based, may be null = identity) select

@@ -600,7 +600,8 @@ void candidate_pass(hipStream_t stream, KnnWorkspace& ws, const Tier& T, const d
     // (a seeded search samples too, but a sixth of the rows: the odd query whose seed is loose -- a left cell listed by
     // one far-away right cell -- then starts from a sampled threshold instead of none; the tighter of the two counts)
     if (seed_d2 && T.id == 1) S_auto = std::min(S_auto, BMX_SEEDED_SAMPLE);
-    int S = (int)round_up(std::getenv("BMX_SAMPLE") ? std::atoi(std::getenv("BMX_SAMPLE")) : S_auto, 64);
+    int S = (int)round_up(std::getenv("BMX_SAMPLE") ? std::atoi(std::getenv("BMX_SAMPLE")) : S_auto,
+                          T.id == 1 ? f16_rows_per_slot(NS, KS) : 64);
     int C = 1, n_full = 0;
     {
         const int a = nqb / 256, b = nqb % 256;
@@ -622,12 +623,12 @@ void candidate_pass(hipStream_t stream, KnnWorkspace& ws, const Tier& T, const d
         C = std::max(1, std::min(MAX_CHUNKS - 1, std::atoi(std::getenv("BMX_FORCE_C"))));
         n_full = 0;
     }
-    const int rmul = T.id == 1 ? 64 : 32;  // the fp16 ring hands two tiles over at a time
+    const int rmul = T.id == 1 ? f16_rows_per_slot(NS, KS) : 32;  // the fp16 ring hands two (or four) tiles over at a time
     const int chunk_len = (int)round_up(cdiv(nr, C), rmul);
     C = std::max(1, cdiv(nr, chunk_len));
     const int nr_pad = chunk_len * C;
     const int nchunks = C;
-    S = std::min(S, nr_pad / 64 * 64);  // (a forced sample size beyond the reference: the prepared image ends at nr_pad)
+    S = std::min(S, nr_pad / rmul * rmul);  // (a forced sample size beyond the reference: the prepared image ends at nr_pad)
     if (std::getenv("BMX_DEBUG"))
         fprintf(stderr, "[bmx] knn tier %d: nq=%d nr=%d d=%d NS=%d KS=%d S=%d C=%d chunk=%d full-range blocks=%d of %d\n", T.id,
                 nq, nr, d, NS, KS, S, C, chunk_len, C > 1 ? n_full : nqb, nqb);

@@ -219,19 +219,30 @@ __global__ __launch_bounds__(256) void knn_prep_f16(const double* __restrict__ X
 // thresholds | hand-over words
 // ---------------------------------------------------------------------------------------------------
 __host__ __device__ constexpr int lds_fixed_bytes() { return NCONS * QCAP * 20 + NQ * 4 + NQ * 4 + NQ * 4 + 512; }
-// A ring slot holds TWO reference tiles (64 rows): the consumers wait, hand back and poll once per two tiles.
-__host__ __device__ constexpr int ring_slots_for(int NS, int LCAP) {
+// A ring slot holds TP PAIRS of reference tiles (64 TP rows): the consumers wait, hand back and poll once per slot.
+__host__ __device__ constexpr int ring_slots_for(int NS, int LCAP, int TP) {
     const int rest = 160 * 1024 - lds_fixed_bytes() - NQ * LCAP * 8;
-    const int n = rest / (2 * NS * 1024);
+    const int n = rest / (TP * 2 * NS * 1024);
     return n > BMX_RING_MAX ? BMX_RING_MAX : n;
 }
-// list capacity: as long as the ring keeps at least two slots (four tiles), else as short as a useful pending part allows
 #ifndef BMX_LCAP_MAX
 #define BMX_LCAP_MAX 56
 #endif
+#ifndef BMX_TP_MAX
+#define BMX_TP_MAX 2
+#endif
+// Slots of FOUR tiles (TP = 2) where a ring of three such slots fits beside lists of at least KS + 16 entries (up to 61
+// columns at KS = 32): the hand-over -- ready check, polls, hand-back: a quarter of the base loop -- then comes once per
+// four tiles (config 3: candidate passes -5 %; with two such slots: no gain, with four: as with three).  Else two tiles.
+__host__ __device__ constexpr int tile_pairs_for(int NS, int KS) {
+    return (BMX_TP_MAX >= 2 && KS + 16 <= BMX_LCAP_MAX && ring_slots_for(NS, KS + 16, 2) >= 3) ? 2 : 1;
+}
+// list capacity: the longest that leaves the ring three slots of four tiles, or at least two slots of two; else as short as
+// a useful pending part allows
 __host__ __device__ constexpr int list_cap(int NS, int KS) {
+    const int TP = tile_pairs_for(NS, KS);
     for (int c = BMX_LCAP_MAX; c >= KS + 16; c -= 8)
-        if (ring_slots_for(NS, c) >= 2) return c;
+        if (ring_slots_for(NS, c, TP) >= (TP == 2 ? 3 : 2)) return c;
     return KS + 16 <= 64 ? KS + 16 : 64;
 }
 
@@ -253,8 +264,9 @@ __global__ __launch_bounds__((NCONS + NPROD + serv_waves(NS)) * 64) void knn_top
     int n_full, int nranges, int out_chunk0, int out_nchunks, uint32_t* __restrict__ tau_g, int32_t* __restrict__ cand,
     float* __restrict__ cand_v, float* __restrict__ tau_out, const float* __restrict__ margin_g, int kq) {
     constexpr int TILE_BYTES = NS * 1024;
-    constexpr int SLOT_BYTES = 2 * TILE_BYTES;
-    constexpr int NSLOT = ring_slots_for(NS, LCAP);
+    constexpr int TP = tile_pairs_for(NS, KS);  // tile pairs per ring slot
+    constexpr int SLOT_BYTES = TP * 2 * TILE_BYTES;
+    constexpr int NSLOT = ring_slots_for(NS, LCAP, TP);
     static_assert(NSLOT >= 2, "LDS ring");
     static_assert(LCAP <= 64 && LCAP > KS, "one list entry per lane during compaction");
     // what a cut in mid-sweep may keep: a full list must come out with room again (the appends that found it full retry
@@ -293,7 +305,7 @@ __global__ __launch_bounds__((NCONS + NPROD + serv_waves(NS)) * 64) void knn_top
         r_end = min(r_limit, r_begin + range_len);
     }
     const int ntiles = (r_end - r_begin) >> 5;  // even: ranges are multiples of 64 rows
-    const int nslots = ntiles >> 1;
+    const int nslots = ntiles / (2 * TP);  // (ranges are multiples of 64 TP rows)
     const int out_chunk = out_chunk0 + rng;
     if (tid < 2 * NSLOT + 3 * NCONS) ready[tid] = 0;  // ready[], done[], wrL[], rdL[], stL[] are contiguous
     if (tid < NQ) {
@@ -492,16 +504,48 @@ __global__ __launch_bounds__((NCONS + NPROD + serv_waves(NS)) * 64) void knn_top
         // unconditional (past the end: the last slot again, never published): with conditional loads the compiler has to
         // wait for ALL outstanding loads before it touches a register set -- the set just asked for included -- because
         // it cannot tell how many are in flight
-        if (nslots > 0) {
-            const int last = nslots - 1;
-            int sl = p;
-            load(ra, sl < last ? sl : last);
-            load(rb, sl + NPROD < last ? sl + NPROD : last);
-            for (; sl < nslots; sl += 2 * NPROD) {
-                publish(ra, sl);
-                load(ra, sl + 2 * NPROD < last ? sl + 2 * NPROD : last);
-                if (sl + NPROD < nslots) publish(rb, sl + NPROD);
-                load(rb, sl + 3 * NPROD < last ? sl + 3 * NPROD : last);
+        if constexpr (TP == 1) {
+            if (nslots > 0) {
+                const int last = nslots - 1;
+                int sl = p;
+                load(ra, sl < last ? sl : last);
+                load(rb, sl + NPROD < last ? sl + NPROD : last);
+                for (; sl < nslots; sl += 2 * NPROD) {
+                    publish(ra, sl);
+                    load(ra, sl + 2 * NPROD < last ? sl + 2 * NPROD : last);
+                    if (sl + NPROD < nslots) publish(rb, sl + NPROD);
+                    load(rb, sl + 3 * NPROD < last ? sl + 3 * NPROD : last);
+                }
+            }
+        } else {
+            // slots of four tiles: a producer stages whole slots, its two register sets hold the two halves of one; the
+            // ready word goes out after the second half
+            auto load_half = [&](f32x4(&r)[2 * NS], int sl, int half) {
+#pragma unroll
+                for (int s = 0; s < 2 * NS; ++s) r[s] = src[(((int64_t)sl * TP + half) * 2 * NS + s) * 64];
+            };
+            auto store_half = [&](const f32x4(&r)[2 * NS], int pos, int half) {
+                f32x4* dst = ring_l + pos * (SLOT_BYTES / 16) + half * (2 * TILE_BYTES / 16);
+#pragma unroll
+                for (int s = 0; s < 2 * NS; ++s) dst[s * 64] = r[s];
+            };
+            if (nslots > 0) {
+                const int last = nslots - 1;
+                int sl = p;
+                load_half(ra, sl < last ? sl : last, 0);
+                load_half(rb, sl < last ? sl : last, 1);
+                for (; sl < nslots; sl += NPROD) {
+                    const int pos = sl % NSLOT;
+                    const int nx = sl + NPROD < last ? sl + NPROD : last;
+                    wait_free(sl, pos);
+                    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                    store_half(ra, pos, 0);
+                    load_half(ra, nx, 0);
+                    store_half(rb, pos, 1);
+                    load_half(rb, nx, 1);
+                    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                    if (lane == 0) __hip_atomic_store(&ready[pos], sl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
         }
         // two empty slots past the end: the consumers' loop runs one step longer than the data and always refills from
@@ -913,50 +957,58 @@ __global__ __launch_bounds__((NCONS + NPROD + serv_waves(NS)) * 64) void knn_top
                 b[s] = tp[(NS + s) * 64];
             }
         }
-        hand_back(0);
+        if constexpr (TP == 1) hand_back(0);  // (a slot of four tiles is handed back once its second half has been read)
         poll(1 % NSLOT);
-        // One iteration = one slot = two tiles.  Matrix phase: the two tiles' MFMA chains interleaved (independent
+        // One iteration = one pair of tiles.  Matrix phase: the two tiles' MFMA chains interleaved (independent
         // accumulators: the wave issues its 2 NS MFMAs back to back without waiting on its own results), each fragment
-        // register refilled from the next slot right after the MFMA that consumed it.  Vector phase: filter and spill of
+        // register refilled from the next pair right after the MFMA that consumed it.  Vector phase: filter and spill of
         // both tiles.  The two consumer waves of a SIMD fall into opposite phases: one's vector phase runs under the
-        // other's MFMAs.
+        // other's MFMAs.  With slots of four tiles (TP = 2) only every other pair crosses a slot boundary: the ready
+        // check, the polls and the hand-back happen once per four tiles.
+        auto tile_pair = [&](const lds_f4ptr tp, const int t0, const int hand_back_pos) __attribute__((always_inline)) {
+            f32x16 accA, accB;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) accA[e] = accB[e] = 0.f;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[s]), bq[s], accA, 0, 0, 0);
+                a[s] = tp[s * 64];
+                accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, b[s]), bq[s], accB, 0, 0, 0);
+                b[s] = tp[(NS + s) * 64];
+            }
+#pragma unroll
+            for (int s = 0; s < 2 * NS; ++s) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one LDS read
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (hand_back_pos >= 0) hand_back(hand_back_pos);  // that slot's tiles are all on their way into registers
+            const float mnA = sift(accA, t0);
+            const float mnB = sift(accB, t0 + 1);
+            if constexpr (SAMPLE) {
+                // sorted insertion of ONE candidate per pair: the lane's minimum over both tiles (32 references of
+                // one query; still one distinct reference per candidate, half the insertions)
+                sample_insert(fminf(fminf(mnA, mnB), mnB));
+            }
+        };
         for (int sl0 = 0; sl0 < nslots; sl0 += NSLOT) {
 #pragma unroll
             for (int k = 0; k < NSLOT; ++k) {
-                const int sl = sl0 + k;  // its fragments are in a[], b[]; slot sl + 1 sits at position kn
+                const int sl = sl0 + k;  // its (first) fragments are in a[], b[]; slot sl + 1 sits at position kn
                 if (sl >= nslots) break;
                 const int kn = (k + 1) % NSLOT;
-                __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this slot's fragments, the next one's ready word, tau
+                if constexpr (TP == 2) {
+                    // first pair of the slot: refill from the slot's own second half, then the slot is read
+                    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this pair's fragments
+                    tile_pair((lds_f4ptr)(ring_lane + k * SLOT_BYTES + 2 * TILE_BYTES), 4 * sl, k);
+                }
+                __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this pair's fragments, the next slot's ready word, tau
                 if constexpr (!SAMPLE) asm("v_min_f32 %0, %0, %1" : "+v"(tau) : "v"(tau_next));
                 spin_until_staged(sl + 1, kn);
                 __atomic_signal_fence(__ATOMIC_SEQ_CST);
                 poll((kn + 1) % NSLOT);
-                const lds_f4ptr tp = (lds_f4ptr)(ring_lane + kn * SLOT_BYTES);
-                f32x16 accA, accB;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) accA[e] = accB[e] = 0.f;
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[s]), bq[s], accA, 0, 0, 0);
-                    a[s] = tp[s * 64];
-                    accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, b[s]), bq[s], accB, 0, 0, 0);
-                    b[s] = tp[(NS + s) * 64];
-                }
-#pragma unroll
-                for (int s = 0; s < 2 * NS; ++s) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one LDS read
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                hand_back(kn);  // both tiles of slot sl + 1 are on their way into the fragment registers
-                const float mnA = sift(accA, 2 * sl);
-                const float mnB = sift(accB, 2 * sl + 1);
-                if constexpr (SAMPLE) {
-                    // sorted insertion of ONE candidate per slot: the lane's minimum over both tiles (32 references of
-                    // one query; still one distinct reference per candidate, half the insertions)
-                    sample_insert(fminf(fminf(mnA, mnB), mnB));
-                }
+                tile_pair((lds_f4ptr)(ring_lane + kn * SLOT_BYTES), 2 * TP * sl + 2 * (TP - 1), TP == 1 ? kn : -1);
             }
         }
     }
@@ -1021,7 +1073,9 @@ __global__ __launch_bounds__((NCONS + NPROD + serv_waves(NS)) * 64) void knn_top
 template <int NS, int KS>
 void launch(hipStream_t stream, KnnWorkspace& ws, const Bf16Launch& L) {
     constexpr int LCAP = list_cap(NS, KS);
-    constexpr size_t lds = (size_t)ring_slots_for(NS, LCAP) * 2 * NS * 1024 + (size_t)NQ * LCAP * 8 + lds_fixed_bytes();
+    constexpr int TP = tile_pairs_for(NS, KS);
+    constexpr size_t lds =
+        (size_t)ring_slots_for(NS, LCAP, TP) * TP * 2 * NS * 1024 + (size_t)NQ * LCAP * 8 + lds_fixed_bytes();
     static_assert(lds <= 160 * 1024, "LDS budget");
     ensure_dynamic_lds(reinterpret_cast<const void*>(&knn_topk_f16<NS, KS, LCAP, false>), lds);
     ensure_dynamic_lds(reinterpret_cast<const void*>(&knn_topk_f16<NS, KS, LCAP, true>), lds);
@@ -1125,5 +1179,6 @@ bool f16_launch(hipStream_t stream, KnnWorkspace& ws, int NS, int KS, const Bf16
 }
 
 double f16_scale_host(double max_n2) { return f16_scale(max_n2); }
+int f16_rows_per_slot(int NS, int KS) { return 64 * tile_pairs_for(NS, KS); }
 
 }  // namespace bmx
