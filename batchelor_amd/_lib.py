@@ -53,6 +53,12 @@ def check(rc):
         raise BatchelorMI355XError(rc, lib().bmx_last_error().decode("utf-8", "replace"))
 
 
+def dev_set(name, value):
+    """Testing hook (bmx_dev_set): process-wide knobs of the library that tests and developer scripts set explicitly --
+    the environment of the host process never changes what the library computes.  dev_set("reset", 0) restores all."""
+    check(lib().bmx_dev_set(name.encode(), ctypes.c_int32(int(value))))
+
+
 def device_count():
     return int(lib().bmx_device_count())
 

@@ -134,6 +134,26 @@ int64_t bmx_last_knn_exact_fallbacks(void) { return g_last_fallbacks; }
 
 void bmx_set_force_exact_knn(int32_t on) { g_force_exact = on; }
 
+int32_t bmx_dev_set(const char* name, int32_t value) {
+    if (!name) return BMX_ERR_ARG;
+    bmx::DevKnobs& k = bmx::dev_knobs();
+    const std::string n(name);
+    if (n == "knn_tier") k.knn_tier = value;
+    else if (n == "sample") k.sample = value;
+    else if (n == "split_c") k.split_c = value;
+    else if (n == "force_c") k.force_c = value;
+    else if (n == "no_margin") k.no_margin = value;
+    else if (n == "asv_fast") k.asv_fast = value;
+    else if (n == "exchange_always") k.exchange_always = value;
+    else if (n == "refine_full") k.refine_full = value;
+    else if (n == "reset") k = bmx::DevKnobs();
+    else {
+        g_last_error = "bmx_dev_set: unknown knob '" + n + "'";
+        return BMX_ERR_ARG;
+    }
+    return BMX_OK;
+}
+
 void bmx_shard_range(int64_t n, int32_t rank, int32_t world, int64_t* begin, int64_t* end) {
     bmx::bmx_shard_range_impl(n, rank, world, begin, end);
 }
@@ -428,24 +448,16 @@ int32_t bmx_adjust_shift_variance(const double* data1, int32_t g1, int32_t n1, c
         const int32_t* q1 = upload(dr1, restrict1, (size_t)nr1, s);
         const int32_t* q2 = upload(dr2, restrict2, (size_t)nr2, s);
         double* po = dO.reserve(n2);
-        int asv_blocks = 1, asv_npad = 1, asv_exact = 1;
-        double* pw = dW.reserve(bmx::adjust_shift_variance_scratch(n2, nr1, nr2, &asv_blocks, &asv_npad, &asv_exact) +
-                                bmx::adjust_shift_variance_extra(g, nr1, nr2, n2, 0));
-        bmx::adjust_shift_variance_device(s, p1, g, n1, p2, n2, pv, sigma2, q1, nr1, q2, nr2, po, pw);
+        const bmx::AsvPlan plan = bmx::adjust_shift_variance_plan(g, n2, nr1, nr2, 0);
+        double* pw = dW.reserve(plan.main_doubles + plan.extra_doubles);
+        bmx::adjust_shift_variance_device(s, p1, g, n1, p2, n2, pv, sigma2, q1, nr1, q2, nr2, po, pw, plan);
         BMX_HIP(hipMemcpyAsync(out, po, (size_t)n2 * sizeof(double), hipMemcpyDeviceToHost, s));
         BMX_HIP(hipStreamSynchronize(s));
     });
 }
 
 int32_t bmx_adjust_shift_variance_form(int32_t n2, int32_t nr1, int32_t nr2) {
-    int blocks = 1, npad = 1, exact = 1;
-    try {
-        (void)bmx::adjust_shift_variance_scratch(n2, nr1, nr2, &blocks, &npad, &exact);
-    } catch (...) {
-        return 0;
-    }
-    if (exact) return 1;
-    return std::getenv("BMX_ASV_BISECT") ? 3 : 2;
+    return bmx::adjust_shift_variance_plan(1, n2, nr1, nr2, 1).exact ? 1 : 2;
 }
 
 int32_t bmx_cosine_norm(const double* x, int32_t G, int32_t n, double* l2, double* normalized) {

@@ -44,6 +44,22 @@ void guarded_stream_sync(hipStream_t stream, double budget_s);
 #define BMX_KS1 32
 #endif
 
+// Testing hooks (bmx_dev_set in the C ABI): process-wide knobs that tests and developer scripts set by an explicit call.
+// Nothing in the ENVIRONMENT of the host process changes what the library computes or which tier / form runs
+// (BMX_DEBUG=1 only prints, BMX_HOST_THREADS only sizes the staging thread pool).
+struct DevKnobs {
+    int knn_tier = 0;         // 1 / 2: that candidate tier only, 3: exact FP64 scan only
+    int sample = -1;          // rows of the threshold sample of a candidate pass (-1: automatic)
+    int split_c = 0;          // reference ranges of the tail query blocks (0: automatic)
+    int force_c = 0;          // reference ranges of EVERY query block (0: off)
+    int no_margin = 0;        // fp16 tier: lists cut at their KS-th best only (round 2's rule)
+    int asv_fast = 0;         // adjust_shift_variance: the tiled form whatever the size
+    int exchange_always = 0;  // a single rank goes through its exchange transport too (an all-gather of one)
+    int refine_full = 0;      // knn_refine: full ranking for every search (no membership-only mode)
+};
+DevKnobs& dev_knobs();
+bool debug_prints();  // BMX_DEBUG set in the environment (read once)
+
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 

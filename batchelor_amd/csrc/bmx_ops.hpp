@@ -116,13 +116,19 @@ void pca_project(Pca* p, int batch, double* out_host);
 // ---- legacy natives (legacy.hip) -------------------------------------------------------------------
 void smooth_gaussian_kernel_device(hipStream_t stream, const double* averaged, int g, int U, const int32_t* index,
                                    const double* mat, int gd, int n, double sigma2, double* out, double* ws_density);
-// doubles of scratch adjust_shift_variance_device needs (and the launch shape it will use)
-size_t adjust_shift_variance_scratch(int n2, int nr1, int nr2, int* blocks, int* npad, int* exact);
-// doubles needed BEHIND that scratch (norms of the cells, a row-major copy of vect): reserve scratch + extra
-size_t adjust_shift_variance_extra(int g, int nr1, int nr2, int n2, int vect_row_major);
+// What a call of these sizes runs and needs -- a pure function of its arguments (and of the testing hook "asv_fast"):
+// the caller reserves main_doubles + extra_doubles of scratch and hands the same plan to the launch.
+struct AsvPlan {
+    int exact = 1;   // 1: asv_exact_kernel (the reference's order of operations literally), 0: the tiled FP64-MFMA form
+    int blocks = 1;  // workgroups
+    int npad = 1;    // exact form: nr1 rounded up to a power of two
+    size_t main_doubles = 0, extra_doubles = 0;
+};
+AsvPlan adjust_shift_variance_plan(int g, int n2, int nr1, int nr2, int vect_row_major);
+// out[c] for the cells c in [cell_begin, cell_end) only (cell_end < 0: n2) -- the unit a multi-GPU run shards by
 void adjust_shift_variance_device(hipStream_t stream, const double* data1, int g, int n1, const double* data2, int n2,
                                   const double* vect, double sigma2, const int32_t* restrict1, int nr1,
-                                  const int32_t* restrict2, int nr2, double* out, double* ws_pairs,
-                                  int vect_row_major = 0);
+                                  const int32_t* restrict2, int nr2, double* out, double* ws_pairs, const AsvPlan& plan,
+                                  int vect_row_major = 0, int cell_begin = 0, int cell_end = -1);
 
 }  // namespace bmx

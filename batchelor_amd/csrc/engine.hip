@@ -61,7 +61,6 @@ Engine::Engine(int device) : device_(device) {
     BMX_HIP(hipSetDevice(device_));
     BMX_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     scal_.reserve(4096);
-    if (const char* v = std::getenv("BMX_WATCHDOG_MS")) wd_base_s_ = 1e-3 * std::atof(v);
 }
 
 void Engine::check_alive() const {
@@ -163,8 +162,8 @@ void Engine::init_rccl(int rank, int world, const void* unique_id) {
 }
 
 void Engine::exchange(void* buf, int64_t bytes_per_rank) {
-    // BMX_EXCHANGE_ALWAYS (testing hook): a single rank goes through its transport too (an in-place all-gather of one)
-    static const bool always = std::getenv("BMX_EXCHANGE_ALWAYS") != nullptr;
+    // testing hook (bmx_dev_set "exchange_always"): a single rank goes through its transport too (an all-gather of one)
+    const bool always = dev_knobs().exchange_always != 0;
     if (world_ == 1 && !(always && (comm_ || gather_fn_))) return;
     ++xchg_calls_;
     xchg_bytes_ += bytes_per_rank * world_;
@@ -282,8 +281,13 @@ void Engine::knn(const double* X, const int32_t* ref_rows, int nr, const double*
         // indices and distances of one search: grouped, RCCL sends them as one launch
         const bool group = dist && comm_ && world_ > 1 && rccl::api().GroupStart && rccl::api().GroupEnd;
         if (group) (void)rccl::api().GroupStart();
-        exchange(idx, per * k * (int64_t)sizeof(int32_t));
-        if (dist) exchange(dist, per * k * (int64_t)sizeof(double));
+        try {
+            exchange(idx, per * k * (int64_t)sizeof(int32_t));
+            if (dist) exchange(dist, per * k * (int64_t)sizeof(double));
+        } catch (...) {
+            if (group) (void)rccl::api().GroupEnd();  // never leave the group open behind an error
+            throw;
+        }
         if (group && rccl::api().GroupEnd() != 0) throw Error(BMX_ERR_EXCHANGE, "ncclGroupEnd failed");
     }
 }
@@ -316,7 +320,7 @@ Engine::MnnOut Engine::find_mnn(const Node& left, const Node& right, int k, doub
     wait();
     const int32_t nsel = pin[0];
     o.nsel = nsel;
-    if (std::getenv("BMX_DEBUG")) fprintf(stderr, "[bmx] find_mnn: %d of %d left cells are in some right cell's list\n", nsel, nL);
+    if (debug_prints()) fprintf(stderr, "[bmx] find_mnn: %d of %d left cells are in some right cell's list\n", nsel, nL);
     const int32_t* qsel = lsel;  // rows of left.data to query with
     if (lrows) {
         int32_t* q = qsel_.reserve(nsel);
@@ -589,13 +593,19 @@ void Engine::merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p,
                 r2 = io;
             }
             BMX_LAUNCH_CHECK();
-            int blocks = 1, npad = 1, exact = 1;
-            double* ws = asv_ws_.reserve(adjust_shift_variance_scratch(right.n, nLs, nRs, &blocks, &npad, &exact) +
-                                         adjust_shift_variance_extra(d_, nLs, nRs, right.n, 1));
-            double* scaling = asv_scale_.reserve(right.n);
+            // The reference's loop is independent per right cell (src/adjust_shift_variance.cpp:51-161): each rank takes its
+            // slice of them (the layout of the sharded searches, bmx_shard_range) and the scalings are all-gathered in place.
+            // The form (exact / tiled) is decided from the WHOLE call's size, so every rank count gives the same numbers.
+            AsvPlan plan = adjust_shift_variance_plan(d_, right.n, nLs, nRs, 1);
+            int64_t cb = 0, ce = right.n;
+            bmx_shard_range_impl(right.n, rank_, world_, &cb, &ce);
+            const int64_t per_cells = bmx_shard_rows_per_rank(right.n, world_);
+            double* ws = asv_ws_.reserve(plan.main_doubles + plan.extra_doubles);
+            double* scaling = asv_scale_.reserve((size_t)per_cells * world_);
             adjust_shift_variance_device(stream_, left.data.p, d_, left.n, right.data.p, right.n, corr, p.sigma, r1, nLs, r2,
-                                         nRs, scaling, ws, /* vect_row_major */ 1);
-            queued_work_s_ += 5e-8 * (double)right.n * ((double)nLs + (double)nRs);
+                                         nRs, scaling, ws, plan, /* vect_row_major */ 1, (int)cb, (int)ce);
+            queued_work_s_ += 5e-8 * (double)(ce - cb) * ((double)nLs + (double)nRs);
+            exchange(scaling, per_cells * (int64_t)sizeof(double));
             add_scaled_rows(stream_, right.data.p, right.n, d_, corr, scaling);
         }
         right.stat_slot.assign(right.origin.size(), -1);  // the corrected cells moved

@@ -11,9 +11,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <functional>
+#include <map>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -112,19 +114,24 @@ inline void host_parallel_memcpy(void* dst, const void* src, size_t bytes) {
     });
 }
 
-// Process-wide pinned staging buffers (two per direction), handed out under a lock: transfers of different engines on
-// different threads take turns.
+// Pinned staging buffers (two per direction and DEVICE: an event belongs to the device it was created on, and recording it
+// on another device's stream fails), handed out under the ring's lock: transfers of different engines of one device take
+// turns, engines on different devices do not wait for each other.
 class PinnedRing {
   public:
     static constexpr size_t kChunk = (size_t)32 << 20;
-    static PinnedRing& upload_ring() {
-        static PinnedRing* r = new PinnedRing();
+    static PinnedRing& for_device(int direction) {
+        static std::mutex mu;
+        static std::map<std::pair<int, int>, PinnedRing*>* rings = new std::map<std::pair<int, int>, PinnedRing*>();
+        int dev = 0;
+        BMX_HIP(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> lk(mu);
+        PinnedRing*& r = (*rings)[{dev, direction}];
+        if (!r) r = new PinnedRing();  // never destroyed: no hipHostFree after the runtime is torn down
         return *r;
     }
-    static PinnedRing& download_ring() {
-        static PinnedRing* r = new PinnedRing();
-        return *r;
-    }
+    static PinnedRing& upload_ring() { return for_device(0); }
+    static PinnedRing& download_ring() { return for_device(1); }
     std::mutex mu;
     void* buf[2] = {nullptr, nullptr};
     hipEvent_t ev[2] = {nullptr, nullptr};
@@ -139,6 +146,21 @@ class PinnedRing {
     }
 };
 
+// A staging buffer's DMA is waited for with a deadline too (the watchdog contract of bmx_common.hpp: the host never waits
+// without one): a copy queued behind a kernel that never ends gives up with an error instead of blocking the process.
+inline void guarded_event_sync(hipEvent_t ev, double budget_s = 120.0) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e == hipSuccess) return;
+        (void)hipGetLastError();
+        if (e != hipErrorNotReady) throw Error(BMX_ERR_HIP, std::string("hipEventQuery failed: ") + hipGetErrorString(e));
+        const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (el > budget_s) throw WatchdogTimeout("watchdog: a staged host transfer did not finish in time");
+        if (el > 2e-3) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+}
+
 // host (pageable) -> device on `stream`.  The caller's memory has been read completely when this returns; the last DMA
 // may still be in flight on the stream (later work on the stream is ordered behind it).
 inline void upload_pageable(void* dev, const void* host, size_t bytes, hipStream_t stream) {
@@ -151,7 +173,14 @@ inline void upload_pageable(void* dev, const void* host, size_t bytes, hipStream
     for (size_t o = 0; o < bytes; o += PinnedRing::kChunk) {
         const size_t m = std::min(PinnedRing::kChunk, bytes - o);
         const int c = r.cur;
-        if (r.busy[c]) BMX_HIP(hipEventSynchronize(r.ev[c]));
+        if (r.busy[c]) {
+            try {
+                guarded_event_sync(r.ev[c]);
+            } catch (...) {
+                r.busy[0] = r.busy[1] = false;  // (the stream these were recorded on is stuck: the next user starts afresh)
+                throw;
+            }
+        }
         host_parallel_memcpy(r.buf[c], src + o, m);
         BMX_HIP(hipMemcpyAsync(dst + o, r.buf[c], m, hipMemcpyHostToDevice, stream));
         BMX_HIP(hipEventRecord(r.ev[c], stream));
@@ -177,7 +206,7 @@ inline void download_pageable(void* host, const void* dev, size_t bytes, hipStre
     };
     issue(0);
     for (size_t i = 0; i < nchunks; ++i) {
-        BMX_HIP(hipEventSynchronize(r.ev[i & 1]));
+        guarded_event_sync(r.ev[i & 1]);
         if (i + 1 < nchunks) issue(i + 1);  // the other buffer fills while this one is copied out
         const size_t o = i * PinnedRing::kChunk, m = std::min(PinnedRing::kChunk, bytes - o);
         host_parallel_memcpy(dst + o, r.buf[i & 1], m);

@@ -559,10 +559,7 @@ struct Tier {
 
 // the candidate tiers that take this shape, cheapest first
 int candidate_tiers(int d, int k, int nr, Tier out[2]) {
-    static const int only = [] {
-        const char* v = std::getenv("BMX_KNN_TIER");  // developer switch: 1 / 2 = that tier only, 3 = exact scan only
-        return v ? std::atoi(v) : 0;
-    }();
+    const int only = dev_knobs().knn_tier;  // testing hook: 1 / 2 = that tier only, 3 = exact scan only
     int n = 0;
     if (k > 36) return 0;
     const int KS1 = k <= 20 ? BMX_KS1 : 48, KS2 = k <= 20 ? 24 : 40;
@@ -600,8 +597,7 @@ void candidate_pass(hipStream_t stream, KnnWorkspace& ws, const Tier& T, const d
     // (a seeded search samples too, but a sixth of the rows: the odd query whose seed is loose -- a left cell listed by
     // one far-away right cell -- then starts from a sampled threshold instead of none; the tighter of the two counts)
     if (seed_d2 && T.id == 1) S_auto = std::min(S_auto, BMX_SEEDED_SAMPLE);
-    int S = (int)round_up(std::getenv("BMX_SAMPLE") ? std::atoi(std::getenv("BMX_SAMPLE")) : S_auto,
-                          T.id == 1 ? f16_rows_per_slot(NS, KS) : 64);
+    int S = (int)round_up(dev_knobs().sample >= 0 ? dev_knobs().sample : S_auto, T.id == 1 ? f16_rows_per_slot(NS, KS) : 64);
     int C = 1, n_full = 0;
     {
         const int a = nqb / 256, b = nqb % 256;
@@ -618,9 +614,9 @@ void candidate_pass(hipStream_t stream, KnnWorkspace& ws, const Tier& T, const d
             }
         }
     }
-    if (std::getenv("BMX_SPLIT_C")) C = std::max(1, std::atoi(std::getenv("BMX_SPLIT_C")));
-    if (std::getenv("BMX_FORCE_C")) {
-        C = std::max(1, std::min(MAX_CHUNKS - 1, std::atoi(std::getenv("BMX_FORCE_C"))));
+    if (dev_knobs().split_c > 0) C = std::max(1, dev_knobs().split_c);
+    if (dev_knobs().force_c > 0) {
+        C = std::max(1, std::min(MAX_CHUNKS - 1, dev_knobs().force_c));
         n_full = 0;
     }
     const int rmul = T.id == 1 ? f16_rows_per_slot(NS, KS) : 32;  // the fp16 ring hands two (or four) tiles over at a time
@@ -629,7 +625,7 @@ void candidate_pass(hipStream_t stream, KnnWorkspace& ws, const Tier& T, const d
     const int nr_pad = chunk_len * C;
     const int nchunks = C;
     S = std::min(S, nr_pad / rmul * rmul);  // (a forced sample size beyond the reference: the prepared image ends at nr_pad)
-    if (std::getenv("BMX_DEBUG"))
+    if (debug_prints())
         fprintf(stderr, "[bmx] knn tier %d: nq=%d nr=%d d=%d NS=%d KS=%d S=%d C=%d chunk=%d full-range blocks=%d of %d\n", T.id,
                 nq, nr, d, NS, KS, S, C, chunk_len, C > 1 ? n_full : nqb, nqb);
 
@@ -689,7 +685,7 @@ void candidate_pass(hipStream_t stream, KnnWorkspace& ws, const Tier& T, const d
     }
     Bf16Launch L{reinterpret_cast<const uint16_t*>(pq), reinterpret_cast<const uint16_t*>(pr), nqb, 0, S, 1, S, 0, nchunks,
                  tau_g, 1, cand, cand_v, tau};
-    static const bool no_margin = std::getenv("BMX_NO_MARGIN") != nullptr;  // developer switch: the KS-th-best cut only
+    const bool no_margin = dev_knobs().no_margin != 0;  // testing hook: the KS-th-best cut only
     if (T.id == 1 && !no_margin) {
         float* margin = ws.margin.reserve(nq_pad);
         hipLaunchKernelGGL(margin_kernel, dim3(cdiv(nq_pad, 256)), dim3(256), 0, stream, qn2, maxbits, nq, nq_pad, eps_k,
@@ -735,7 +731,7 @@ void candidate_pass(hipStream_t stream, KnnWorkspace& ws, const Tier& T, const d
 #undef BMX_REFINE
     }
     BMX_LAUNCH_CHECK();
-    if (std::getenv("BMX_DEBUG")) {
+    if (debug_prints()) {
         std::vector<int32_t> hc((size_t)nq * nchunks * KS);
         BMX_HIP(hipMemcpyAsync(hc.data(), cand, hc.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
         ws.sync(stream);
@@ -754,6 +750,16 @@ int read_count(hipStream_t stream, KnnWorkspace& ws, const int32_t* dev) {
 }
 
 }  // namespace
+
+DevKnobs& dev_knobs() {
+    static DevKnobs k;
+    return k;
+}
+
+bool debug_prints() {
+    static const bool on = std::getenv("BMX_DEBUG") != nullptr;
+    return on;
+}
 
 void guarded_stream_sync(hipStream_t stream, double budget_s) {
     if (!(budget_s > 0.0)) {

@@ -14,7 +14,7 @@
 // cost O(cells x (nr1 + nr2)) dependent steps (1.6 ns per pair): it is taken up to 4e7 pairs per call; beyond that
 // asv_tile_kernel (16-cell tiles on the FP64 matrix cores + a sort-free histogram quantile, 0.015 ns per pair) takes over and
 // agrees except on those ill-conditioned cells (tests/testthat/test-mnn-correct.R:141,396-399 acknowledge the effect
-// upstream).  asv_kernel is round 2's scalable form, kept behind BMX_ASV_BISECT=1.
+// upstream).
 #include "bmx_ops.hpp"
 #include "portable_math.hpp"
 
@@ -226,155 +226,6 @@ __global__ __launch_bounds__(256) void sgk_flash(const double* __restrict__ X, i
 }
 
 // ---------------------------------------------------------------------------------------------------
-// adjust_shift_variance: one workgroup per cell of data2 (grid-stride), scratch = (proj, weight) of restrict1
-// ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned long long f64_orderable(double v) {
-    unsigned long long u = (unsigned long long)__double_as_longlong(v);
-    return u ^ ((u >> 63) ? ~0ull : 0x8000000000000000ull);
-}
-__device__ __forceinline__ double orderable_f64(unsigned long long o) {
-    unsigned long long u = o ^ ((o >> 63) ? 0x8000000000000000ull : ~0ull);
-    return __longlong_as_double((long long)u);
-}
-
-__global__ __launch_bounds__(T) void asv_kernel(const double* __restrict__ data1, int g, int n1,
-                                                const double* __restrict__ data2, int n2,
-                                                const double* __restrict__ vect, int64_t vs_cell, int64_t vs_x,
-                                                double sigma2, const int32_t* __restrict__ r1, int nr1,
-                                                const int32_t* __restrict__ r2, int nr2, double* __restrict__ out,
-                                                double* __restrict__ scratch) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    double* grad = reinterpret_cast<double*>(smem_raw);  // [g]
-    double* cur = grad + g;                              // [g]
-    __shared__ double sm[T];
-    __shared__ double sh_l2, sh_proj;
-    const int tid = threadIdx.x;
-    double* proj1 = scratch + (int64_t)blockIdx.x * 2 * nr1;
-    double* lw1 = proj1 + nr1;
-
-    for (int cell = blockIdx.x; cell < n2; cell += gridDim.x) {
-        // unit gradient and own projection (adjust_shift_variance.cpp:57-70)
-        for (int x = tid; x < g; x += T) {
-            grad[x] = vect[(int64_t)x * vs_x + (int64_t)cell * vs_cell];
-            cur[x] = data2[(int64_t)cell * g + x];
-        }
-        __syncthreads();
-        if (tid == 0) {
-            double l2 = 0.0;
-            for (int x = 0; x < g; ++x) l2 += grad[x] * grad[x];
-            sh_l2 = sqrt(l2);
-        }
-        __syncthreads();
-        const double l2 = sh_l2;
-        if (l2 != 0.0)
-            for (int x = tid; x < g; x += T) grad[x] /= l2;
-        __syncthreads();
-        if (tid == 0) {
-            double p = 0.0;
-            for (int x = 0; x < g; ++x) p += grad[x] * cur[x];
-            sh_proj = p;
-        }
-        __syncthreads();
-        const double curproj = sh_proj;
-
-        // own-batch cumulative probability (:74-112): two passes, max then sums
-        auto pair_stats = [&](const double* other, double& proj, double& lw) {
-            double pr = 0.0, sc = 0.0;
-            for (int x = 0; x < g; ++x) {
-                pr += grad[x] * other[x];
-                sc += (cur[x] - other[x]) * grad[x];
-            }
-            double dist = 0.0;
-            for (int x = 0; x < g; ++x) {
-                const double w = (cur[x] - other[x]) - sc * grad[x];
-                dist += w * w;
-            }
-            proj = pr;
-            lw = -dist / sigma2;
-        };
-        double mx = -__builtin_inf();
-        for (int s = tid; s < nr2; s += T) {
-            const int same = r2[s];
-            double pr, lw;
-            if (same == cell)
-                lw = 0.0;
-            else
-                pair_stats(data2 + (int64_t)same * g, pr, lw);
-            mx = fmax(mx, lw);
-        }
-        mx = block_max(mx, sm);
-        double below = 0.0, all = 0.0;
-        for (int s = tid; s < nr2; s += T) {
-            const int same = r2[s];
-            double pr = 0.0, lw = 0.0;
-            bool add = true;
-            if (same != cell) {
-                pair_stats(data2 + (int64_t)same * g, pr, lw);
-                add = !(pr > curproj);
-            }
-            const double w = exp(lw - mx);
-            all += w;
-            if (add) below += w;
-        }
-        below = block_sum(below, sm);
-        all = block_sum(all, sm);
-        // prob2 (log) = log(below) - log(all); with nothing added the reference's prob2 stays 0 before the subtraction
-        const double prob2 = (nr2 > 0 ? (below > 0.0 ? mx + log(below) : 0.0) - (mx + log(all)) : 0.0);
-
-        // reference batch: projections and log-weights (:115-135)
-        double mx1 = -__builtin_inf();
-        for (int o = tid; o < nr1; o += T) {
-            double pr, lw;
-            pair_stats(data1 + (int64_t)r1[o] * g, pr, lw);
-            proj1[o] = pr;
-            lw1[o] = lw;
-            mx1 = fmax(mx1, lw);
-        }
-        mx1 = block_max(mx1, sm);
-        double tot1 = 0.0;
-        for (int o = tid; o < nr1; o += T) {
-            const double w = exp(lw1[o] - mx1);
-            lw1[o] = w;  // now a linear weight relative to the maximum
-            tot1 += w;
-        }
-        tot1 = block_sum(tot1, sm);
-
-        double ref_quan = __builtin_nan("");
-        if (nr1 > 0) {
-            // smallest projection whose cumulative weight reaches exp(prob2) * total (:138-157); found by bisection on
-            // the order-preserving integer image of the projections (sort-free, deterministic reductions)
-            const double target = exp(prob2) * tot1;
-            unsigned long long lo = 0ull, hi = ~0ull;  // invariant: cum(<= hi) >= target or hi is the fallback
-            // does any prefix reach the target at all?  (default: last element, :141)
-            double mxp = -__builtin_inf();
-            for (int o = tid; o < nr1; o += T) mxp = fmax(mxp, proj1[o]);
-            mxp = block_max(mxp, sm);
-            hi = f64_orderable(mxp);
-            while (lo < hi) {
-                const unsigned long long mid = lo + (hi - lo) / 2;
-                double cum = 0.0;
-                for (int o = tid; o < nr1; o += T)
-                    if (f64_orderable(proj1[o]) <= mid) cum += lw1[o];
-                cum = block_sum(cum, sm);
-                if (cum >= target)
-                    hi = mid;
-                else
-                    lo = mid + 1;
-            }
-            // hi is now the smallest key with cum >= target (or the maximum); snap to the data value at / above it
-            double best = __builtin_inf();
-            for (int o = tid; o < nr1; o += T)
-                if (f64_orderable(proj1[o]) >= hi) best = fmin(best, proj1[o]);
-            best = -block_max(-best, sm);
-            ref_quan = best;
-        }
-        if (tid == 0) out[cell] = (ref_quan - curproj) / l2;  // :160
-        __syncthreads();
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------------
 // adjust_shift_variance, literal order of operations (src/adjust_shift_variance.cpp:52-161), one workgroup per cell.
 // scratch per workgroup: lw2 [nr2], add2 [nr2] (1.0 / 0.0), key [npad] x 2 (projection, log-weight; npad = nr1 rounded
 // up to a power of two, padded with +inf so that the padding sorts last).
@@ -387,7 +238,8 @@ __global__ __launch_bounds__(T) void asv_exact_kernel(const double* __restrict__
                                                       int n2, const double* __restrict__ vect, int64_t vs_cell,
                                                       int64_t vs_x, double sigma2, const int32_t* __restrict__ r1, int nr1,
                                                       const int32_t* __restrict__ r2, int nr2, int npad,
-                                                      double* __restrict__ out, double* __restrict__ scratch) {
+                                                      double* __restrict__ out, double* __restrict__ scratch,
+                                                      int cell_begin, int cell_end) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* grad = reinterpret_cast<double*>(smem_raw);  // [g]
     double* cur = grad + g;                              // [g]
@@ -398,7 +250,7 @@ __global__ __launch_bounds__(T) void asv_exact_kernel(const double* __restrict__
     double* kp = add2 + nr2;  // projections
     double* kw = kp + npad;   // log-weights
 
-    for (int cell = blockIdx.x; cell < n2; cell += gridDim.x) {
+    for (int cell = cell_begin + blockIdx.x; cell < cell_end; cell += gridDim.x) {
         for (int x = tid; x < g; x += T) {
             grad[x] = vect[(int64_t)x * vs_x + (int64_t)cell * vs_cell];
             cur[x] = data2[(int64_t)cell * g + x];
@@ -525,7 +377,7 @@ __global__ __launch_bounds__(T) void asv_exact_kernel(const double* __restrict__
 //      crosses the target is collected, sorted and walked; a bin that is still too full is subdivided again.
 // Weights are taken relative to the cell's largest one and kept to 2^-40: a reference cell 28 sigma2 further from the line
 // than the nearest contributes nothing, as in FP64 it would not either beyond 37.  Cells whose walk is decided on the last
-// bits may pick the neighbouring quantile (as with asv_kernel; asv_exact_kernel is the bit-exact form, taken up to 4e7 pairs).
+// bits may pick the neighbouring quantile (asv_exact_kernel is the bit-exact form, taken up to 4e7 pairs).
 // ---------------------------------------------------------------------------------------------------
 constexpr int AT_C = 16;        // cells per tile
 constexpr int AT_R = 64;        // streamed cells per step
@@ -673,7 +525,7 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                                                      const double* __restrict__ vect, double sigma2, int nr1, int nr2,
                                                      const double* __restrict__ S, const double* __restrict__ snrm,
                                                      const int32_t* __restrict__ sid, double* __restrict__ out,
-                                                     double* __restrict__ scratch) {
+                                                     double* __restrict__ scratch, int cell_begin, int cell_end) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int GP = asv_tile_gp(g);
     double* cx = reinterpret_cast<double*>(smem_raw);  // [16][GP] the tile's cells
@@ -708,11 +560,13 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
     // walked the scratch at a stride of exactly 8 KB, i.e. through a handful of the memory channels
     const int rot0 = blockIdx.x;
     auto at = [rot0](int c, int64_t j) { return (((j >> 6) * AT_C + ((c + (int)(j >> 6) + rot0) & (AT_C - 1))) << 6) + (j & 63); };
-    const int ntiles = (n2 + AT_C - 1) / AT_C;
+    // (a rank of a multi-GPU run owns the cells [cell_begin, cell_end) only; n2 below is the end of that range)
+    n2 = cell_end;
+    const int ntiles = (cell_end - cell_begin + AT_C - 1) / AT_C;
     const double NEG = -__builtin_inf(), POS = __builtin_inf();
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int c0 = tile * AT_C;
+        const int c0 = cell_begin + tile * AT_C;
         // ---- the tile's cells: coordinates, unit gradient (:57-70), own projection
         for (int e = tid; e < AT_C * GP; e += T) {
             const int c = e / GP, x = e - c * GP;
@@ -1121,65 +975,55 @@ void smooth_gaussian_kernel_device(hipStream_t stream, const double* averaged, i
     BMX_LAUNCH_CHECK();
 }
 
-// Which form runs and what it needs.  exact = 1: asv_exact_kernel (bit-exact walk; up to 131 072 restricted cells and 4e7 pairs);
-// exact = 0: the tiled FP64-MFMA form, `blocks` workgroups with 2 x 16 x (nr1 + nr2) doubles of scratch each, behind them
-// the squared norms of both batches' cells and (vect handed over column-major) a row-major copy of vect.
-// BMX_ASV_FAST=1 forces the tiled form (tests), BMX_ASV_BISECT=1 selects round 2's scalable form (asv_kernel).
-size_t adjust_shift_variance_scratch(int n2, int nr1, int nr2, int* blocks, int* npad, int* exact) {
-    static const int force_fast = std::getenv("BMX_ASV_FAST") != nullptr;  // developer switch
+// Which form runs and what it needs: a PURE function of the sizes (and of the testing hook "asv_fast"), so that the
+// caller's allocation and the launch agree whatever happens to the free memory in between.  exact = 1: asv_exact_kernel
+// (bit-exact walk; up to 131 072 restricted cells and 4e7 pairs); exact = 0: the tiled FP64-MFMA form, `blocks` workgroups
+// with 2 x 16 x (nr1 + nr2) doubles of scratch each, behind them (`extra_doubles`) the gathered stream, the squared norms
+// of its cells and -- vect handed over column-major -- a row-major copy of vect.
+AsvPlan adjust_shift_variance_plan(int g, int n2, int nr1, int nr2, int vect_row_major) {
+    AsvPlan pl;
     // the bit-exact form's sequential log-sum chains cost ~1.6 ns per (cell, restricted cell) pair, the tiled form 0.015:
     // exact up to 4e7 pairs (the reference's own test shapes and anything a test can check against the CPU), tiled beyond
-    *exact = !force_fast && (int64_t)nr1 + nr2 <= 131072 && (double)std::max(n2, 1) * ((double)nr1 + nr2) <= 4e7;
+    pl.exact = !dev_knobs().asv_fast && (int64_t)nr1 + nr2 <= 131072 && (double)std::max(n2, 1) * ((double)nr1 + nr2) <= 4e7;
     int p = 1;
     while (p < std::max(nr1, 1)) p <<= 1;
-    *npad = p;
-    if (*exact) {
+    pl.npad = p;
+    if (pl.exact) {
         const size_t per_block = 2 * (size_t)nr2 + 2 * (size_t)p;
         const size_t budget = (size_t)1 << 27;  // doubles: 1 GiB of scratch at most
-        *blocks = (int)std::max<size_t>(1, std::min<size_t>({(size_t)std::max(n2, 1), (size_t)1024, budget / std::max<size_t>(per_block, 1)}));
-        return per_block * (size_t)*blocks;
-    }
-    static const int bisect = std::getenv("BMX_ASV_BISECT") != nullptr;
-    if (bisect) {
-        const size_t per_block = 2 * (size_t)std::max(nr1, 1);
-        *blocks = (int)std::max<size_t>(1, std::min<size_t>({(size_t)std::max(n2, 1), (size_t)1024, ((size_t)1 << 27) / per_block}));
-        return per_block * (size_t)*blocks;
+        pl.blocks = (int)std::max<size_t>(1, std::min<size_t>({(size_t)std::max(n2, 1), (size_t)1024, budget / std::max<size_t>(per_block, 1)}));
+        pl.main_doubles = per_block * (size_t)pl.blocks;
+        pl.extra_doubles = 16;
+        return pl;
     }
     const size_t N = asv_tile_npad((size_t)nr1 + (size_t)nr2);  // (padded to whole pairs of steps of the stream)
     const size_t per_block = (size_t)2 * AT_C * N;
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
-    const size_t budget = std::max<size_t>((size_t)1 << 27, free_b / 2 / sizeof(double));  // half of what is free
+    const size_t budget = (size_t)12 << 30;  // doubles: 96 GiB of the 288 at most
     const size_t tiles = ((size_t)std::max(n2, 1) + AT_C - 1) / AT_C;
-    *blocks = (int)std::max<size_t>(1, std::min<size_t>({tiles, (size_t)256, budget / per_block}));
-    return per_block * (size_t)*blocks;
-}
-
-// extra doubles the tiled form keeps behind its scratch: norms of both batches, and vect row-major if it is not
-size_t adjust_shift_variance_extra(int g, int nr1, int nr2, int n2, int vect_row_major) {
-    // (the nr1 + nr2 streamed cells: their rows, norms, ids; a row-major copy of vect if it came column-major)
-    const size_t N = asv_tile_npad((size_t)nr1 + (size_t)nr2);
-    return N * asv_tile_gs(g) + N + (N + 1) / 2 + 2 + (vect_row_major ? 0 : (size_t)n2 * g) + 16;
+    pl.blocks = (int)std::max<size_t>(1, std::min<size_t>({tiles, (size_t)256, budget / per_block}));
+    pl.main_doubles = per_block * (size_t)pl.blocks;
+    // the nr1 + nr2 streamed cells: their rows, norms, ids; a row-major copy of vect if it came column-major
+    pl.extra_doubles = N * asv_tile_gs(g) + N + (N + 1) / 2 + 2 + (vect_row_major ? 0 : (size_t)n2 * g) + 16;
+    return pl;
 }
 
 void adjust_shift_variance_device(hipStream_t stream, const double* data1, int g, int n1, const double* data2, int n2,
                                   const double* vect, double sigma2, const int32_t* restrict1, int nr1,
-                                  const int32_t* restrict2, int nr2, double* out, double* ws_pairs, int vect_row_major) {
+                                  const int32_t* restrict2, int nr2, double* out, double* ws_pairs, const AsvPlan& pl,
+                                  int vect_row_major, int cell_begin, int cell_end) {
     // vect is an R matrix [n2 x g] (column-major) at the .Call boundary, row-major [n2][g] inside the engine
     const int64_t vs_cell = vect_row_major ? g : 1, vs_x = vect_row_major ? 1 : n2;
-    if (n2 <= 0) return;
-    int blocks = 1, npad = 1, exact = 1;
-    const size_t main_doubles = adjust_shift_variance_scratch(n2, nr1, nr2, &blocks, &npad, &exact);
-    static const int bisect = std::getenv("BMX_ASV_BISECT") != nullptr;
-    if (exact) {
+    (void)n1;
+    if (cell_end < 0) cell_end = n2;
+    if (n2 <= 0 || cell_end <= cell_begin) return;
+    const int blocks = pl.blocks;
+    if (pl.exact) {
         hipLaunchKernelGGL(asv_exact_kernel, dim3(blocks), dim3(T), (size_t)2 * g * sizeof(double), stream, data1, g, data2,
-                           n2, vect, vs_cell, vs_x, sigma2, restrict1, nr1, restrict2, nr2, npad, out, ws_pairs);
-    } else if (bisect) {
-        hipLaunchKernelGGL(asv_kernel, dim3(blocks), dim3(T), (size_t)2 * g * sizeof(double), stream, data1, g, n1, data2,
-                           n2, vect, vs_cell, vs_x, sigma2, restrict1, nr1, restrict2, nr2, out, ws_pairs);
+                           n2, vect, vs_cell, vs_x, sigma2, restrict1, nr1, restrict2, nr2, pl.npad, out, ws_pairs, cell_begin,
+                           cell_end);
     } else {
         if (g > 256) throw Error(BMX_ERR_ARG, "adjust_shift_variance: more than 256 dimensions at this size are not supported");
-        double* extra = ws_pairs + main_doubles;
+        double* extra = ws_pairs + pl.main_doubles;
         const int64_t N = (int64_t)asv_tile_npad((size_t)nr1 + (size_t)nr2);
         const int gs = asv_tile_gs(g);
         double* S = extra;                      // [N][gs] the streamed cells, zero rows up to whole pairs of steps
@@ -1198,7 +1042,7 @@ void adjust_shift_variance_device(hipStream_t stream, const double* data1, int g
     case NB8:                                                                                                                \
         ensure_dynamic_lds(reinterpret_cast<const void*>(&asv_tile_kernel<NB8>), lds);                                       \
         hipLaunchKernelGGL(asv_tile_kernel<NB8>, dim3(blocks), dim3(T), lds, stream, g, data2, n2, vrm, sigma2, nr1, nr2,     \
-                           (const double*)S, (const double*)snrm, (const int32_t*)sid, out, ws_pairs);                       \
+                           (const double*)S, (const double*)snrm, (const int32_t*)sid, out, ws_pairs, cell_begin, cell_end);  \
         break
         switch (asv_tile_nb8(g)) {
             BMX_ASV_TILE(1);

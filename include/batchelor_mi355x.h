@@ -58,11 +58,10 @@ int32_t bmx_adjust_shift_variance(const double* data1, int32_t g1, int32_t n1, c
                                   const int32_t* restrict1, int32_t nr1, const int32_t* restrict2, int32_t nr2,
                                   double* out);
 
-/* Which form of adjust_shift_variance a call of these sizes takes: 1 = the reference's order of operations literally
- * (bit-equal to the CPU restatement, every cell; up to 4e7 (cell, restricted cell) pairs), 2 = 16-cell tiles on the FP64
- * matrix cores with a histogram quantile (beyond that: a cell whose quantile walk is decided on the last bits may land on
- * the neighbouring quantile; >= 99.5 % of cells agree at sigma = 1, >= 95 % at 0.1), 3 = round 2's bisection form
- * (BMX_ASV_BISECT=1).  The engine's var_adj merges go through the same switch. */
+/* Which form of adjust_shift_variance a call of these sizes takes (a pure function of the sizes): 1 = the reference's order
+ * of operations literally (bit-equal to the CPU restatement, every cell; up to 4e7 (cell, restricted cell) pairs), 2 =
+ * 16-cell tiles on the FP64 matrix cores with a histogram quantile (beyond that: a cell whose quantile walk is decided on
+ * the last bits may land on the neighbouring quantile).  The engine's var_adj merges go through the same switch. */
 int32_t bmx_adjust_shift_variance_form(int32_t n2, int32_t nr1, int32_t nr2);
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -83,6 +82,16 @@ int32_t bmx_find_mutual_nn(const double* data1, int32_t n1, const double* data2,
 int64_t bmx_last_knn_exact_fallbacks(void);
 /* Testing hook: non-zero routes every kNN query through the exact FP64 re-scan. */
 void bmx_set_force_exact_knn(int32_t on);
+/* Testing hooks, process-wide, set by an explicit call only: NOTHING in the environment of the host process changes what
+ * the library computes, which tier of the search or which form of adjust_shift_variance runs (the library reads two
+ * environment variables: BMX_DEBUG=1 prints the shape decisions of every search to stderr, BMX_HOST_THREADS=n sizes the
+ * pool of host threads behind the pinned staging ring).  Knobs: "knn_tier" (1 / 2: that candidate tier only, 3: the exact
+ * FP64 scan only), "sample" (rows of a candidate pass's threshold sample, -1 = automatic), "split_c" / "force_c"
+ * (reference ranges of the tail / of every query block), "no_margin" (fp16 tier: lists cut at their KS-th best only),
+ * "asv_fast" (the tiled form of adjust_shift_variance at any size), "exchange_always" (a single rank goes through its
+ * exchange transport too), "refine_full" (the exact re-rank ranks every search's candidates in full), "reset" (all back
+ * to their defaults).  Unknown name: BMX_ERR_ARG. */
+int32_t bmx_dev_set(const char* name, int32_t value);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * The merge engine: replaces .fast_mnn / .fast_mnn_core (R/fastMNN.R:398-562) and everything they call
@@ -94,9 +103,11 @@ typedef struct bmx_engine bmx_engine_t;
 
 typedef struct {
     int32_t struct_size;   /* sizeof(bmx_params_t) as the CALLER's header has it: the library reads that many bytes and
-                              gives the fields a later header added their defaults (var_adj = 0, sigma = 0.1), so a
-                              caller built against an older header keeps working; smaller than the fields up to
-                              auto_merge, or larger than the library's own struct with non-zero bytes beyond: BMX_ERR_ARG */
+                              gives the fields a later header appends their defaults (var_adj = 0, sigma = 0.1), so a
+                              caller built against any header that HAS this field keeps working (the layout before it
+                              -- round 2's, without struct_size -- is not readable and is refused for k < 36; fields
+                              are only ever appended from here on); smaller than the fields up to auto_merge, or
+                              larger than the library's own struct with non-zero bytes beyond: BMX_ERR_ARG */
     int32_t k;             /* k = 20 */
     double prop_k;         /* NaN = NULL (R/MNN_tree.R:140-146) */
     double ndist;          /* ndist = 3 */
@@ -128,8 +139,9 @@ int32_t bmx_rccl_unique_id(void* id_out, int32_t bytes);
 int32_t bmx_engine_init_rccl(bmx_engine_t* e, int32_t rank, int32_t world, const void* unique_id, int32_t bytes);
 /* All-gathers issued and bytes received by this rank since the last bmx_engine_run started. */
 int32_t bmx_engine_exchange_stats(bmx_engine_t* e, int64_t* calls, int64_t* bytes);
-/* Copies the batches to HBM.  data[b]: nrows[b] x d column-major; restrict_idx[b]: 1-based, any order, no cell twice,
- * n_restrict[b] entries, or NULL / n_restrict[b] < 0 for "all cells" (R/checkInputs.R:96-120 normalises them). */
+/* Copies the batches to HBM.  data[b]: nrows[b] x d column-major; restrict_idx[b]: 1-based, any order, a cell may be named
+ * more than once (any R subsetting vector, R/checkInputs.R:96-120: the search then sees it as that many points), 
+ * n_restrict[b] entries, or NULL / n_restrict[b] < 0 for "all cells". */
 int32_t bmx_engine_upload(bmx_engine_t* e, int32_t nbatches, int32_t d, const double* const* data,
                           const int32_t* nrows, const int32_t* const* restrict_idx, const int32_t* n_restrict);
 /* Runs all merges on the resident inputs (asynchronous launches; returns after the final stream synchronisation).
@@ -155,14 +167,13 @@ int32_t bmx_engine_merge_stats(bmx_engine_t* e, int32_t merge, int64_t* out6);
  * the work queued (about 1e4 times its expected duration).  When a deadline passes the call returns BMX_ERR_HIP with a
  * message starting "watchdog:", and the engine is dead: every later call on it fails at once and bmx_engine_destroy
  * abandons its stream and device memory instead of waiting for them -- only a fresh process gets the GPU back.
- * Default base 60 000 ms (environment BMX_WATCHDOG_MS overrides); base_ms <= 0 switches the watchdog off (plain
- * hipStreamSynchronize). */
+ * Default base 60 000 ms; base_ms <= 0 switches the watchdog off (plain hipStreamSynchronize). */
 int32_t bmx_engine_set_watchdog(bmx_engine_t* e, double base_ms);
 /* Testing hook of the watchdog: queues a kernel that keeps the engine's stream busy for `ms` milliseconds and then ends
  * by itself (the GPU stays healthy). */
 int32_t bmx_engine_debug_stall(bmx_engine_t* e, int32_t ms);
-/* With profiling on, every launch of the dominant kernel (knn_topk_mfma) is bracketed by HIP events on the engine's
- * stream; after a run: total milliseconds, number of launches, and queries that needed the exact re-scan. */
+/* With profiling on, every launch of a candidate-pass kernel (knn_topk_f16 / knn_topk_bf16, bmx_engine_knn_kernel names
+ * the last one) is bracketed by HIP events on the engine's stream; after a run: total milliseconds, number of launches, and queries that needed the exact re-scan. */
 int32_t bmx_engine_set_profiling(bmx_engine_t* e, int32_t on);
 int32_t bmx_engine_profile(bmx_engine_t* e, double* topk_ms, int64_t* topk_launches, int64_t* exact_fallbacks);
 /* Diagnostics for full-size parity checks: the next runs keep a device copy of the two matrices that merge `merge`
@@ -180,8 +191,8 @@ int32_t bmx_engine_profile_detail(bmx_engine_t* e, double* out10);
  * included): lets a benchmark check that a stored counter measurement belongs to the kernel it has just timed. */
 int32_t bmx_engine_knn_kernel(bmx_engine_t* e, char* buf, int32_t n);
 /* Candidate-pass kernel used by the engine's last MFMA-path search: 2 = knn_topk_bf16 (split-bf16 MFMA, LDS ring),
- * 3 = knn_topk_f16 (single fp16 product, LDS ring), -1 = none yet.  The environment variable BMX_KNN_TIER restricts the
- * search to one tier for A/B runs. */
+ * 3 = knn_topk_f16 (single fp16 product, LDS ring), -1 = none yet (bmx_dev_set "knn_tier" restricts the search to one
+ * tier for A/B runs). */
 int32_t bmx_engine_knn_variant(bmx_engine_t* e);
 
 /* One-shot convenience (what the R shim calls): create + upload + run + download + pairs stay queryable on *out_engine

@@ -7,7 +7,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests.conftest import synth_batches  # noqa: E402
-from batchelor_amd import neighbors as nb  # noqa: E402
+from batchelor_amd import _lib, neighbors as nb  # noqa: E402
 from oracle import fastmnn_oracle as oracle  # noqa: E402
 
 cases, seed = int(sys.argv[1]), int(sys.argv[2])
@@ -20,11 +20,8 @@ for case in range(cases):
     k = int(min(rng.choice([1, 5, 20, 21, 36]), nx))
     force_c = str(rng.choice(["", "1", "2", "3", "5", "7"]))
     sample = str(rng.choice(["", "", "0", "1024", "4096"]))
-    for name, val in (("BMX_FORCE_C", force_c), ("BMX_SAMPLE", sample)):
-        if val:
-            os.environ[name] = val
-        else:
-            os.environ.pop(name, None)
+    _lib.dev_set("force_c", int(force_c) if force_c else 0)  # testing hooks of the library (bmx_dev_set)
+    _lib.dev_set("sample", int(sample) if sample else -1)
     print("case", case, nx, nq, d, k, repr(force_c), repr(sample), flush=True)
     X, Q = synth_batches(1000 + seed * 1000 + case, [nx, nq], d)
     idx, dist = nb.query_knn(X, Q, k)

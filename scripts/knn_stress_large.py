@@ -8,7 +8,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests.conftest import synth_batches  # noqa: E402
-from batchelor_amd import neighbors as nb  # noqa: E402
+from batchelor_amd import _lib, neighbors as nb  # noqa: E402
 from oracle import fastmnn_oracle as oracle  # noqa: E402
 
 cases, seed = int(sys.argv[1]), int(sys.argv[2])
@@ -20,10 +20,7 @@ for case in range(cases):
     d = int(rng.choice([10, 30, 50, 64, 100]))
     k = int(rng.choice([5, 20, 30]))
     split = str(rng.choice(["", "", "3", "7"]))
-    if split:
-        os.environ["BMX_SPLIT_C"] = split
-    else:
-        os.environ.pop("BMX_SPLIT_C", None)
+    _lib.dev_set("split_c", int(split) if split else 0)  # testing hook of the library (bmx_dev_set)
     print("case", case, nx, nq, d, k, repr(split), flush=True)
     X, Q = synth_batches(5000 + seed * 100 + case, [nx, nq], d)
     idx, dist = nb.query_knn(X, Q, k)

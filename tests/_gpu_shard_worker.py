@@ -11,6 +11,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     rank, world, port, outdir = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    var_adj = len(sys.argv) > 5 and sys.argv[5] == "var_adj"
     import torch
     import torch.distributed as dist
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
@@ -23,7 +24,7 @@ def main():
     ex = TorchExchange(0)
     eng.set_shard(rank, world, ex)
     eng.upload(B)
-    eng.run()
+    eng.run(var_adj=var_adj, sigma=1.0)
     out = eng.download()
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), corrected=out.corrected,
              pl0=out.merge_info.pairs[0][0], pr0=out.merge_info.pairs[0][1],

@@ -37,6 +37,16 @@ def pytest_collection_modifyitems(config, items):
                 item.add_marker(skip)
 
 
+@pytest.fixture
+def dev():
+    """The library's testing hooks (bmx_dev_set), restored to their defaults when the test is through."""
+    from batchelor_amd import _lib
+    try:
+        yield _lib.dev_set
+    finally:
+        _lib.dev_set("reset", 0)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import fastmnn_oracle

@@ -3,7 +3,7 @@ merge 1..8) -- the shape whose merges have a growing left side (up to 700k refer
 vectors, a threshold sample pass and split reference ranges.
 
 * reduced size (8 x 6000 x 50): the whole result against the CPU oracle, pairs bit-exact;
-* a shape that takes the sample pass (reference >= 32 768 rows) and, with BMX_FORCE_C, split reference ranges with
+* a shape that takes the sample pass (reference >= 32 768 rows) and, with the testing hook "force_c", split reference ranges with
   shared thresholds, against the oracle;
 * FULL size (8 x 100 000): properties that do not need the oracle to repeat the job.  For three merges the engine
   keeps the two matrices it hands to findMutualNN (bmx_engine_set_snapshot); for a random sample of right cells the
@@ -38,20 +38,13 @@ def test_config3_reduced_eight_batches_vs_oracle(oracle, bx):
 
 
 @pytest.mark.parametrize("force_c", [None, "3"])
-def test_sample_pass_and_split_ranges_vs_oracle(oracle, bx, force_c):
-    # left = 40 000 cells: the candidate pass runs its threshold sample first; BMX_FORCE_C splits every query block
-    # into three reference ranges that share their thresholds through global memory
+def test_sample_pass_and_split_ranges_vs_oracle(oracle, bx, dev, force_c):
+    # left = 40 000 cells: the candidate pass runs its threshold sample first; the testing hook "force_c" splits every
+    # query block into three reference ranges that share their thresholds through global memory
     B = synth_batches(3, [40000, 3000, 2500], 50)
-    old = os.environ.get("BMX_FORCE_C")
-    try:
-        if force_c is not None:
-            os.environ["BMX_FORCE_C"] = force_c
-        out = bx.reducedMNN(*B)
-    finally:
-        if old is None:
-            os.environ.pop("BMX_FORCE_C", None)
-        else:
-            os.environ["BMX_FORCE_C"] = old
+    if force_c is not None:
+        dev("force_c", force_c)
+    out = bx.reducedMNN(*B)
     ref = oracle.reduced_mnn(*B)
     assert_same_result(out, ref)
 

@@ -12,8 +12,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_n_rank_engine_equals_single_rank(tmp_path, world):
+@pytest.mark.parametrize("world,var_adj", [(2, False), (4, False), (2, True), (4, True)])
+def test_n_rank_engine_equals_single_rank(tmp_path, world, var_adj):
     import batchelor_amd as bx
     from tests.conftest import synth_batches
     s = socket.socket()
@@ -22,11 +22,14 @@ def test_n_rank_engine_equals_single_rank(tmp_path, world):
     s.close()
     env = dict(os.environ, PYTHONPATH=ROOT)
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_gpu_shard_worker.py"), str(r), str(world),
-                               str(port), str(tmp_path)], env=env) for r in range(world)]
+                               str(port), str(tmp_path)] + (["var_adj"] if var_adj else []), env=env)
+             for r in range(world)]
     for p in procs:
         assert p.wait(timeout=900) == 0
     B = synth_batches(13, [3001, 2500, 1777], 50)
-    ref = bx.reducedMNN(*B)
+    # var_adj: every right cell's scaling (adjust_shift_variance, independent per cell) is computed by the rank that owns
+    # the cell and all-gathered -- one more exchange per merge
+    ref = bx.reducedMNN(*B, var_adj=var_adj, sigma=1.0)
     for r in range(world):
         got = np.load(tmp_path / f"rank{r}.npz")
         assert np.array_equal(got["corrected"], ref.corrected)
@@ -34,7 +37,8 @@ def test_n_rank_engine_equals_single_rank(tmp_path, world):
             assert np.array_equal(got[f"pl{m}"], ref.merge_info.pairs[m][0])
             assert np.array_equal(got[f"pr{m}"], ref.merge_info.pairs[m][1])
         assert np.array_equal(got["lost_var"], ref.merge_info.lost_var)
-        assert int(got["calls"]) == 2 * (3 + 2)   # per merge: index + distance + index gathers, tricube index + distance
+        # per merge: index + distance + index gathers, tricube index + distance (+ the scalings with var_adj)
+        assert int(got["calls"]) == 2 * (3 + 2 + (1 if var_adj else 0))
 
 
 def test_nccl_exchange_aliases_raw_device_pointer():
@@ -71,7 +75,8 @@ print("nccl-ok")
 
 def test_engine_owned_rccl_communicator_world_size_one():
     """The production exchange: RCCL called from inside the engine, in place on its stream.  One GPU on the test box, so
-    the communicator has one rank; BMX_EXCHANGE_ALWAYS makes that rank go through ncclAllGather for every list anyway.
+    the communicator has one rank; the testing hook "exchange_always" makes that rank go through ncclAllGather for every
+    list anyway.
     The result must be the plain engine's, bit for bit, and the gathers must have happened."""
     code = r'''
 import os, sys
@@ -80,10 +85,12 @@ import numpy as np, torch, torch.distributed as dist
 torch.cuda.set_device(0)
 dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["BMX_PORT"], rank=0, world_size=1)
 import batchelor_amd as bx
+from batchelor_amd import _lib
 from batchelor_amd.dist import init_engine_rccl
 from tests.conftest import synth_batches
 B = synth_batches(13, [3001, 2500, 1777], 50)
 ref = bx.reducedMNN(*B)
+_lib.dev_set("exchange_always", 1)
 eng = bx.MnnEngine(0)
 assert init_engine_rccl(eng) == (0, 1)
 eng.upload(B)
@@ -102,6 +109,6 @@ print("rccl-engine-ok")
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, BMX_ROOT=ROOT, BMX_PORT=str(port), BMX_EXCHANGE_ALWAYS="1", PYTHONPATH=ROOT)
+    env = dict(os.environ, BMX_ROOT=ROOT, BMX_PORT=str(port), PYTHONPATH=ROOT)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "rccl-engine-ok" in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])

@@ -92,14 +92,14 @@ def test_query_knn_clusters_the_first_tier_certifies(oracle, nb):
 
 
 @pytest.mark.parametrize("sample,force_c", [("0", None), ("0", "3"), ("1024", "2")])
-def test_query_knn_spill_queue_under_pressure(oracle, nb, monkeypatch, sample, force_c):
+def test_query_knn_spill_queue_under_pressure(oracle, nb, dev, sample, force_c):
     # the candidate kernel's consumers hand every survivor to service waves through a 64-record queue.  Without a
     # sampled threshold ("0") a 20 000-row sweep starts with every value a survivor: the queue wraps many times, the
     # consumers wait for room, and lists are compacted while more is appended; with ranges, thresholds are shared
     # through global words as well.  Must still be the oracle's answer, bit for bit.
-    monkeypatch.setenv("BMX_SAMPLE", sample)
+    dev("sample", sample)
     if force_c:
-        monkeypatch.setenv("BMX_FORCE_C", force_c)
+        dev("force_c", force_c)
     X, Q = synth_batches(9, [20000, 2500], 20)
     idx, dist = nb.query_knn(X, Q, 20)
     oi, od = oracle.query_knn(X, Q, 20)
@@ -107,7 +107,7 @@ def test_query_knn_spill_queue_under_pressure(oracle, nb, monkeypatch, sample, f
     assert nb.last_knn_exact_fallbacks() <= 25
 
 
-def test_query_knn_random_shapes(oracle, nb, monkeypatch):
+def test_query_knn_random_shapes(oracle, nb, dev):
     # seeded draw of shapes, range counts and sample sizes around the candidate kernel's corner cases: rings shorter
     # than their slot count, one-slot ranges, references just above / below the sampling limits, single queries,
     # k at both list sizes, every fragment-count class
@@ -119,11 +119,8 @@ def test_query_knn_random_shapes(oracle, nb, monkeypatch):
         k = int(min(rng.choice([1, 5, 20, 21, 36]), nx))
         force_c = rng.choice(["", "1", "2", "5"])
         sample = rng.choice(["", "0", "1024"])
-        for name, val in (("BMX_FORCE_C", force_c), ("BMX_SAMPLE", sample)):
-            if val:
-                monkeypatch.setenv(name, str(val))
-            else:
-                monkeypatch.delenv(name, raising=False)
+        dev("force_c", int(force_c) if force_c else 0)
+        dev("sample", int(sample) if sample else -1)
         X, Q = synth_batches(100 + case, [nx, nq], d)
         idx, dist = nb.query_knn(X, Q, k)
         oi, od = oracle.query_knn(X, Q, k)
@@ -134,44 +131,31 @@ def test_query_knn_random_shapes(oracle, nb, monkeypatch):
 @pytest.mark.parametrize("nx,nq,d,k,tier", [(2500, 1200, 84, 20, "2"), (2500, 1200, 120, 20, "2"), (1500, 900, 31, 20, "2"),
                                             (2500, 1200, 50, 30, "2"), (3000, 2000, 100, 30, None),
                                             (3000, 2000, 70, 36, None)])
-def test_query_knn_second_tier_shapes(oracle, nb, monkeypatch, nx, nq, d, k, tier):
+def test_query_knn_second_tier_shapes(oracle, nb, dev, nx, nq, d, k, tier):
     # the split-bf16 kernel runs 8 or 4 consumer waves per workgroup (long rows and long lists: 4), and the host has to
-    # size its query blocks accordingly.  It is the first tier for k in 21..36 beyond 61 dimensions; BMX_KNN_TIER=2 sends
-    # the other shapes through it as well.
+    # size its query blocks accordingly.  It is the first tier for k in 21..36 beyond 61 dimensions; the testing hook
+    # "knn_tier" = 2 sends the other shapes through it as well.
     if tier:
-        monkeypatch.setenv("BMX_KNN_TIER", tier)
+        dev("knn_tier", tier)
     X, Q = synth_batches(11, [nx, nq], d)
     idx, dist = nb.query_knn(X, Q, k)
     oi, od = oracle.query_knn(X, Q, k)
     assert np.array_equal(idx, oi) and np.array_equal(dist, od)
 
 
-def test_rank_cut_without_the_margin_and_near_ties(oracle, nb):
+def test_rank_cut_without_the_margin_and_near_ties(oracle, nb, dev):
     """Round 3: the fp16 pass cuts its lists at (k-th best + twice the error bound); the round-2 rule (the KS-th best) is
-    what remains when that keeps too much.  Both must give the oracle's rows: (a) the rank cut alone, in a subprocess
-    with the developer switch BMX_NO_MARGIN=1; (b) the margin cut on data where thousands of references sit within the
-    margin of each query's k-th neighbour (clusters of near-duplicates: the margin keeps more than a list holds and the
-    rank cut has to take over in mid-sweep)."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = r'''
-import sys, numpy as np
-sys.path.insert(0, %r)
-from tests.conftest import synth_batches
-from batchelor_amd import neighbors as nb
-from oracle import fastmnn_oracle as orc
-for nx, nq, d, k in ((9000, 2500, 50, 20), (20000, 900, 100, 20), (6000, 700, 30, 5)):
-    X, Q = synth_batches(77, [nx, nq], d)
-    idx, dist = nb.query_knn(X, Q, k)
-    oi, od = orc.query_knn(X, Q, k)
-    assert np.array_equal(idx, oi) and np.array_equal(dist, od), (nx, nq, d, k)
-print("rank-cut-ok")
-''' % root
-    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BMX_NO_MARGIN="1"), capture_output=True,
-                         text=True, timeout=600)
-    assert out.returncode == 0 and "rank-cut-ok" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
+    what remains when that keeps too much.  Both must give the oracle's rows: (a) the rank cut alone (testing hook
+    "no_margin"); (b) the margin cut on data where thousands of references sit within the margin of each query's k-th
+    neighbour (clusters of near-duplicates: the margin keeps more than a list holds and the rank cut has to take over in
+    mid-sweep)."""
+    dev("no_margin", 1)
+    for nx, nq, d, k in ((9000, 2500, 50, 20), (20000, 900, 100, 20), (6000, 700, 30, 5)):
+        X, Q = synth_batches(77, [nx, nq], d)
+        idx, dist = nb.query_knn(X, Q, k)
+        oi, od = oracle.query_knn(X, Q, k)
+        assert np.array_equal(idx, oi) and np.array_equal(dist, od), (nx, nq, d, k)
+    dev("no_margin", 0)
     rng = np.random.default_rng(5150)
     centres = rng.standard_normal((40, 50)) * 2.0
     X = np.repeat(centres, 200, axis=0) + 1e-4 * rng.standard_normal((8000, 50))  # 200 near-duplicates per centre

@@ -151,47 +151,35 @@ def test_portable_logspace_add_is_the_oracles(oracle, nat):
         assert np.array_equal(a, b, equal_nan=True)
 
 
-def test_adjust_shift_variance_scalable_form_agrees_off_the_ill_conditioned_cells():
-    """BMX_ASV_FAST selects the form used beyond ~1e5 restricted cells (parallel sums + sort-free quantile search): it
-    may pick a different cell only where the walk decides on the last bit (a few per cent at sigma = 0.1)."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = r'''
-import sys, numpy as np
-sys.path.insert(0, %r)
-from batchelor_amd import natives as nat
-from oracle import fastmnn_oracle as orc
-rng = np.random.default_rng(100032)
-data1 = rng.standard_normal((25, 400)) * 0.1
-data2 = rng.standard_normal((25, 1000)) * 0.1
-corvect = rng.random((1000, 25))
-for sigma, bar in ((1.0, 0.999), (0.1, 0.95)):
-    out = nat.adjust_shift_variance(data1, data2, corvect, sigma, np.arange(400), np.arange(1000))
-    ref = orc.adjust_shift_variance(data1, data2, corvect, sigma, np.arange(400), np.arange(1000))
-    close = np.isclose(out, ref, rtol=1e-8, atol=1e-12)
-    assert close.mean() > bar, (sigma, close.mean())
-    again = nat.adjust_shift_variance(data1, data2, corvect, sigma, np.arange(400), np.arange(1000))
-    assert np.array_equal(out, again, equal_nan=True)          # integer histogram sums: runs are bit-identical
-# the tiled form's edges: 100 dimensions (four staged steps of 32, the last ragged), cell and stream counts that are not
-# multiples of the tile sizes, restrict vectors in arbitrary order that leave cells out, a zero gradient
-d1 = rng.standard_normal((100, 1237)) / np.sqrt(1.0 + np.arange(100) / 5.0)[:, None]
-d2 = rng.standard_normal((100, 1003)) / np.sqrt(1.0 + np.arange(100) / 5.0)[:, None] + 0.3
-cv = rng.standard_normal((1003, 100)) * 0.2
-cv[17] = 0.0
-r1 = rng.permutation(1237)[:901]
-r2 = rng.permutation(1003)[:777]
-out = nat.adjust_shift_variance(d1, d2, cv, 1.0, r1, r2)
-ref = orc.adjust_shift_variance(d1, d2, cv, 1.0, r1, r2)
-close = np.isclose(out, ref, rtol=1e-8, atol=1e-12, equal_nan=True)
-assert close.mean() > 0.995, close.mean()
-assert np.isnan(out[17]) and np.isnan(ref[17])                  # 0 / 0, as the reference (:160)
-print("asv-fast-ok")
-''' % root
-    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BMX_ASV_FAST="1"), capture_output=True,
-                         text=True, timeout=600)
-    assert out.returncode == 0 and "asv-fast-ok" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
+def test_adjust_shift_variance_scalable_form_agrees_off_the_ill_conditioned_cells(oracle, nat, dev):
+    """The testing hook "asv_fast" selects the form used beyond 4e7 (cell, restricted cell) pairs (16-cell tiles on the FP64
+    matrix cores + a sort-free histogram quantile): it may pick a different cell only where the walk decides on the last
+    bit (a few per cent at sigma = 0.1)."""
+    dev("asv_fast", 1)
+    rng = np.random.default_rng(100032)
+    data1 = rng.standard_normal((25, 400)) * 0.1
+    data2 = rng.standard_normal((25, 1000)) * 0.1
+    corvect = rng.random((1000, 25))
+    for sigma, bar in ((1.0, 0.999), (0.1, 0.95)):
+        out = nat.adjust_shift_variance(data1, data2, corvect, sigma, np.arange(400), np.arange(1000))
+        ref = oracle.adjust_shift_variance(data1, data2, corvect, sigma, np.arange(400), np.arange(1000))
+        close = np.isclose(out, ref, rtol=1e-8, atol=1e-12)
+        assert close.mean() > bar, (sigma, close.mean())
+        again = nat.adjust_shift_variance(data1, data2, corvect, sigma, np.arange(400), np.arange(1000))
+        assert np.array_equal(out, again, equal_nan=True)          # integer histogram sums: runs are bit-identical
+    # the tiled form's edges: 100 dimensions (four staged steps of 32, the last ragged), cell and stream counts that are
+    # not multiples of the tile sizes, restrict vectors in arbitrary order that leave cells out, a zero gradient
+    d1 = rng.standard_normal((100, 1237)) / np.sqrt(1.0 + np.arange(100) / 5.0)[:, None]
+    d2 = rng.standard_normal((100, 1003)) / np.sqrt(1.0 + np.arange(100) / 5.0)[:, None] + 0.3
+    cv = rng.standard_normal((1003, 100)) * 0.2
+    cv[17] = 0.0
+    r1 = rng.permutation(1237)[:901]
+    r2 = rng.permutation(1003)[:777]
+    out = nat.adjust_shift_variance(d1, d2, cv, 1.0, r1, r2)
+    ref = oracle.adjust_shift_variance(d1, d2, cv, 1.0, r1, r2)
+    close = np.isclose(out, ref, rtol=1e-8, atol=1e-12, equal_nan=True)
+    assert close.mean() > 0.995, close.mean()
+    assert np.isnan(out[17]) and np.isnan(ref[17])                  # 0 / 0, as the reference (:160)
 
 
 def test_adjust_shift_variance_form_is_reported(nat):
