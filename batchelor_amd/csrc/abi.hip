@@ -293,8 +293,8 @@ int32_t bmx_mnn_average_correction(const double* refdata, int32_t n1, const doub
         bmx::emit_pairs(s, e.idxLR_.p, mo.nsel, mo.k2, e.idxRL_.p, mo.k1, e.offL_.p, nullptr, nullptr, f.p, sc.p,
                         e.lsel_.p, e.maskL_.p);
         double* avg = e.averaged_.reserve(std::max<size_t>(1, (size_t)mo.U * d));
-        bmx::average_correction(s, L.data.p, nullptr, R.data.p, nullptr, d, e.second_u_.p, mo.U, e.partR_.p, e.cntR_.p,
-                                mo.k1, avg);
+        bmx::average_correction(s, e.red_ws_, L.data.p, nullptr, R.data.p, nullptr, d, e.second_u_.p, mo.U, e.partR_.p,
+                                e.cntR_.p, mo.k1, avg);
         double* acm = avg_cm.reserve(std::max<size_t>(1, (size_t)mo.U * d));
         bmx::transpose_rm_to_cm(s, avg, mo.U, d, acm, mo.U, 0);
         *first = download_malloc(f.p, (size_t)mo.P, s);

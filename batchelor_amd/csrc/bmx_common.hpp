@@ -260,6 +260,8 @@ struct KnnWorkspace {
     DevBuf<float> cand_v;          // [nq][C][KS] approximate values of the candidates (refine pre-ranks by them)
     DevBuf<uint32_t> tau_g;        // [nq] per-query thresholds shared across reference ranges
     DevBuf<float> margin;          // [nq] twice the fp16 pass's error bound per query, in the pass's own units
+    DevBuf<uint32_t> tau_seed;     // [nq] seeded search: each query's seed threshold in the pass's units (orderable image)
+    bool slots_clean = false;      // maxslots is zero (knn_refine leaves it so behind an fp16 search)
     DevBuf<unsigned long long> maxslots;  // 64 x 16 words: per-slot maxima of the reference norms (prep kernels)
     // per candidate tier: [count + 1] compact list of the queries it could not certify (+ counter in word 0), their
     // k-th candidate distances, and the scratch of the sub-search the next tier runs on them
@@ -268,6 +270,19 @@ struct KnnWorkspace {
     DevBuf<double> drow;           // exact-path distance rows
     DevBuf<double> xd;             // short exact lists
     DevBuf<int32_t> xcnt, xi, slow;
+    // Optimistic searches (the engine's runs): no host read-back inside a search -- see search_tiers.  opt_state (device):
+    // [0] raised when a search could not be completed that way, [1] queries that took the bounded exact sweep.
+    static constexpr int OPT_CAP = 256;
+    bool optimistic = false;
+    bool xcnt_clear = false;
+    DevBuf<int32_t> opt_state;
+    int32_t* opt_state_ptr(hipStream_t s) {
+        if (!opt_state.p) {
+            opt_state.reserve(8);
+            BMX_HIP(hipMemsetAsync(opt_state.p, 0, 8 * sizeof(int32_t), s));
+        }
+        return opt_state.p;
+    }
     int force_exact = 0;           // testing hook: route every query through the exact path
     double wd_budget_s = 0.0;      // deadline of every host wait inside a search (0 = none); the engine scales it per search
     void sync(hipStream_t s) const { guarded_stream_sync(s, wd_budget_s); }
@@ -357,6 +372,7 @@ struct Bf16Launch {
     // (k-th best value + margin) instead of at its KS-th best -- what lies beyond cannot be among the k nearest
     const float* margin = nullptr;
     int k = 0;
+    const uint32_t* tau_seed = nullptr;  // fp16 tier, sample pass of a seeded search: tau_g = min(sampled, tau_seed)
 };
 int bf16_pick_ns(int d);         // MFMA k-steps (16 bf16 each) for 3 d + 3 columns; 0 = unsupported
 int bf16_ncons(int NS, int KS);  // consumer waves (32 queries each) per workgroup

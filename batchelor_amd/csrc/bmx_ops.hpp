@@ -6,42 +6,58 @@
 namespace bmx {
 
 // ---- scan / small utilities (pairs.hip) ------------------------------------------------------------
+namespace scan {
+struct Chain;
+}
+// Chains of the single-pass scans (scan_lookback.hpp): two, so that one launch can compact two lists.  Never cleared
+// between launches: every launch brings a fresh epoch.
 struct ScanWorkspace {
-    DevBuf<int32_t> block_sums, block_offs;
+    DevBuf<unsigned long long> status;
+    DevBuf<unsigned int> ticket;
+    size_t chain_cap = 0;
+    unsigned int epoch = 0;
+    scan::Chain chain(hipStream_t stream, int which, int nblocks);
 };
-// out[i] = sum_{j<i} in[j] for i in [0, n]; out has n + 1 entries (out[n] = total).  in/out may not alias.
+// out[i] = sum_{j<i} in[j] for i in [0, n]; out has n + 1 entries (out[n] = total).  in/out may not alias.  One launch.
 void exclusive_scan_i32(hipStream_t stream, ScanWorkspace& ws, const int32_t* in, int32_t* out, int n);
 
 // ---- mutual nearest neighbours (pairs.hip) ---------------------------------------------------------
 // idxLR [nL][k2]: for each left cell the positions of its nearest right cells (rank order);
 // idxRL [nR][k1]: for each right cell the positions of its nearest left cells.
-// cntL[l]  = number of mutual partners of left cell l;   flags via the emit kernel.
 // partR [nR][k1]: mutual left partners of each right cell, ascending; cntR[r] their number.
+// maskL (nL words, k2 <= 64): bit j of word c = neighbour j of row c of idxLR is mutual (zeroed here unless the caller says
+// it is clear); without it (k2 > 64) cntL[c] = number of mutual partners of row c.
 // idxLR may cover a SUBSET of the left cells: row c belongs to left cell lsel[c] (ascending) and lpos2c[l] is the row
 // of a selected left cell l (both nullptr: one row per left cell).  nL = number of rows of idxLR.
 void mutual_counts(hipStream_t stream, const int32_t* idxLR, int nL, int k2, const int32_t* idxRL, int nR, int k1,
                    int32_t* cntL, int32_t* partR, int32_t* cntR, const int32_t* lsel = nullptr,
-                   const int32_t* lpos2c = nullptr, unsigned long long* maskL = nullptr);
-// maskL (nullable, nL words): bit j of word c = neighbour j of row c is mutual; emit_pairs then skips the lookups.
+                   const int32_t* lpos2c = nullptr, unsigned long long* maskL = nullptr, bool mask_is_clear = false);
+// ONE launch behind mutual_counts: offL [nsel + 1] = exclusive scan of the pairs per row of idxLR (popcount of maskL, or
+// cntL where k2 > 64), *totalP = their number; second_u = ascending positions r with cntR[r] > 0, offR [nR + 1] their
+// exclusive scan, *totalU their number (device words).
+void pair_scans(hipStream_t stream, ScanWorkspace& ws, const unsigned long long* maskL, const int32_t* cntL, int nsel, int k2,
+                int32_t* offL, int32_t* totalP, const int32_t* cntR, int nR, int32_t* offR, int32_t* second_u, int32_t* totalU);
 // Pairs in the reference order (src/find_mutual_nns.cpp:23-36): left ascending, then the left cell's neighbour rank.
-// offL = exclusive scan of cntL.  Ids written are lrows[l] + 1 / rrows[r] + 1 (1-based rows in the node; identity if null).
+// offL = exclusive scan of the pairs per row.  Ids written are lrows[l] + 1 / rrows[r] + 1 (1-based rows in the node;
+// identity if null).  maskL (nullable): emit_pairs then skips the lookups.
 void emit_pairs(hipStream_t stream, const int32_t* idxLR, int nL, int k2, const int32_t* idxRL, int k1,
                 const int32_t* offL, const int32_t* lrows, const int32_t* rrows, int32_t* first, int32_t* second,
                 const int32_t* lsel = nullptr, const unsigned long long* maskL = nullptr);
-// Rows (of n_rows) that occur in idx[0, n_entries): flag[r] = 0/1, off = exclusive scan of flag (n_rows + 1 entries:
-// off[r] = position of a listed row in sel, off[n_rows] = their number), sel = the listed rows, ascending.
+// Rows (of n_rows) that occur in idx[0, n_entries): they are stamped with `gen` in stamp [n_rows] (a buffer that is zero
+// when first used and never cleared: every call brings a larger gen), off = exclusive scan of "row is listed" (n_rows + 1
+// entries: off[r] = position of a listed row in sel, off[n_rows] = their number, also written to the device word
+// *total_out), sel = the listed rows, ascending.  seed_zero / mask_zero (nullable): word `position` of each is zeroed for
+// every selected row -- what seed_thresholds and mutual_counts accumulate into.  Two launches.
 void select_listed_rows(hipStream_t stream, ScanWorkspace& ws, const int32_t* idx, int64_t n_entries, int n_rows,
-                        int32_t* flag, int32_t* off, int32_t* sel);
-// seed[c] (c < nsel) = the largest squared distance (rounded up to f32) at which a right cell lists the c-th selected
-// left cell: idxRL / distRL [n_entries] = the right cells' neighbour lists with their Euclidean distances, lpos2c maps
-// a listed left cell to its row among the selected ones.  No mutual partner of that left cell lies farther.
+                        int32_t* stamp, int gen, int32_t* off, int32_t* sel, int32_t* total_out, float* seed_zero = nullptr,
+                        unsigned long long* mask_zero = nullptr);
+// seed[c] (c < nsel, zero on entry) = the largest squared distance (rounded up to f32) at which a right cell lists the c-th
+// selected left cell: idxRL / distRL [n_entries] = the right cells' neighbour lists with their Euclidean distances, lpos2c
+// maps a listed left cell to its row among the selected ones.  No mutual partner of that left cell lies farther.
 void seed_thresholds(hipStream_t stream, const int32_t* idxRL, const double* distRL, int64_t n_entries,
                      const int32_t* lpos2c, int nsel, float* seed);
 // out[i] = rows[sel[i]]
 void compose_row_list(hipStream_t stream, const int32_t* sel, int n, const int32_t* rows, int32_t* out);
-// second_u = ascending positions r with cntR[r] > 0 (offR = exclusive scan of the 0/1 flags, computed here).
-void compact_mnn_cells(hipStream_t stream, ScanWorkspace& ws, const int32_t* cntR, int nR, int32_t* flagR,
-                       int32_t* offR, int32_t* second_u);
 
 // ---- correction primitives (correct.hip) -----------------------------------------------------------
 struct ReduceWorkspace {
@@ -64,6 +80,21 @@ void col_reduce2(hipStream_t stream, ReduceWorkspace& ws, const double* X, int n
 void rows_apply_stats(hipStream_t stream, ReduceWorkspace& ws, double* X, int d, const int* starts, const int* ns,
                       int nseg, const double* mu, const double* vec_pool, const int* vec_ids, int nvec,
                       const int* stat_slots, double* means_pool, double* scal);
+// The general form: the segments may live in different matrices (the left and the right node of a merge go through one
+// launch) and bring their own column mean and variance shift.
+struct RowSeg {
+    double* X;            // the matrix the rows [start, start + n) belong to
+    int start, n;
+    const double* mu;     // nvec > 0: column mean over the restrict rows of the segment's node
+    const double* pivot;  // stats: a vector near the segment's mean (its earlier mean); nullptr: its first row
+    int slot;             // stats: where its means / total variance go
+};
+void rows_multi(hipStream_t stream, ReduceWorkspace& ws, int d, const RowSeg* segs, int nseg, const double* vec_pool,
+                const int* vec_ids, int nvec, bool stats, double* means_pool, double* scal);
+// mu0 / mu1 [d] = row-weighted means of the segment means of two nodes (segments [0, nseg0) and [nseg0, nseg0 + nseg1); at
+// most 16 in all) -- one launch
+void node_means_from_segments(hipStream_t stream, const double* means_pool, const int* ns, const int* slots, int nseg0, int nseg1,
+                              int d, double* mu0, double* mu1);
 // mu [d] = row-weighted mean of the segment means means_pool[slots[i]] (at most 16 segments)
 void node_mean_from_segments(hipStream_t stream, const double* means_pool, const int* ns, const int* slots, int nseg,
                              int d, double* mu);
@@ -73,10 +104,14 @@ void batch_magnitude(hipStream_t stream, const double* overall, const double* ms
 void sum_vector(hipStream_t stream, const double* in, int d, double scale, double* out);
 
 // .average_correction (R/fastMNN.R:567-580): for the u-th MNN-involved right cell (position second_u[u]) the mean of
-// L[lrows[l]] - R[rrows[r]] over its partners l (ascending).  averaged [U][d].
-void average_correction(hipStream_t stream, const double* L, const int32_t* lrows, const double* R,
-                        const int32_t* rrows, int d, const int32_t* second_u, int U, const int32_t* partR,
-                        const int32_t* cntR, int k1, double* averaged);
+// L[lrows[l]] - R[rrows[r]] over its partners l (ascending).  averaged [U][d].  Returns true when the fused form ran: then
+// (with_sums) overall [d] = colMeans(averaged), msq [d] = colMeans(averaged^2) and *magnitude = .get_batch_magnitude
+// (R/fastMNN.R:481,582-595; magnitude nullable) have come out of the same pass, and srows (nullable) [U] holds each cell's
+// row in its node (rrows[second_u[u]]); false: the caller does those itself.
+bool average_correction(hipStream_t stream, ReduceWorkspace& ws, const double* L, const int32_t* lrows, const double* R,
+                        const int32_t* rrows, int d, const int32_t* second_u, int U, const int32_t* partR, const int32_t* cntR,
+                        int k1, double* averaged, bool with_sums = false, double* overall = nullptr, double* msq = nullptr,
+                        double* magnitude = nullptr, int32_t* srows = nullptr);
 
 // .compute_tricube_average + add (R/utils_tricube.R:1-27, R/fastMNN.R:606-607) in place on X [n][d].
 // idx [n][k] positions into `averaged` rows, dist [n][k] ascending Euclidean distances.

@@ -107,6 +107,14 @@ struct SegDesc {
     int n[16];
     int nseg;
 };
+// per segment: the matrix its rows live in (left and right node of a merge go through ONE launch), the column mean the
+// centring of its node works with, and the shift of its one-pass variance (any vector near the segment's mean: its old
+// mean where it has statistics, else its first row -- read in place when the pass does not rewrite the rows)
+struct SegPtrs {
+    double* X[16];
+    const double* mu[16];
+    const double* pivot[16];
+};
 struct StatSlots {
     int slot[16];
 };
@@ -142,47 +150,111 @@ __global__ __launch_bounds__(256) void average_correction_kernel(
 }
 
 // The same for an even d <= 64 and k1 <= 32: half a wave per MNN-involved right cell, 16-byte pieces, the partner rows of
-// four partners in flight at a time; the sum runs over the partners in ascending order, as above.
+// four partners in flight at a time; the sum runs over the partners in ascending order, as above.  The workgroups stride
+// over the cells; with `partial` each leaves the column sums and sums of squares of what it wrote ([grid][2][d], combined
+// in block order by average_final: overall.batch and the mean squares .get_batch_magnitude wants come out of this very
+// pass), and with `srows` the row of every MNN-involved cell in its node (the reference list of the tricube search).
 __global__ __launch_bounds__(256) void average_correction_half(
     const double* __restrict__ L, const int32_t* __restrict__ lrows, const double* __restrict__ R,
     const int32_t* __restrict__ rrows, int d, const int32_t* __restrict__ second_u, int U,
-    const int32_t* __restrict__ partR, const int32_t* __restrict__ cntR, int k1, double* __restrict__ averaged) {
+    const int32_t* __restrict__ partR, const int32_t* __restrict__ cntR, int k1, double* __restrict__ averaged,
+    double* __restrict__ partial, int32_t* __restrict__ srows) {
     typedef double d2 __attribute__((ext_vector_type(2)));
+    __shared__ double red[8][2][64];
     const int lane = threadIdx.x & 63, hl = lane & 31, half = lane >> 5;
-    const int u = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + half;
-    const bool live = u < U;
-    const int r = second_u[live ? u : 0];
-    const int m = live ? cntR[r] : 0;
     const int np = d >> 1;
     const bool act = hl < np;
-    // lane j of the half holds partner j's row
-    int64_t prow = 0;
-    if (hl < m) {
-        const int l = partR[(int64_t)r * k1 + hl];
-        prow = lrows ? lrows[l] : l;
-    }
-    const d2 rc = act ? reinterpret_cast<const d2*>(R + (int64_t)(rrows ? rrows[r] : r) * d)[hl] : d2{0.0, 0.0};
-    d2 s = d2{0.0, 0.0};
-    const int mm = max(m, __shfl_xor(m, 32));  // both halves run the same trip count (shuffles stay convergent)
-    for (int p0 = 0; p0 < mm; p0 += 4) {
-        d2 x[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int64_t row = __shfl(prow, (half << 5) + ((p0 + t) & 31));
-            x[t] = (act && p0 + t < m) ? reinterpret_cast<const d2*>(L + row * d)[hl] : rc;
+    d2 cs = d2{0.0, 0.0}, cq = d2{0.0, 0.0};
+    for (int u0 = blockIdx.x * 8; u0 < U; u0 += gridDim.x * 8) {
+        const int u = u0 + (threadIdx.x >> 6) * 2 + half;
+        const bool live = u < U;
+        const int r = second_u[live ? u : 0];
+        const int m = live ? cntR[r] : 0;
+        // lane j of the half holds partner j's row
+        int64_t prow = 0;
+        if (hl < m) {
+            const int l = partR[(int64_t)r * k1 + hl];
+            prow = lrows ? lrows[l] : l;
         }
+        const int64_t rrow = rrows ? rrows[r] : r;
+        const d2 rc = act ? reinterpret_cast<const d2*>(R + rrow * d)[hl] : d2{0.0, 0.0};
+        d2 s = d2{0.0, 0.0};
+        const int mm = max(m, __shfl_xor(m, 32));  // both halves run the same trip count (shuffles stay convergent)
+        for (int p0 = 0; p0 < mm; p0 += 4) {
+            d2 x[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-            if (p0 + t < m) {
-                s[0] += x[t][0] - rc[0];
-                s[1] += x[t][1] - rc[1];
+            for (int t = 0; t < 4; ++t) {
+                const int64_t row = __shfl(prow, (half << 5) + ((p0 + t) & 31));
+                x[t] = (act && p0 + t < m) ? reinterpret_cast<const d2*>(L + row * d)[hl] : rc;
             }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (p0 + t < m) {
+                    s[0] += x[t][0] - rc[0];
+                    s[1] += x[t][1] - rc[1];
+                }
+        }
+        if (live && act) {
+            d2 o;
+            o[0] = s[0] / (double)m;
+            o[1] = s[1] / (double)m;
+            reinterpret_cast<d2*>(averaged + (int64_t)u * d)[hl] = o;
+            cs[0] += o[0];
+            cs[1] += o[1];
+            cq[0] += o[0] * o[0];
+            cq[1] += o[1] * o[1];
+        }
+        if (srows && live && hl == 0) srows[u] = (int32_t)rrow;
     }
-    if (live && act) {
-        d2 o;
-        o[0] = s[0] / (double)m;
-        o[1] = s[1] / (double)m;
-        reinterpret_cast<d2*>(averaged + (int64_t)u * d)[hl] = o;
+    if (partial) {
+        const int h8 = (threadIdx.x >> 6) * 2 + half;
+        if (act) {
+            red[h8][0][2 * hl] = cs[0];
+            red[h8][0][2 * hl + 1] = cs[1];
+            red[h8][1][2 * hl] = cq[0];
+            red[h8][1][2 * hl + 1] = cq[1];
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < 2 * d; e += 256) {
+            const int which = e / d, c = e - which * d;
+            double t = 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t += red[q][which][c];
+            partial[(int64_t)blockIdx.x * 2 * d + e] = t;
+        }
+    }
+}
+
+// overall.batch = colMeans(averaged) and colMeans(averaged^2) from average_correction_half's partials, then
+// .get_batch_magnitude (R/fastMNN.R:582-595) -- one workgroup
+__global__ __launch_bounds__(256) void average_final(const double* __restrict__ partial, int nblocks, int d, double scale,
+                                                     double* __restrict__ out_sum, double* __restrict__ out_sq,
+                                                     double* __restrict__ magnitude) {
+    __shared__ double sm[4][64];
+    __shared__ double fin[2][256];
+    const int c0 = threadIdx.x & 63, g = threadIdx.x >> 6;
+    for (int which = 0; which < 2; ++which)
+        for (int cb = 0; cb < d; cb += 64) {
+            const int c = cb + c0;
+            double s = 0.0;
+            if (c < d)
+                for (int b = g; b < nblocks; b += 4) s += partial[(int64_t)b * 2 * d + which * d + c];
+            sm[g][c0] = s;
+            __syncthreads();
+            if (g == 0 && c < d) {
+                const double v = ((sm[0][c0] + sm[1][c0]) + (sm[2][c0] + sm[3][c0])) * scale;
+                (which ? out_sq : out_sum)[c] = v;
+                fin[which][c] = v;
+            }
+            __syncthreads();
+        }
+    if (threadIdx.x == 0 && magnitude) {
+        double l2sq = 0.0, ave = 0.0;
+        for (int c = 0; c < d; ++c) {
+            ave += fin[1][c];
+            l2sq += fin[0][c] * fin[0][c];
+        }
+        *magnitude = ave == 0.0 ? 0.0 : sqrt(l2sq / ave);
     }
 }
 
@@ -302,13 +374,14 @@ struct VecIds {
 };
 
 template <bool APPLY, bool STATS>
-__global__ __launch_bounds__(256) void rows_pass(double* __restrict__ X, int d, SegDesc sd, const double* __restrict__ mu,
-                                                 const double* __restrict__ vec_pool, VecIds ids,
-                                                 const double* __restrict__ pivots, int maxnb,
-                                                 double* __restrict__ partial) {
+__global__ __launch_bounds__(256) void rows_pass(int d, SegDesc sd, SegPtrs sp, const double* __restrict__ vec_pool, VecIds ids,
+                                                 int maxnb, double* __restrict__ partial) {
     __shared__ double vhat[APPLY ? PASS_EMAX : 1][256];
     __shared__ double red[STATS ? 4 : 1][2][256];
     const int seg = blockIdx.y;
+    double* __restrict__ X = sp.X[seg];
+    const double* __restrict__ mu = sp.mu[seg];
+    const double* __restrict__ pivots = sp.pivot[seg];
     const int b0 = sd.start[seg] + blockIdx.x * PASS_ROWS;
     const int b1 = min(sd.start[seg] + sd.n[seg], b0 + PASS_ROWS);
     if (blockIdx.x * PASS_ROWS >= sd.n[seg]) return;
@@ -330,7 +403,7 @@ __global__ __launch_bounds__(256) void rows_pass(double* __restrict__ X, int d, 
     for (int i = 0; i < 4; ++i) {
         const int c = lane + 64 * i;
         m_[i] = (APPLY && c < d) ? mu[c] : 0.0;
-        pv[i] = (STATS && c < d) ? pivots[(int64_t)seg * d + c] : 0.0;
+        pv[i] = (STATS && c < d) ? pivots[c] : 0.0;
     }
     // two rows per wave and trip: their loads are in flight together
     for (int r = b0 + w; r < b1; r += 8) {
@@ -412,10 +485,8 @@ __global__ __launch_bounds__(256) void rows_pass(double* __restrict__ X, int d, 
 // instruction) or 64 -- each lane holding one 16-byte piece (two columns), four wave-loads of rows in flight per trip.
 // Partial statistics come out in the layout rows_stats_final reads.
 template <bool APPLY, bool STATS, int LPR>
-__global__ __launch_bounds__(256) void rows_pass_v2(double* __restrict__ X, int d, SegDesc sd, const double* __restrict__ mu,
-                                                    const double* __restrict__ vec_pool, VecIds ids,
-                                                    const double* __restrict__ pivots, int maxnb,
-                                                    double* __restrict__ partial) {
+__global__ __launch_bounds__(256) void rows_pass_v2(int d, SegDesc sd, SegPtrs sp, const double* __restrict__ vec_pool,
+                                                    VecIds ids, int maxnb, double* __restrict__ partial) {
     typedef double d2 __attribute__((ext_vector_type(2)));
     constexpr int RPW = 64 / LPR;   // rows per wave-load
     constexpr int UNR = 4;          // wave-loads in flight
@@ -423,6 +494,9 @@ __global__ __launch_bounds__(256) void rows_pass_v2(double* __restrict__ X, int 
     __shared__ double red[STATS ? 4 * RPW : 1][2][128];
     const int seg = blockIdx.y;
     if (blockIdx.x * PASS_ROWS >= sd.n[seg]) return;
+    double* __restrict__ X = sp.X[seg];
+    const double* __restrict__ mu = sp.mu[seg];
+    const double* __restrict__ pivots = sp.pivot[seg];
     const int b0 = sd.start[seg] + blockIdx.x * PASS_ROWS;
     const int b1 = min(sd.start[seg] + sd.n[seg], b0 + PASS_ROWS);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -443,7 +517,7 @@ __global__ __launch_bounds__(256) void rows_pass_v2(double* __restrict__ X, int 
     d2 m_ = d2{0.0, 0.0}, pv = d2{0.0, 0.0}, s1 = d2{0.0, 0.0}, s2 = d2{0.0, 0.0};
     if (act) {
         if (APPLY) m_ = reinterpret_cast<const d2*>(mu)[hl];
-        if (STATS) pv = reinterpret_cast<const d2*>(pivots + (int64_t)seg * d)[hl];
+        if (STATS) pv = reinterpret_cast<const d2*>(pivots)[hl];
     }
     for (int r0 = b0 + (w * UNR) * RPW; r0 < b1; r0 += 4 * UNR * RPW) {
         d2 x[UNR];
@@ -506,21 +580,16 @@ __global__ __launch_bounds__(256) void rows_pass_v2(double* __restrict__ X, int 
     }
 }
 
-// first row of every segment: the shift of the one-pass variance
-__global__ void gather_pivots(const double* __restrict__ X, int d, SegDesc sd, double* __restrict__ pivots) {
-    const int seg = blockIdx.x;
-    for (int c = threadIdx.x; c < d; c += blockDim.x) pivots[(int64_t)seg * d + c] = X[(int64_t)sd.start[seg] * d + c];
-}
-
 // per segment: column means and the sum over columns of the sample variance.  Four thread groups share each column's
 // partials and are combined in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void rows_stats_final(const double* __restrict__ partial, int maxnb, int d, SegDesc sd,
-                                                        const double* __restrict__ pivots, StatSlots slots,
-                                                        double* __restrict__ means_pool, double* __restrict__ scal) {
+                                                        SegPtrs sp, StatSlots slots, double* __restrict__ means_pool,
+                                                        double* __restrict__ scal) {
     __shared__ double sa[4][64], sb[4][64];
     __shared__ double sacc[64];
     const int seg = blockIdx.x;
     const int n = sd.n[seg];
+    const double* __restrict__ pivots = sp.pivot[seg];
     const int nb = (n + PASS_ROWS - 1) / PASS_ROWS;
     const int c0 = threadIdx.x & 63, g = threadIdx.x >> 6;
     double acc = 0.0;
@@ -541,7 +610,7 @@ __global__ __launch_bounds__(256) void rows_stats_final(const double* __restrict
         if (g == 0 && c < d) {
             a = (sa[0][c0] + sa[1][c0]) + (sa[2][c0] + sa[3][c0]);
             b = (sb[0][c0] + sb[1][c0]) + (sb[2][c0] + sb[3][c0]);
-            means_pool[(int64_t)slots.slot[seg] * d + c] = pivots[(int64_t)seg * d + c] + a / (double)n;
+            means_pool[(int64_t)slots.slot[seg] * d + c] = pivots[c] + a / (double)n;
             acc += (b - a * a / (double)n) / (double)(n - 1);  // one cell: 0 / 0 = NaN, as colVars gives NA
         }
         __syncthreads();
@@ -555,17 +624,20 @@ __global__ __launch_bounds__(256) void rows_stats_final(const double* __restrict
     }
 }
 
-// mu = sum_s n_s mean_s / sum_s n_s over the segments of a node (their means are current)
-__global__ void combine_means(const double* __restrict__ means_pool, SegDesc sd, StatSlots slots, int d,
-                              double* __restrict__ mu) {
+// mu = sum_s n_s mean_s / sum_s n_s over the segments of a node (their means are current).  blockIdx.y picks the node:
+// segments [0, split) -> mu0, [split, nseg) -> mu1 (both nodes of a merge in one launch)
+__global__ void combine_means(const double* __restrict__ means_pool, SegDesc sd, StatSlots slots, int d, int split,
+                              double* __restrict__ mu0, double* __restrict__ mu1) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= d) return;
+    const int i0 = blockIdx.y == 0 ? 0 : split, i1 = blockIdx.y == 0 ? split : sd.nseg;
+    if (i1 <= i0) return;
     double s = 0.0, n = 0.0;
-    for (int i = 0; i < sd.nseg; ++i) {
+    for (int i = i0; i < i1; ++i) {
         s += (double)sd.n[i] * means_pool[(int64_t)slots.slot[i] * d + c];
         n += (double)sd.n[i];
     }
-    mu[c] = s / n;
+    (blockIdx.y == 0 ? mu0 : mu1)[c] = s / n;
 }
 
 // .get_batch_magnitude (R/fastMNN.R:582-595): sqrt(sum(ave^2) / sum(colMeans(correction^2))), 0 if the latter is 0
@@ -625,17 +697,28 @@ void sum_vector(hipStream_t stream, const double* in, int d, double scale, doubl
     BMX_LAUNCH_CHECK();
 }
 
-void average_correction(hipStream_t stream, const double* L, const int32_t* lrows, const double* R,
-                        const int32_t* rrows, int d, const int32_t* second_u, int U, const int32_t* partR,
-                        const int32_t* cntR, int k1, double* averaged) {
-    if (U <= 0) return;
-    if ((d & 1) == 0 && d <= 64 && k1 <= 32)
-        hipLaunchKernelGGL(average_correction_half, dim3(cdiv(U, 8)), dim3(256), 0, stream, L, lrows, R, rrows, d, second_u, U,
-                           partR, cntR, k1, averaged);
-    else
-        hipLaunchKernelGGL(average_correction_kernel, dim3(cdiv(U, 4)), dim3(256), 0, stream, L, lrows, R, rrows, d,
-                           second_u, U, partR, cntR, k1, averaged);
+bool average_correction(hipStream_t stream, ReduceWorkspace& ws, const double* L, const int32_t* lrows, const double* R,
+                        const int32_t* rrows, int d, const int32_t* second_u, int U, const int32_t* partR, const int32_t* cntR,
+                        int k1, double* averaged, bool with_sums, double* overall, double* msq, double* magnitude,
+                        int32_t* srows) {
+    if (U <= 0) return false;
+    if ((d & 1) == 0 && d <= 64 && k1 <= 32) {
+        const int grid = std::min(cdiv(U, 8), 1024);
+        double* partial = with_sums ? ws.partial.reserve((size_t)grid * 2 * d) : nullptr;
+        hipLaunchKernelGGL(average_correction_half, dim3(grid), dim3(256), 0, stream, L, lrows, R, rrows, d, second_u, U, partR,
+                           cntR, k1, averaged, partial, srows);
+        BMX_LAUNCH_CHECK();
+        if (with_sums) {
+            hipLaunchKernelGGL(average_final, dim3(1), dim3(256), 0, stream, (const double*)partial, grid, d, 1.0 / (double)U,
+                               overall, msq, magnitude);
+            BMX_LAUNCH_CHECK();
+        }
+        return true;
+    }
+    hipLaunchKernelGGL(average_correction_kernel, dim3(cdiv(U, 4)), dim3(256), 0, stream, L, lrows, R, rrows, d, second_u, U,
+                       partR, cntR, k1, averaged);
     BMX_LAUNCH_CHECK();
+    return false;  // (the caller takes the column sums / the row list in passes of their own)
 }
 
 void tricube_apply(hipStream_t stream, double* X, int n, int d, const double* averaged, const int32_t* idx,
@@ -690,36 +773,45 @@ void transpose_rm_to_cm(hipStream_t stream, const double* rm, int n, int d, doub
 
 
 // ---- fused row passes (host side) -------------------------------------------------------------------
-namespace {
-void fill_desc(SegDesc& sd, StatSlots* sl, const int* starts, const int* ns, const int* slots, int s0, int cnt, int* maxn) {
-    sd.nseg = cnt;
-    *maxn = 1;
-    for (int i = 0; i < cnt; ++i) {
-        sd.start[i] = starts[s0 + i];
-        sd.n[i] = ns[s0 + i];
-        if (sl) sl->slot[i] = slots[s0 + i];
-        *maxn = std::max(*maxn, ns[s0 + i]);
-    }
-}
-}  // namespace
-
-void rows_apply_stats(hipStream_t stream, ReduceWorkspace& ws, double* X, int d, const int* starts, const int* ns,
-                      int nseg, const double* mu, const double* vec_pool, const int* vec_ids, int nvec,
-                      const int* stat_slots, double* means_pool, double* scal) {
+void rows_multi(hipStream_t stream, ReduceWorkspace& ws, int d, const RowSeg* segs, int nseg, const double* vec_pool,
+                const int* vec_ids, int nvec, bool stats, double* means_pool, double* scal) {
     if (d > 256) throw Error(BMX_ERR_ARG, "more than 256 dimensions are not supported");
-    const bool stats = stat_slots != nullptr;
     if (nvec == 0 && !stats) return;
     for (int s0 = 0; s0 < nseg; s0 += 16) {
         SegDesc sd;
         StatSlots sl;
+        SegPtrs sp;
+        sd.nseg = std::min(16, nseg - s0);
         int maxn = 1;
-        fill_desc(sd, stats ? &sl : nullptr, starts, ns, stat_slots, s0, std::min(16, nseg - s0), &maxn);
+        // a segment without a pivot takes its first row: read in place by a pass that leaves the rows alone, copied out
+        // first (d doubles) by one that rewrites them
+        double* pivcopy = nullptr;
+        for (int i = 0; i < sd.nseg; ++i) {
+            const RowSeg& g = segs[s0 + i];
+            sd.start[i] = g.start;
+            sd.n[i] = g.n;
+            sl.slot[i] = g.slot;
+            sp.X[i] = g.X;
+            sp.mu[i] = g.mu;
+            sp.pivot[i] = g.pivot;
+            maxn = std::max(maxn, g.n);
+        }
         const int maxnb = cdiv(maxn, PASS_ROWS);
         double* partial = nullptr;
-        double* pivots = nullptr;
         if (stats) {
             partial = ws.partial.reserve((size_t)sd.nseg * maxnb * 2 * d + (size_t)16 * d);
-            pivots = partial + (size_t)sd.nseg * maxnb * 2 * d;
+            pivcopy = partial + (size_t)sd.nseg * maxnb * 2 * d;
+            for (int i = 0; i < sd.nseg; ++i) {
+                if (sp.pivot[i]) continue;
+                const double* first_row = sp.X[i] + (size_t)sd.start[i] * d;
+                if (nvec > 0) {
+                    BMX_HIP(hipMemcpyAsync(pivcopy + (size_t)i * d, first_row, (size_t)d * sizeof(double), hipMemcpyDeviceToDevice,
+                                           stream));
+                    sp.pivot[i] = pivcopy + (size_t)i * d;
+                } else {
+                    sp.pivot[i] = first_row;
+                }
+            }
         }
         const dim3 grid(maxnb, sd.nseg);
         // batch vectors in launches of PASS_EMAX; the statistics ride on the last one (they describe the final rows)
@@ -730,28 +822,24 @@ void rows_apply_stats(hipStream_t stream, ReduceWorkspace& ws, double* X, int d,
             for (int e = 0; e < ids.n; ++e) ids.id[e] = vec_ids[e0 + e];
             const bool last = e0 + ids.n >= nvec;
             const int form = (d & 1) || d > 128 ? 0 : (d <= 64 ? 32 : 64);  // lanes per row of the 16-byte form
-#define BMX_ROWS_PASS(A, S, PIV, PART)                                                                                       \
-    do {                                                                                                                     \
-        if (form == 32)                                                                                                      \
-            hipLaunchKernelGGL((rows_pass_v2<A, S, 32>), grid, dim3(256), 0, stream, X, d, sd, mu, vec_pool, ids, PIV, maxnb, \
-                               PART);                                                                                        \
-        else if (form == 64)                                                                                                 \
-            hipLaunchKernelGGL((rows_pass_v2<A, S, 64>), grid, dim3(256), 0, stream, X, d, sd, mu, vec_pool, ids, PIV, maxnb, \
-                               PART);                                                                                        \
-        else                                                                                                                 \
-            hipLaunchKernelGGL((rows_pass<A, S>), grid, dim3(256), 0, stream, X, d, sd, mu, vec_pool, ids, PIV, maxnb, PART); \
+#define BMX_ROWS_PASS(A, S, PART)                                                                                              \
+    do {                                                                                                                       \
+        if (form == 32)                                                                                                        \
+            hipLaunchKernelGGL((rows_pass_v2<A, S, 32>), grid, dim3(256), 0, stream, d, sd, sp, vec_pool, ids, maxnb, PART);   \
+        else if (form == 64)                                                                                                   \
+            hipLaunchKernelGGL((rows_pass_v2<A, S, 64>), grid, dim3(256), 0, stream, d, sd, sp, vec_pool, ids, maxnb, PART);   \
+        else                                                                                                                   \
+            hipLaunchKernelGGL((rows_pass<A, S>), grid, dim3(256), 0, stream, d, sd, sp, vec_pool, ids, maxnb, PART);          \
     } while (0)
             if (stats && last) {
-                // the pivots are read from rows this very launch rewrites: take them first, after the earlier launches
-                hipLaunchKernelGGL(gather_pivots, dim3(sd.nseg), dim3(64), 0, stream, X, d, sd, pivots);
                 if (ids.n > 0)
-                    BMX_ROWS_PASS(true, true, (const double*)pivots, partial);
+                    BMX_ROWS_PASS(true, true, partial);
                 else
-                    BMX_ROWS_PASS(false, true, (const double*)pivots, partial);
-                hipLaunchKernelGGL(rows_stats_final, dim3(sd.nseg), dim3(256), 0, stream, partial, maxnb, d, sd, pivots, sl,
-                                   means_pool, scal);
+                    BMX_ROWS_PASS(false, true, partial);
+                hipLaunchKernelGGL(rows_stats_final, dim3(sd.nseg), dim3(256), 0, stream, partial, maxnb, d, sd, sp, sl, means_pool,
+                                   scal);
             } else if (ids.n > 0) {
-                BMX_ROWS_PASS(true, false, (const double*)nullptr, (double*)nullptr);
+                BMX_ROWS_PASS(true, false, (double*)nullptr);
             }
 #undef BMX_ROWS_PASS
             BMX_LAUNCH_CHECK();
@@ -760,19 +848,33 @@ void rows_apply_stats(hipStream_t stream, ReduceWorkspace& ws, double* X, int d,
     }
 }
 
-void node_mean_from_segments(hipStream_t stream, const double* means_pool, const int* ns, const int* slots, int nseg,
-                             int d, double* mu) {
-    if (nseg > 16) throw Error(BMX_ERR_ARG, "node_mean_from_segments: more than 16 segments");
+void rows_apply_stats(hipStream_t stream, ReduceWorkspace& ws, double* X, int d, const int* starts, const int* ns,
+                      int nseg, const double* mu, const double* vec_pool, const int* vec_ids, int nvec,
+                      const int* stat_slots, double* means_pool, double* scal) {
+    std::vector<RowSeg> segs((size_t)nseg);
+    for (int i = 0; i < nseg; ++i) segs[i] = RowSeg{X, starts[i], ns[i], mu, nullptr, stat_slots ? stat_slots[i] : -1};
+    rows_multi(stream, ws, d, segs.data(), nseg, vec_pool, vec_ids, nvec, stat_slots != nullptr, means_pool, scal);
+}
+
+void node_means_from_segments(hipStream_t stream, const double* means_pool, const int* ns, const int* slots, int nseg0, int nseg1,
+                              int d, double* mu0, double* mu1) {
+    if (nseg0 + nseg1 > 16) throw Error(BMX_ERR_ARG, "node_means_from_segments: more than 16 segments");
     SegDesc sd;
     StatSlots sl;
-    sd.nseg = nseg;
-    for (int i = 0; i < nseg; ++i) {
+    sd.nseg = nseg0 + nseg1;
+    for (int i = 0; i < sd.nseg; ++i) {
         sd.start[i] = 0;
         sd.n[i] = ns[i];
         sl.slot[i] = slots[i];
     }
-    hipLaunchKernelGGL(combine_means, dim3(cdiv(d, 64)), dim3(64), 0, stream, means_pool, sd, sl, d, mu);
+    hipLaunchKernelGGL(combine_means, dim3(cdiv(d, 64), nseg1 > 0 ? 2 : 1), dim3(64), 0, stream, means_pool, sd, sl, d, nseg0, mu0,
+                       mu1);
     BMX_LAUNCH_CHECK();
+}
+
+void node_mean_from_segments(hipStream_t stream, const double* means_pool, const int* ns, const int* slots, int nseg,
+                             int d, double* mu) {
+    node_means_from_segments(stream, means_pool, ns, slots, nseg, 0, d, mu, nullptr);
 }
 
 void batch_magnitude(hipStream_t stream, const double* overall, const double* msq, int d, double* out) {

@@ -4,10 +4,13 @@
 #include "rccl_dyn.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <thread>
 
 namespace bmx {
 namespace {
@@ -22,6 +25,19 @@ __global__ void gather_rows_i32(const int32_t* __restrict__ pos, int n, const in
 __global__ void stall_kernel(unsigned long long ticks) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+
+// The run's device words go to the host by a STORE into pinned (host-coherent) memory, the sequence number last: the host
+// spins on that word instead of waiting for a copy to be scheduled, signalled and polled through the runtime (measured:
+// 100-170 us of idle GPU per wait that way, 14 waits per config-3 step).
+__global__ void publish_state(const int32_t* __restrict__ st, int32_t* host, int seq) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int32_t v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = st[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) __hip_atomic_store(&host[i], v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&host[8], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __global__ void iota_offset(int32_t* __restrict__ out, int n, int off) {
@@ -292,6 +308,44 @@ void Engine::knn(const double* X, const int32_t* ref_rows, int nr, const double*
     }
 }
 
+// The run's small device words (KnnWorkspace::opt_state: [0] optimistic search failed, [1] queries through the bounded exact
+// sweep, [2] listed left cells, [3] pairs, [4] MNN-involved right cells) come back in ONE 32-byte copy per wait.
+const int32_t* Engine::read_state() {
+    int32_t* st = knn_ws_.opt_state_ptr(stream_);
+    int32_t* pin = reinterpret_cast<int32_t*>(knn_ws_.pinned_words() + 8);  // [0..7] the words, [8] the sequence number
+    if (state_seq_ == 0) pin[8] = 0;  // (a pooled block may hold an earlier engine's numbers)
+    const int seq = ++state_seq_;
+    hipLaunchKernelGGL(publish_state, dim3(1), dim3(64), 0, stream_, (const int32_t*)st, pin, seq);
+    BMX_LAUNCH_CHECK();
+    prefetch_one();  // (lazy upload: the host has nothing to do until the GPU is through -- move the next batch)
+    // the wait: spin on the sequence word (host memory: no runtime call in the loop), with the watchdog's deadline
+    const double budget = wd_base_s_ > 0.0 ? wd_base_s_ + queued_work_s_ : 0.0;
+    const auto t0 = std::chrono::steady_clock::now();
+    volatile int32_t* vp = pin;
+    unsigned spins = 0;
+    while (vp[8] != seq) {
+        if ((++spins & 0x3FFu) == 0) {
+            const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (budget > 0.0 && el > budget) {
+                mark_dead();
+                throw WatchdogTimeout("watchdog: the GPU work queued on the engine's stream did not finish in time; the engine is "
+                                      "dead (restart the process)");
+            }
+            if (el > 0.5) {  // a long wait (adjust_shift_variance at scale): stop burning the core, and look for errors
+                const hipError_t e = hipStreamQuery(stream_);
+                (void)hipGetLastError();
+                if (e != hipSuccess && e != hipErrorNotReady)
+                    throw Error(BMX_ERR_HIP, std::string("the engine's stream failed: ") + hipGetErrorString(e));
+                std::this_thread::sleep_for(std::chrono::microseconds(200));
+            }
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    queued_work_s_ = 0.0;
+    if (pin[0] != 0) throw OptimisticRetry();
+    return pin;
+}
+
 Engine::MnnOut Engine::find_mnn(const Node& left, const Node& right, int k, double prop_k, const double* mu_left,
                                 const double* mu_right) {
     // .restricted_mnn (R/MNN_tree.R:113-133): search among the restricted rows only
@@ -303,6 +357,7 @@ Engine::MnnOut Engine::find_mnn(const Node& left, const Node& right, int k, doub
     o.k1 = std::min(choose_k(k, prop_k, nL), nL);  // neighbours sought in LEFT for each right cell
     o.k2 = std::min(choose_k(k, prop_k, nR), nR);  // neighbours sought in RIGHT for each left cell
     if (o.k1 < 1 || o.k2 < 1) throw Error(BMX_ERR_ARG, "'k' must be positive");
+    int32_t* st = knn_ws_.opt_state_ptr(stream_);
     const int64_t perR = bmx_shard_rows_per_rank(nR, world_) * (int64_t)world_;
     int32_t* idxRL = idxRL_.reserve((size_t)perR * o.k1);
     // 1. every right cell's neighbours in LEFT, with their distances
@@ -310,15 +365,29 @@ Engine::MnnOut Engine::find_mnn(const Node& left, const Node& right, int k, doub
     knn(left.data.p, lrows, nL, right.data.p, rrows, nR, o.k1, idxRL, distRL, nullptr, mu_left);
     // 2. a pair needs its left cell in some right cell's list, so only those left cells are searched in RIGHT (with a
     //    growing merged reference most left cells are in nobody's list).  The result is the same set of pairs.
-    int32_t* flagL = flagL_.reserve(nL);
+    const size_t stamp_cap = stampL_.cap;
+    int32_t* stamp = stampL_.reserve(nL);
+    if (stampL_.cap != stamp_cap) {  // a fresh block: stamps start at zero, the searches' numbers at one
+        BMX_HIP(hipMemsetAsync(stamp, 0, stampL_.cap * sizeof(int32_t), stream_));
+        if (stamp_gen_ > 0x7FFFFF00) stamp_gen_ = 0;
+    }
+    if (stamp_gen_ > 0x7FFFFF00) {
+        BMX_HIP(hipMemsetAsync(stamp, 0, stampL_.cap * sizeof(int32_t), stream_));
+        stamp_gen_ = 0;
+    }
+    const int gen = ++stamp_gen_;
     int32_t* offSel = offSel_.reserve((size_t)nL + 1);
     int32_t* lsel = lsel_.reserve(nL);
-    select_listed_rows(stream_, scan_ws_, idxRL, (int64_t)nR * o.k1, nL, flagL, offSel, lsel);
-    int32_t* pin = reinterpret_cast<int32_t*>(knn_ws_.pinned_words() + 1);  // (pinned: see KnnWorkspace::pinned_words)
-    BMX_HIP(hipMemcpyAsync(pin, offSel + nL, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
-    prefetch_one();  // (lazy upload: the host has nothing to do until the search is through -- move the next batch)
-    wait();
-    const int32_t nsel = pin[0];
+    // (an upper bound sizes what the selected cells accumulate into: their seeds and pair masks are zeroed as they are selected)
+    const int64_t perLmax = bmx_shard_rows_per_rank(nL, world_) * (int64_t)world_;
+    float* seed = seedL_.reserve((size_t)std::max<int64_t>(1, perLmax));
+    unsigned long long* maskL = maskL_.reserve(std::max(1, nL));
+    select_listed_rows(stream_, scan_ws_, idxRL, (int64_t)nR * o.k1, nL, stamp, gen, offSel, lsel, st + 2, seed, maskL);
+    // A right cell r can only pair with a left cell l if it lists l, at a distance search 1 has just measured: the
+    // largest such distance bounds how far search 2 has to look for l -- a tight starting threshold for free.  Rows may
+    // come back short, padded with -1.  (The seeds only need the selected cells' positions, not their number.)
+    seed_thresholds(stream_, idxRL, distRL, (int64_t)nR * o.k1, offSel, nL, seed);
+    const int32_t nsel = read_state()[2];
     o.nsel = nsel;
     if (debug_prints()) fprintf(stderr, "[bmx] find_mnn: %d of %d left cells are in some right cell's list\n", nsel, nL);
     const int32_t* qsel = lsel;  // rows of left.data to query with
@@ -329,29 +398,18 @@ Engine::MnnOut Engine::find_mnn(const Node& left, const Node& right, int k, doub
     }
     const int64_t perL = bmx_shard_rows_per_rank(nsel, world_) * (int64_t)world_;
     int32_t* idxLR = idxLR_.reserve((size_t)std::max<int64_t>(1, perL) * o.k2);
-    // A right cell r can only pair with a left cell l if it lists l, at a distance search 1 has just measured: the
-    // largest such distance bounds how far search 2 has to look for l -- a tight starting threshold for free (no
-    // sample pass, and few candidates beyond the ones that matter).  Rows may come back short, padded with -1.
-    float* seed = seedL_.reserve((size_t)std::max<int64_t>(1, perL));
-    seed_thresholds(stream_, idxRL, distRL, (int64_t)nR * o.k1, offSel, nsel, seed);
     knn(right.data.p, rrows, nR, left.data.p, qsel, nsel, o.k2, idxLR, nullptr, seed, mu_right);
-    int32_t* cntL = cntL_.reserve(std::max(1, nsel));
+    int32_t* cntL = o.k2 > 64 ? cntL_.reserve(std::max(1, nsel)) : nullptr;
     int32_t* offL = offL_.reserve((size_t)nsel + 1);
     int32_t* partR = partR_.reserve((size_t)nR * o.k1);
     int32_t* cntR = cntR_.reserve(nR);
-    int32_t* flagR = flagR_.reserve(nR);
     int32_t* offR = offR_.reserve((size_t)nR + 1);
     int32_t* second_u = second_u_.reserve(nR);
-    mutual_counts(stream_, idxLR, nsel, o.k2, idxRL, nR, o.k1, cntL, partR, cntR, lsel, offSel,
-                  maskL_.reserve(std::max(1, nsel)));
-    exclusive_scan_i32(stream_, scan_ws_, cntL, offL, nsel);
-    compact_mnn_cells(stream_, scan_ws_, cntR, nR, flagR, offR, second_u);
-    BMX_HIP(hipMemcpyAsync(&pin[2], offL + nsel, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
-    BMX_HIP(hipMemcpyAsync(&pin[3], offR + nR, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
-    prefetch_one();
-    wait();
-    o.P = pin[2];
-    o.U = pin[3];
+    mutual_counts(stream_, idxLR, nsel, o.k2, idxRL, nR, o.k1, cntL, partR, cntR, lsel, offSel, maskL, /* mask_is_clear */ true);
+    pair_scans(stream_, scan_ws_, maskL, cntL, nsel, o.k2, offL, st + 3, cntR, nR, offR, second_u, st + 4);
+    const int32_t* pin = read_state();
+    o.P = pin[3];
+    o.U = pin[4];
     return o;
 }
 
@@ -400,25 +458,71 @@ void Engine::row_pass(Node& node, const std::vector<int>& vec_ids, bool with_sta
         node.stat_slot.assign(node.origin.size(), -1);  // the rows moved: their statistics are stale
 }
 
-void Engine::ensure_stats(Node& node) {
-    // .compute_perbatch_var (R/fastMNN.R:651-658) only for the segments whose rows changed since their last statistics
-    if (node.stat_slot.size() != node.origin.size()) node.stat_slot.assign(node.origin.size(), -1);
-    std::vector<int> starts, ns, slots, which;
-    int r0 = 0;
-    for (size_t i = 0; i < node.origin.size(); ++i) {
-        if (node.stat_slot[i] < 0) {
-            starts.push_back(r0);
-            ns.push_back(node.origin[i].n);
-            which.push_back((int)i);
+void Engine::ensure_stats(Node& node) { ensure_stats2(node, nullptr); }
+
+void Engine::ensure_stats2(Node& a, Node* b) {
+    // .compute_perbatch_var (R/fastMNN.R:651-658) only for the segments whose rows changed since their last statistics; the
+    // stale segments of both nodes of a merge go through ONE pass (+ one small launch that finishes the sums)
+    std::vector<RowSeg> segs;
+    std::vector<std::pair<Node*, int>> which;
+    for (Node* node : {&a, b}) {
+        if (!node) continue;
+        if (node->stat_slot.size() != node->origin.size()) node->stat_slot.assign(node->origin.size(), -1);
+        int r0 = 0;
+        for (size_t i = 0; i < node->origin.size(); ++i) {
+            if (node->stat_slot[i] < 0) {
+                if (n_slots_ + 1 > slot_cap_) throw Error(BMX_ERR_ARG, "internal: statistics slots exhausted");
+                segs.push_back(RowSeg{node->data.p, r0, node->origin[i].n, nullptr, nullptr, n_slots_++});
+                which.emplace_back(node, (int)i);
+            }
+            r0 += node->origin[i].n;
         }
-        r0 += node.origin[i].n;
     }
-    if (which.empty()) return;
-    if (n_slots_ + (int)which.size() > slot_cap_) throw Error(BMX_ERR_ARG, "internal: statistics slots exhausted");
-    for (size_t i = 0; i < which.size(); ++i) slots.push_back(n_slots_++);
-    rows_apply_stats(stream_, red_ws_, node.data.p, d_, starts.data(), ns.data(), (int)ns.size(), nullptr, vecs_.p, nullptr,
-                     0, slots.data(), means_pool_.p, scal_.p);
-    for (size_t i = 0; i < which.size(); ++i) node.stat_slot[which[i]] = slots[i];
+    if (segs.empty()) return;
+    rows_multi(stream_, red_ws_, d_, segs.data(), (int)segs.size(), vecs_.p, nullptr, 0, true, means_pool_.p, scal_.p);
+    for (size_t i = 0; i < which.size(); ++i) which[i].first->stat_slot[which[i].second] = segs[i].slot;
+}
+
+void Engine::node_means(const Node& left, const Node& right, double* mu_l, double* mu_r) {
+    auto fresh = [](const Node& n) {
+        bool f = !n.has_restrict && n.stat_slot.size() == n.origin.size();
+        for (int sl : n.stat_slot) f = f && sl >= 0;
+        return f;
+    };
+    if (fresh(left) && fresh(right) && left.origin.size() + right.origin.size() <= 16) {
+        std::vector<int> ns, slots;
+        for (const Node* n : {&left, &right})
+            for (size_t i = 0; i < n->origin.size(); ++i) {
+                ns.push_back(n->origin[i].n);
+                slots.push_back(n->stat_slot[i]);
+            }
+        node_means_from_segments(stream_, means_pool_.p, ns.data(), slots.data(), (int)left.origin.size(),
+                                 (int)right.origin.size(), d_, mu_l, mu_r);
+    } else {
+        node_mean(left, mu_l);
+        node_mean(right, mu_r);
+    }
+}
+
+void Engine::centre_both(Node& left, Node& right, int vid, const double* mu_l, const double* mu_r) {
+    // .center_along_batch_vector on both sides (R/fastMNN.R:496-497) with the "new" variances (:498-499) out of the same
+    // pass; every segment has current statistics here (ensure_stats2 ran, the orthogonalised side was refreshed), so its
+    // old mean is the shift of its one-pass variance
+    ensure_stats2(left, &right);
+    std::vector<RowSeg> segs;
+    for (Node* node : {&left, &right}) {
+        int r0 = 0;
+        for (size_t i = 0; i < node->origin.size(); ++i) {
+            if (n_slots_ + 1 > slot_cap_) throw Error(BMX_ERR_ARG, "internal: statistics slots exhausted");
+            segs.push_back(RowSeg{node->data.p, r0, node->origin[i].n, node == &left ? mu_l : mu_r,
+                                  means_pool_.p + (size_t)node->stat_slot[i] * d_, n_slots_++});
+            r0 += node->origin[i].n;
+        }
+    }
+    rows_multi(stream_, red_ws_, d_, segs.data(), (int)segs.size(), vecs_.p, &vid, 1, true, means_pool_.p, scal_.p);
+    size_t j = 0;
+    for (Node* node : {&left, &right})
+        for (size_t i = 0; i < node->origin.size(); ++i) node->stat_slot[i] = segs[j++].slot;
 }
 
 void Engine::orthogonalize(Node& node, const std::vector<int>& extras) {
@@ -665,6 +769,22 @@ void Engine::run(const bmx_params_t& p, const int32_t* tree, int tree_len) {
     CacheScope cache_scope(&cache_);
     BMX_HIP(hipSetDevice(device_));
     check_alive();
+    // Optimistic first: the searches leave the count of their uncertified queries on the device and sweep them without a
+    // host round trip (knn.hip: search_tiers).  A search that cannot be completed that way (hundreds of uncertified queries,
+    // lists overflowing with exact ties) raises a device flag the waits of the merge loop look at; the run then starts over
+    // from the resident inputs with host-checked searches.  Nothing of a merge is visible outside before the run returns.
+    knn_ws_.optimistic = !knn_ws_.force_exact;
+    try {
+        run_once(p, tree, tree_len);
+    } catch (const OptimisticRetry&) {
+        if (debug_prints()) fprintf(stderr, "[bmx] optimistic run gave up; repeating with host-checked searches\n");
+        knn_ws_.optimistic = false;
+        run_once(p, tree, tree_len);
+    }
+    knn_ws_.optimistic = false;
+}
+
+void Engine::run_once(const bmx_params_t& p, const int32_t* tree, int tree_len) {
     if (B_ < 2) throw Error(BMX_ERR_ARG, "at least two batches must be specified");
     if (p.k < 1) throw Error(BMX_ERR_ARG, "'k' must be positive");
     queued_work_s_ = 0.0;
@@ -683,6 +803,7 @@ void Engine::run(const bmx_params_t& p, const int32_t* tree, int tree_len) {
     scal_.reserve(slot_cap_);
     means_pool_.reserve((size_t)slot_cap_ * d_);
     BMX_HIP(hipMemsetAsync(scal_.p, 0, (size_t)slot_cap_ * sizeof(double), stream_));
+    BMX_HIP(hipMemsetAsync(knn_ws_.opt_state_ptr(stream_), 0, 8 * sizeof(int32_t), stream_));
     scal_host_.assign(slot_cap_, 0.0);
     knn_ws_.exact_total = knn_ws_.tier2_total = 0;
 
@@ -866,7 +987,8 @@ void Engine::run(const bmx_params_t& p, const int32_t* tree, int tree_len) {
     }
     BMX_HIP(hipMemcpyAsync(scal_pin_, scal_.p, scal_host_.size() * sizeof(double), hipMemcpyDeviceToHost, stream_));
     // (with var_adj the last merge's adjust_shift_variance is still running: its budget is n2 (nr1 + nr2) pair visits)
-    wait();
+    const int32_t* fin = read_state();  // (the last tricube search's flag is looked at here)
+    knn_ws_.exact_total += fin[1];
     std::memcpy(scal_host_.data(), scal_pin_, scal_host_.size() * sizeof(double));
     if (lazy_) {  // every batch is resident now: later runs need nothing from the caller
         for (int b = 0; b < B_; ++b) ensure_uploaded(b);

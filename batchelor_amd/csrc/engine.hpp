@@ -66,6 +66,7 @@ class Engine {
     void upload(int nbatches, int d, const double* const* data, const int32_t* nrows,
                 const int32_t* const* restrict_idx, const int32_t* n_restrict, bool lazy = false);
     void run(const bmx_params_t& p, const int32_t* tree, int tree_len);
+    struct OptimisticRetry {};  // thrown by the waits of an optimistic run whose device flag is up (see run)
     void download(double* corrected, int32_t* batch, int32_t* merge_left, int32_t* merge_right, double* batch_size,
                   int32_t* skipped, double* lost_var);
     void pairs(int merge, int32_t** left, int32_t** right, int64_t* npairs);
@@ -115,7 +116,9 @@ class Engine {
     ScanWorkspace scan_ws_;
     ReduceWorkspace red_ws_;
     DevBuf<int32_t> idxLR_, idxRL_, cntL_, offL_, partR_, cntR_, flagR_, offR_, second_u_, second_rows_, idxT_;
-    DevBuf<int32_t> flagL_, offSel_, lsel_, qsel_;
+    DevBuf<int32_t> stampL_, offSel_, lsel_, qsel_;
+    int state_seq_ = 0;  // sequence number of the last publish_state (read_state)
+    int stamp_gen_ = 0;  // number of the last search whose listed rows were stamped (stampL_ is never cleared)
     DevBuf<unsigned long long> maskL_;
     DevBuf<double> distT_, distRL_, averaged_, loc_, vecs_, scal_, means_pool_;
     DevBuf<float> seedL_;
@@ -125,9 +128,14 @@ class Engine {
     int n_slots_ = 0, slot_cap_ = 0;
 
   private:
+    void run_once(const bmx_params_t& p, const int32_t* tree, int tree_len);
+    const int32_t* read_state();  // one wait: the run's device words in pinned memory; throws OptimisticRetry
     void merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p, std::unique_ptr<Node>& merged);
     // statistics (column means + total variance) of the segments whose slot is stale
     void ensure_stats(Node& node);
+    void ensure_stats2(Node& a, Node* b);  // both nodes of a merge in one pass
+    void node_means(const Node& left, const Node& right, double* mu_l, double* mu_r);  // one launch where both are fresh
+    void centre_both(Node& left, Node& right, int vid, const double* mu_l, const double* mu_r);
     // one pass over the node: centre along the given batch vectors (may be none), optionally with fresh statistics
     // mu_known: the node's restrict-row column mean when the caller already has it (it is invariant under centring)
     void row_pass(Node& node, const std::vector<int>& vec_ids, bool with_stats, const double* mu_known = nullptr);

@@ -29,9 +29,10 @@
 namespace bmx {
 
 int f16_pick_ns(int d, int KS);
-void f16_prep(hipStream_t stream, const double* X, const int32_t* rows, int n, int n_pad, int d, int NS,
-              const double* mean, int is_query, uint16_t* P, double* n2, unsigned long long* maxbits,
-              unsigned long long* slots);
+void f16_prep_all(hipStream_t stream, const double* X, const int32_t* rrows, int nr, int nr_pad, const double* Q,
+                  const int32_t* qrows, int nq, int nq_pad, int d, int NS, const double* mean, uint16_t* Pr, uint16_t* Pq,
+                  double* rn2, double* qn2, unsigned long long* maxbits, unsigned long long* slots, int32_t* flagged0,
+                  float* margin, const sel::PassEps& pe, const float* seed_d2, uint32_t* tau_seed, uint32_t* tau_init);
 bool f16_launch(hipStream_t stream, KnnWorkspace& ws, int NS, int KS, const Bf16Launch& L);
 
 namespace {
@@ -135,61 +136,22 @@ __device__ __forceinline__ bool key_less(double da, int ia, double db, int ib) {
 // ---------------------------------------------------------------------------------------------------
 constexpr int REFINE_MAXM = MAX_CHUNKS * 48;
 
-__device__ __forceinline__ double pass_scale(double max_n2) {  // same arithmetic as knn_f16.hip: f16_scale
-    const double rm = sqrt(max_n2);
-    if (!(rm > 1e-150) || !(rm < 1e150)) return 1.0;
-    int e = 0;
-    (void)frexp(48.0 / rm, &e);
-    return ldexp(1.0, e - 1);
-}
-
-// error bound of a candidate pass for one query (unscaled units): f32 rounding of the centred coordinates +
-// accumulation over eps_k terms, the low-order products the pass drops (eps_split |q||r|), and fp16 inputs below the
-// normal range taken as flushed to zero (eps_den, scaled units)
-__device__ __forceinline__ double pass_eps(double qn, double rm, double s, double eps_k, double eps_qr, double eps_split,
-                                           double eps_den) {
-    const double u = 5.9604644775390625e-8;  // 2^-24
-    return 1.5 * u * (2.0 * (qn + rm) * (qn + rm) + (eps_k + 1.0) * (rm * rm + eps_qr * qn * rm)) +
-           eps_split * qn * rm + eps_den * ((2.0 * qn + rm) * s + 1.0) / (s * s);
-}
-
-// seeded search: the starting threshold of query q in the pass's own units.  A reference within seed_d2[q] of the
-// query has an approximate value below (seed - |q~|^2 + eps) s^2, so nothing the caller cares about is filtered out.
+// seeded search: tau_g = min(what is there, the seed's threshold) -- the form for passes that do not take the fused prep
 __global__ void seed_tau_kernel(const float* __restrict__ seed_d2, const double* __restrict__ qn2,
-                                const unsigned long long* __restrict__ max_rn2_bits, int nq, int nq_pad, double eps_k,
-                                double eps_qr, double eps_split, double eps_den, int scaled,
+                                const unsigned long long* __restrict__ max_rn2_bits, int nq, int nq_pad, PassEps pe,
                                 uint32_t* __restrict__ tau_g) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq_pad) return;
-    float t = -__builtin_inff();  // padded queries: nothing passes
-    if (q < nq) {
-        const double max_rn2 = __longlong_as_double((long long)*max_rn2_bits);
-        const double s = scaled ? pass_scale(max_rn2) : 1.0;
-        const double eps = pass_eps(sqrt(qn2[q]), sqrt(max_rn2), s, eps_k, eps_qr, eps_split, eps_den);
-        const double x = ((double)seed_d2[q] - qn2[q] + eps) * (s * s);
-        t = (float)(x + fabs(x) * 9.5367431640625e-7 + 1e-30);  // + 2^-20 relative: the f32 rounding cannot land below x
-    }
-    const uint32_t o = f32_orderable(t);
+    uint32_t o = f32_orderable(-__builtin_inff());  // padded queries: nothing passes
+    if (q < nq) o = pass_seed_tau((double)seed_d2[q], qn2[q], __longlong_as_double((long long)*max_rn2_bits), pe);
     tau_g[q] = q < nq ? min(tau_g[q], o) : o;  // the image is order-preserving: min of images = image of the min
 }
 
-// Twice the candidate pass's error bound per query, in the pass's own (scaled) units, rounded up: a reference whose
-// approximate value exceeds the k-th best approximate value by more than this is farther, exactly, than each of those
-// k -- the cut knn_refine applies to the candidates (below), handed to the pass itself so that it stops collecting them.
 __global__ void margin_kernel(const double* __restrict__ qn2, const unsigned long long* __restrict__ max_rn2_bits, int nq,
-                              int nq_pad, double eps_k, double eps_qr, double eps_split, double eps_den, int scaled,
-                              float* __restrict__ margin) {
+                              int nq_pad, PassEps pe, float* __restrict__ margin) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq_pad) return;
-    float m = 0.f;
-    if (q < nq) {
-        const double max_rn2 = __longlong_as_double((long long)*max_rn2_bits);
-        const double s = scaled ? pass_scale(max_rn2) : 1.0;
-        const double eps = pass_eps(sqrt(qn2[q]), sqrt(max_rn2), s, eps_k, eps_qr, eps_split, eps_den);
-        const double x = 2.0 * eps * (s * s) * 1.0000002 + 1e-30;
-        m = (float)(x * 1.000001);  // (the f32 rounding cannot land below x)
-    }
-    margin[q] = m;
+    margin[q] = q < nq ? pass_margin(qn2[q], __longlong_as_double((long long)*max_rn2_bits), pe) : 0.f;
 }
 
 template <int REFINE_NC>  // pieces of 8 doubles (one 16-byte load per lane of a quad) a row may have; 0: lane-per-row gather
@@ -202,10 +164,13 @@ __global__ __launch_bounds__(256) void knn_refine(const double* __restrict__ X, 
                                                   const unsigned long long* __restrict__ max_rn2_bits,
                                                   const float* __restrict__ seed_d2, int32_t* __restrict__ idx_out,
                                                   double* __restrict__ dist_out, int32_t* __restrict__ flagged,
-                                                  double* __restrict__ flag_bound) {
+                                                  double* __restrict__ flag_bound,
+                                                  unsigned long long* __restrict__ zero_slots) {
     __shared__ __attribute__((aligned(16))) double sd[4][REFINE_MAXM];
     __shared__ int si[4][REFINE_MAXM];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // (the prep kernels' 64 slot maxima have been folded by now: left zeroed for the next search's norm pass)
+    if (zero_slots && blockIdx.x == 0 && threadIdx.x < 64) zero_slots[(size_t)threadIdx.x * 16] = 0ull;
     const int q = blockIdx.x * 4 + w;
     if (q >= nq) return;
     const int Mall = nchunks * KS;
@@ -454,14 +419,18 @@ __global__ __launch_bounds__(256) void knn_exact_filter(const double* __restrict
                                                         const double* __restrict__ Q,
                                                         const int32_t* __restrict__ q_rows, int d,
                                                         const int32_t* __restrict__ flagged,
-                                                        const double* __restrict__ flag_bound, int nflag,
+                                                        const double* __restrict__ flag_bound, int nflag, int dev_cap,
                                                         int32_t* __restrict__ xcnt, double* __restrict__ xd,
                                                         int32_t* __restrict__ xi) {
     extern __shared__ __attribute__((aligned(16))) char smem_x[];
+    if (dev_cap > 0) {  // launched without the host knowing the count: nothing flagged (the rule) -> nothing staged
+        nflag = flagged[0];
+        if (nflag <= 0 || nflag > dev_cap) return;  // (more than the cap: knn_exact_pick raises the run's invalid flag)
+    }
     double* xs = reinterpret_cast<double*>(smem_x);  // [XF_TILE][d + 1]  (+1: breaks the bank stride)
     const int ld = d + 1;
     const int tid = threadIdx.x;
-    const int r0 = blockIdx.x * XF_TILE;
+    for (int r0 = blockIdx.x * XF_TILE; r0 < nr; r0 += gridDim.x * XF_TILE) {
     const int rows_here = min(XF_TILE, nr - r0);
     for (int e = tid; e < rows_here * d; e += 256) {
         const int rr = e / d, c = e - rr * d;
@@ -470,9 +439,8 @@ __global__ __launch_bounds__(256) void knn_exact_filter(const double* __restrict
     }
     __syncthreads();
     const int rr = tid & (XF_TILE - 1);
-    if (rr >= rows_here) return;
     const double* xr = xs + rr * ld;
-    for (int f = tid / XF_TILE; f < nflag; f += 256 / XF_TILE) {
+    for (int f = tid / XF_TILE; f < nflag && rr < rows_here; f += 256 / XF_TILE) {
         const int q = flagged[1 + f];
         const double* qv = Q + (int64_t)(q_rows ? q_rows[q] : q) * d;
         double s = 0.0;
@@ -488,22 +456,44 @@ __global__ __launch_bounds__(256) void knn_exact_filter(const double* __restrict
             }
         }
     }
+    __syncthreads();  // the tile is restaged
+    }
 }
 
-// one wave per flagged query: exact (distance, index) ranking of its short list; overflowed lists go to `slow`
-__global__ __launch_bounds__(256) void knn_exact_pick(const int32_t* __restrict__ flagged, int nflag, int k,
-                                                      const int32_t* __restrict__ xcnt, const double* __restrict__ xd,
+// one wave per flagged query: exact (distance, index) ranking of its short list; overflowed lists go to `slow`.
+// dev_cap > 0: launched without the host knowing the count (optimistic run): the count is flagged[0]; a count beyond the
+// cap or a list that overflowed cannot be handled here and raises opt[0] (the engine then repeats the run with host-checked
+// searches); opt[1] accumulates the queries that came this way; the counters of the lists are left zeroed for the next use.
+__global__ __launch_bounds__(256) void knn_exact_pick(const int32_t* __restrict__ flagged, int nflag, int dev_cap, int k,
+                                                      int seeded, int32_t* __restrict__ xcnt, const double* __restrict__ xd,
                                                       const int32_t* __restrict__ xi, int32_t* __restrict__ idx_out,
-                                                      double* __restrict__ dist_out, int32_t* __restrict__ slow) {
+                                                      double* __restrict__ dist_out, int32_t* __restrict__ slow,
+                                                      int32_t* __restrict__ opt) {
     const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
+    if (dev_cap > 0) {
+        nflag = flagged[0];
+        if (blockIdx.x == 0 && threadIdx.x == 0 && nflag > 0) {
+            atomicAdd(&opt[1], nflag);
+            if (nflag > dev_cap) opt[0] = 1;
+        }
+        if (nflag > dev_cap) return;
+    }
     if (f >= nflag) return;
     const int q = flagged[1 + f];
     const int n = xcnt[f];
-    if (n > XF_CAP || n < k) {  // n < k cannot happen (the k candidates themselves qualify); belt and braces
+    if (dev_cap > 0 && lane == 0) xcnt[f] = 0;
+    // fewer than k within the bound: only a seeded row (exactly the references within its seed distance: a short row,
+    // padded with -1, is what the caller asked for); otherwise it cannot happen (the k candidates themselves qualify)
+    const bool short_ok = seeded && n < k && n <= XF_CAP;
+    if (n > XF_CAP || (n < k && !short_ok)) {
         if (lane == 0) {
-            const int pos = atomicAdd(&slow[0], 1);
-            slow[1 + pos] = q;
+            if (dev_cap > 0) {
+                opt[0] = 1;
+            } else {
+                const int pos = atomicAdd(&slow[0], 1);
+                slow[1 + pos] = q;
+            }
         }
         return;
     }
@@ -519,6 +509,8 @@ __global__ __launch_bounds__(256) void knn_exact_pick(const int32_t* __restrict_
             if (dist_out) dist_out[(int64_t)q * k + rank] = sqrt(dm);
         }
     }
+    if (short_ok)
+        for (int m = n + lane; m < k; m += 64) idx_out[(int64_t)q * k + m] = -1;
 }
 
 __global__ void fill_u32(uint32_t* __restrict__ p, int n, uint32_t v) {
@@ -657,52 +649,64 @@ void candidate_pass(hipStream_t stream, KnnWorkspace& ws, const Tier& T, const d
         BMX_LAUNCH_CHECK();
         centre = mean;
     }
-    BMX_HIP(hipMemsetAsync(maxbits, 0, sizeof(unsigned long long), stream));
-
+    PassEps pe;
     if (T.id == 1) {
-        f16_prep(stream, X, ref_rows, nr, nr_pad, d, NS, centre, 0, reinterpret_cast<uint16_t*>(pr), rn2, maxbits, slots);
-        f16_prep(stream, Qs, qrs, nq, nq_pad, d, NS, centre, 1, reinterpret_cast<uint16_t*>(pq), qn2, maxbits, slots);
+        pe.eps_k = 16.0 * NS;                                              // f32 accumulation over the K columns
+        pe.eps_qr = 2.0;                                                   // one product block, <= 2 |q||r|
+        pe.eps_split = 2.0 * (0.0009765625 + 2.384185791015625e-07);       // both operands rounded to fp16: 2^-10 (1 + 2^-12) * 2|q||r|
+        pe.eps_den = 6.103515625e-05 * (std::sqrt((double)d) + 3.0);       // 2^-14 per flushed input, scaled units
+        pe.scaled = 1;
     } else {
-        bf16_prep(stream, X, ref_rows, nr, nr_pad, d, NS, centre, 0, reinterpret_cast<uint16_t*>(pr), rn2, maxbits, slots);
-        bf16_prep(stream, Qs, qrs, nq, nq_pad, d, NS, centre, 1, reinterpret_cast<uint16_t*>(pq), qn2, maxbits, slots);
+        pe.eps_k = 16.0 * NS;                                              // f32 accumulation over the concatenated K
+        pe.eps_qr = 6.0;                                                   // three product blocks, each <= 2 |q||r|
+        pe.eps_split = 1.5 * 3.03 * 2.0 * 1.52587890625e-05;               // dropped ql.rl, qh.r3, q3.rh: 3.03 * 2^-16 * 2|q||r|
+        pe.eps_den = 0.0;
+        pe.scaled = 0;
     }
-    double eps_k, eps_qr, eps_split, eps_den;
-    if (T.id == 1) {
-        eps_k = 16.0 * NS;                                              // f32 accumulation over the K columns
-        eps_qr = 2.0;                                                   // one product block, <= 2 |q||r|
-        eps_split = 2.0 * (0.0009765625 + 2.384185791015625e-07);       // both operands rounded to fp16: 2^-10 (1 + 2^-12) * 2|q||r|
-        eps_den = 6.103515625e-05 * (std::sqrt((double)d) + 3.0);       // 2^-14 per flushed input, scaled units
-    } else {
-        eps_k = 16.0 * NS;                                              // f32 accumulation over the concatenated K
-        eps_qr = 6.0;                                                   // three product blocks, each <= 2 |q||r|
-        eps_split = 1.5 * 3.03 * 2.0 * 1.52587890625e-05;               // dropped ql.rl, qh.r3, q3.rh: 3.03 * 2^-16 * 2|q||r|
-        eps_den = 0.0;
-    }
-    // sample pass: threshold estimation over rows [0, S); full pass: every row, starting from that threshold
-    if (S == 0) {  // no sample: +inf everywhere (0xFF800000 is the orderable image of +inf)
-        hipLaunchKernelGGL(fill_u32, dim3(cdiv(nq_pad, 256)), dim3(256), 0, stream, tau_g, nq_pad, 0xFF800000u);
-        BMX_LAUNCH_CHECK();
-    }
+    const double eps_k = pe.eps_k, eps_qr = pe.eps_qr, eps_split = pe.eps_split, eps_den = pe.eps_den;
     Bf16Launch L{reinterpret_cast<const uint16_t*>(pq), reinterpret_cast<const uint16_t*>(pr), nqb, 0, S, 1, S, 0, nchunks,
                  tau_g, 1, cand, cand_v, tau};
     const bool no_margin = dev_knobs().no_margin != 0;  // testing hook: the KS-th-best cut only
-    if (T.id == 1 && !no_margin) {
-        float* margin = ws.margin.reserve(nq_pad);
-        hipLaunchKernelGGL(margin_kernel, dim3(cdiv(nq_pad, 256)), dim3(256), 0, stream, qn2, maxbits, nq, nq_pad, eps_k,
-                           eps_qr, eps_split, eps_den, 1, margin);
-        BMX_LAUNCH_CHECK();
-        L.margin = margin;
-        L.k = k;
-    }
     auto go = [&](const Bf16Launch& l) {
         return T.id == 1 ? f16_launch(stream, ws, NS, KS, l) : bf16_launch(stream, ws, NS, KS, l);
     };
     bool ok = true;
-    if (S > 0) ok = go(L);
-    if (seed_d2) {  // tau_g = min(sampled threshold, seed threshold)
-        hipLaunchKernelGGL(seed_tau_kernel, dim3(cdiv(nq_pad, 256)), dim3(256), 0, stream, seed_d2, qn2, maxbits, nq,
-                           nq_pad, eps_k, eps_qr, eps_split, eps_den, T.id == 1 ? 1 : 0, tau_g);
-        BMX_LAUNCH_CHECK();
+    unsigned long long* zero_slots = nullptr;
+    if (T.id == 1) {
+        // fp16 tier: references (norms, then image) and queries (image, norm, margin, seed threshold) in TWO launches; the
+        // slot maxima are folded by the second one, which also resets the flagged-query counter (knn_f16.hip)
+        if (!ws.slots_clean) BMX_HIP(hipMemsetAsync(slots, 0, 64 * 16 * sizeof(unsigned long long), stream));
+        float* margin = no_margin ? nullptr : ws.margin.reserve(nq_pad);
+        uint32_t* tau_seed = seed_d2 ? ws.tau_seed.reserve(nq_pad) : nullptr;
+        // without a sample pass the thresholds start at the seed (or at +inf): prep writes them
+        f16_prep_all(stream, X, ref_rows, nr, nr_pad, Qs, qrs, nq, nq_pad, d, NS, centre, reinterpret_cast<uint16_t*>(pr),
+                     reinterpret_cast<uint16_t*>(pq), rn2, qn2, maxbits, slots, flagged, margin, pe, seed_d2, tau_seed,
+                     S == 0 ? tau_g : nullptr);
+        if (margin) {
+            L.margin = margin;
+            L.k = k;
+        }
+        L.tau_seed = tau_seed;
+        zero_slots = slots;  // knn_refine leaves them zeroed for the next search
+        ws.slots_clean = false;
+        if (S > 0) ok = go(L);
+    } else {
+        ws.slots_clean = false;
+        BMX_HIP(hipMemsetAsync(maxbits, 0, sizeof(unsigned long long), stream));
+        bf16_prep(stream, X, ref_rows, nr, nr_pad, d, NS, centre, 0, reinterpret_cast<uint16_t*>(pr), rn2, maxbits, slots);
+        bf16_prep(stream, Qs, qrs, nq, nq_pad, d, NS, centre, 1, reinterpret_cast<uint16_t*>(pq), qn2, maxbits, slots);
+        // sample pass: threshold estimation over rows [0, S); full pass: every row, starting from that threshold
+        if (S == 0) {  // no sample: +inf everywhere (0xFF800000 is the orderable image of +inf)
+            hipLaunchKernelGGL(fill_u32, dim3(cdiv(nq_pad, 256)), dim3(256), 0, stream, tau_g, nq_pad, 0xFF800000u);
+            BMX_LAUNCH_CHECK();
+        }
+        if (S > 0) ok = go(L);
+        if (seed_d2) {  // tau_g = min(sampled threshold, seed threshold)
+            hipLaunchKernelGGL(seed_tau_kernel, dim3(cdiv(nq_pad, 256)), dim3(256), 0, stream, seed_d2, qn2, maxbits, nq, nq_pad,
+                               pe, tau_g);
+            BMX_LAUNCH_CHECK();
+        }
+        BMX_HIP(hipMemsetAsync(flagged, 0, sizeof(int32_t), stream));
     }
     L.first_begin = 0;
     L.range_len = chunk_len;
@@ -712,15 +716,13 @@ void candidate_pass(hipStream_t stream, KnnWorkspace& ws, const Tier& T, const d
     L.sample = 0;
     ok = ok && go(L);
     if (!ok) throw Error(BMX_ERR_ARG, "kNN: unsupported padded dimension");
-
-    BMX_HIP(hipMemsetAsync(flagged, 0, sizeof(int32_t), stream));
     {
         // rows of an even number of doubles are 16-byte aligned: the quad gather, instantiated for the row length
         const int need = (d & 1) ? 0 : cdiv(d, 8);
 #define BMX_REFINE(NC) \
     hipLaunchKernelGGL(knn_refine<NC>, dim3(cdiv(nq, 4)), dim3(256), 0, stream, X, ref_rows, Qs, qrs, nq, d, k, KS, nchunks, \
                        eps_k, eps_qr, eps_split, eps_den, T.id == 1 ? 1 : 0, cand, cand_v, tau, qn2, maxbits, seed_d2, io, \
-                       dout, flagged, flag_bound)
+                       dout, flagged, flag_bound, zero_slots)
         if (need == 0 || need > 16) BMX_REFINE(0);
         else if (need <= 2) BMX_REFINE(2);
         else if (need <= 4) BMX_REFINE(4);
@@ -731,6 +733,7 @@ void candidate_pass(hipStream_t stream, KnnWorkspace& ws, const Tier& T, const d
 #undef BMX_REFINE
     }
     BMX_LAUNCH_CHECK();
+    if (zero_slots) ws.slots_clean = true;
     if (debug_prints()) {
         std::vector<int32_t> hc((size_t)nq * nchunks * KS);
         BMX_HIP(hipMemcpyAsync(hc.data(), cand, hc.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
@@ -794,7 +797,7 @@ namespace {
 // everything when there are no bounds, takes the full scan.
 void exact_search(hipStream_t stream, KnnWorkspace& ws, const double* X, const int32_t* ref_rows, int nr, const double* Qs,
                   const int32_t* qrs, int d, int k, int32_t* io, double* dout, const int32_t* list,
-                  const double* bounds, int count) {
+                  const double* bounds, int count, bool seeded = false) {
     if (count <= 0) return;
     ws.last_exact += count;
     const int32_t* scan_list = list;
@@ -803,15 +806,16 @@ void exact_search(hipStream_t stream, KnnWorkspace& ws, const double* X, const i
         double* xd = ws.xd.reserve((size_t)count * XF_CAP);
         int32_t* xi = ws.xi.reserve((size_t)count * XF_CAP);
         int32_t* slow = ws.slow.reserve((size_t)count + 1);
+        ws.xcnt_clear = false;  // (the lists' counters are left as the sweep filled them)
         BMX_HIP(hipMemsetAsync(xcnt, 0, (size_t)count * sizeof(int32_t), stream));
         BMX_HIP(hipMemsetAsync(slow, 0, sizeof(int32_t), stream));
         const size_t lds = (size_t)XF_TILE * (d + 1) * sizeof(double);
         ensure_dynamic_lds(reinterpret_cast<const void*>(&knn_exact_filter), lds);
         hipLaunchKernelGGL(knn_exact_filter, dim3(cdiv(nr, XF_TILE)), dim3(256), lds, stream, X, ref_rows, nr, Qs, qrs, d,
-                           list, bounds, count, xcnt, xd, xi);
+                           list, bounds, count, 0, xcnt, xd, xi);
         BMX_LAUNCH_CHECK();
-        hipLaunchKernelGGL(knn_exact_pick, dim3(cdiv(count, 4)), dim3(256), 0, stream, list, count, k, xcnt, xd, xi, io,
-                           dout, slow);
+        hipLaunchKernelGGL(knn_exact_pick, dim3(cdiv(count, 4)), dim3(256), 0, stream, list, count, 0, k, seeded ? 1 : 0, xcnt,
+                           xd, xi, io, dout, slow, (int32_t*)nullptr);
         BMX_LAUNCH_CHECK();
         count = read_count(stream, ws, slow);
         scan_list = slow;
@@ -845,6 +849,30 @@ void search_tiers(hipStream_t stream, KnnWorkspace& ws, const Tier* tiers, int n
     double* bound = ws.flag_bound_t[t].reserve((size_t)nq + 1);
     // (what a seeded pass cannot settle goes on unseeded: the full k nearest serve the caller just as well)
     candidate_pass(stream, ws, tiers[t], X, ref_rows, nr, Qs, qrs, nq, d, k, io, dout, flagged, bound, seed_d2, centre);
+    if (ws.optimistic && t == 0) {
+        // Optimistic run (the merge engine): no read-back inside a search.  Practically every query is certified by the
+        // first tier (config 3: 1-6 of 3 million per step are not), so the bounded FP64 sweep for the few that are not is
+        // launched unconditionally with the count left on the device -- with nothing flagged its workgroups end at once.
+        // More than OPT_CAP flagged queries, or a list that overflows (massive exact ties), raises opt_state[0]; the engine
+        // looks at it at its next wait and repeats the run with host-checked searches.
+        int32_t* opt = ws.opt_state_ptr(stream);
+        int32_t* xcnt = ws.xcnt.reserve((size_t)KnnWorkspace::OPT_CAP);
+        if (!ws.xcnt_clear) {
+            BMX_HIP(hipMemsetAsync(xcnt, 0, (size_t)KnnWorkspace::OPT_CAP * sizeof(int32_t), stream));
+            ws.xcnt_clear = true;
+        }
+        double* xd = ws.xd.reserve((size_t)KnnWorkspace::OPT_CAP * XF_CAP);
+        int32_t* xi = ws.xi.reserve((size_t)KnnWorkspace::OPT_CAP * XF_CAP);
+        const size_t lds = (size_t)XF_TILE * (d + 1) * sizeof(double);
+        ensure_dynamic_lds(reinterpret_cast<const void*>(&knn_exact_filter), lds);
+        hipLaunchKernelGGL(knn_exact_filter, dim3(std::min(cdiv(nr, XF_TILE), 2048)), dim3(256), lds, stream, X, ref_rows, nr, Qs,
+                           qrs, d, flagged, bound, 0, KnnWorkspace::OPT_CAP, xcnt, xd, xi);
+        BMX_LAUNCH_CHECK();
+        hipLaunchKernelGGL(knn_exact_pick, dim3(KnnWorkspace::OPT_CAP / 4), dim3(256), 0, stream, flagged, 0,
+                           KnnWorkspace::OPT_CAP, k, seed_d2 ? 1 : 0, xcnt, xd, xi, io, dout, (int32_t*)nullptr, opt);
+        BMX_LAUNCH_CHECK();
+        return;
+    }
     // the number of uncertified queries decides what is launched next, so it is read back (one small synchronisation)
     const int count = read_count(stream, ws, flagged);
     if (count == 0) return;
@@ -864,7 +892,7 @@ void search_tiers(hipStream_t stream, KnnWorkspace& ws, const Tier* tiers, int n
                            sub_idx, sub_dist, io, dout);
         BMX_LAUNCH_CHECK();
     } else {
-        exact_search(stream, ws, X, ref_rows, nr, Qs, qrs, d, k, io, dout, flagged, bound, count);
+        exact_search(stream, ws, X, ref_rows, nr, Qs, qrs, d, k, io, dout, flagged, bound, count, seed_d2 != nullptr);
     }
 }
 

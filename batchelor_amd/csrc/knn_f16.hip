@@ -98,18 +98,19 @@ __host__ __device__ __forceinline__ double f16_scale(double max_n2) {
 // before anything is written).  PHASE 1: the fp16 tile images (fragment-major for references, row-major for
 // queries; same addressing as knn_prep_bf16), scaled.
 // ---------------------------------------------------------------------------------------------------
+// One tile of 32 rows (tile number `block`).  scale: PHASE 1 only.  Returns the row's exact squared norm (the eight threads
+// of a row all hold it).
 template <int PHASE>
-__global__ __launch_bounds__(256) void knn_prep_f16(const double* __restrict__ X, const int32_t* __restrict__ rows, int n,
-                                                    int d, int NS, const double* __restrict__ mean, int is_query,
-                                                    uint16_t* __restrict__ P, double* __restrict__ n2,
-                                                    unsigned long long* __restrict__ max_slots,
-                                                    const unsigned long long* __restrict__ max_n2_bits) {
-    extern __shared__ __attribute__((aligned(16))) char smem_pp[];
+__device__ __forceinline__ double prep_rows(char* smem_pp, int block, const double* __restrict__ X,
+                                            const int32_t* __restrict__ rows, int n, int d, int NS,
+                                            const double* __restrict__ mean, int is_query, uint16_t* __restrict__ P,
+                                            double* __restrict__ n2, unsigned long long* __restrict__ max_slots,
+                                            double scale) {
     const int K = 16 * NS;
     float* xs = reinterpret_cast<float*>(smem_pp);  // [32][d] centred, rounded to f32
     float* nrm = xs + 32 * d;                       // [32] f32(|x'|^2), scaled
     const int tid = threadIdx.x;
-    const int r0 = blockIdx.x * 32;
+    const int r0 = block * 32;
     const float inv_d = 1.0f / (float)d;
     for (int e = tid; e < 32 * d; e += 256) {
         int rr = (int)(((float)e + 0.5f) * inv_d);  // e < 32 * 128: the float quotient is exact up to +-1
@@ -145,10 +146,9 @@ __global__ __launch_bounds__(256) void knn_prep_f16(const double* __restrict__ X
         double m = live ? s : 0.0;
         for (int o = 8; o < 64; o <<= 1) m = fmax(m, __shfl_xor(m, o));
         if ((tid & 63) == 0)  // one atomic per wave, spread over 64 words a cache line apart
-            atomicMax(max_slots + (size_t)(blockIdx.x & 63) * 16, (unsigned long long)__double_as_longlong(m));
-        return;
+            atomicMax(max_slots + (size_t)(block & 63) * 16, (unsigned long long)__double_as_longlong(m));
+        return s;
     }
-    const double scale = f16_scale(__longlong_as_double((long long)*max_n2_bits));
     const float sf = (float)scale;  // a power of two: every product below is exact
     if (is_query) {
         // a query so far out that -2 q' leaves the fp16 range cannot be handled here: poison its norm, the
@@ -212,6 +212,68 @@ __global__ __launch_bounds__(256) void knn_prep_f16(const double* __restrict__ X
         }
         out[p] = make_uint4(w[0], w[1], w[2], w[3]);
     }
+    return s;
+}
+
+// PHASE 0 over the references: norms + the 64 slot maxima (the slots are zero when the search starts)
+__global__ __launch_bounds__(256) void knn_prep_f16_norms(const double* __restrict__ X, const int32_t* __restrict__ rows, int n,
+                                                          int d, int NS, const double* __restrict__ mean,
+                                                          double* __restrict__ n2, unsigned long long* __restrict__ max_slots) {
+    extern __shared__ __attribute__((aligned(16))) char smem_pp[];
+    (void)prep_rows<0>(smem_pp, blockIdx.x, X, rows, n, d, NS, mean, 0, nullptr, n2, max_slots, 1.0);
+}
+
+// PHASE 1 of references AND queries in one launch (workgroups [0, nrb): reference tiles, the others: query tiles), with
+// what used to be four more launches folded in: every workgroup folds the 64 slot maxima itself (workgroup 0 leaves the
+// result in *max_n2_bits for the kernels behind and zeroes the search's flagged-query counter); the query workgroups write
+// each query's margin (twice the pass's error bound) and, for a seeded search, its seed threshold -- tau_seed, which the
+// sample pass folds into the thresholds it publishes, or straight into tau_g when there is no sample pass (tau_init).
+__global__ __launch_bounds__(256) void knn_prep_f16_rq(const double* __restrict__ X, const int32_t* __restrict__ rrows, int nr,
+                                                       int nrb, const double* __restrict__ Q,
+                                                       const int32_t* __restrict__ qrows, int nq, int d, int NS,
+                                                       const double* __restrict__ mean, uint16_t* __restrict__ Pr,
+                                                       uint16_t* __restrict__ Pq, double* __restrict__ rn2,
+                                                       double* __restrict__ qn2, const unsigned long long* __restrict__ slots,
+                                                       unsigned long long* __restrict__ max_n2_bits,
+                                                       int32_t* __restrict__ flagged0, float* __restrict__ margin, PassEps pe,
+                                                       const float* __restrict__ seed_d2, uint32_t* __restrict__ tau_seed,
+                                                       uint32_t* __restrict__ tau_init) {
+    extern __shared__ __attribute__((aligned(16))) char smem_pp[];
+    __shared__ double sh_max;
+    if (threadIdx.x < 64) {
+        double m = __longlong_as_double((long long)slots[(size_t)threadIdx.x * 16]);
+        for (int o = 1; o < 64; o <<= 1) m = fmax(m, __shfl_xor(m, o));
+        if (threadIdx.x == 0) {
+            sh_max = m;
+            if (blockIdx.x == 0) {
+                *max_n2_bits = (unsigned long long)__double_as_longlong(m);
+                if (flagged0) *flagged0 = 0;
+            }
+        }
+    }
+    __syncthreads();
+    const double max_rn2 = sh_max;
+    const double scale = f16_scale(max_rn2);
+    if ((int)blockIdx.x < nrb) {
+        (void)prep_rows<1>(smem_pp, blockIdx.x, X, rrows, nr, d, NS, mean, 0, Pr, rn2, nullptr, scale);
+        return;
+    }
+    const int qb = blockIdx.x - nrb;
+    const double s = prep_rows<1>(smem_pp, qb, Q, qrows, nq, d, NS, mean, 1, Pq, qn2, nullptr, scale);
+    const int rr = threadIdx.x >> 3, sub = threadIdx.x & 7;
+    if (sub == 0) {
+        const int q = qb * 32 + rr;
+        const bool live = q < nq;
+        // (a query that left the fp16 range has a NaN norm in qn2: its margin and threshold are NaN-safe -- it fails the
+        // certificate whatever the pass collects)
+        const double nn = live ? qn2[q] : 0.0;
+        (void)s;
+        if (margin) margin[q] = live ? pass_margin(nn, max_rn2, pe) : 0.f;
+        uint32_t ts = 0xFF800000u;  // the orderable image of +inf: no seed
+        if (seed_d2) ts = live ? pass_seed_tau((double)seed_d2[q], nn, max_rn2, pe) : f32_orderable(-__builtin_inff());
+        if (tau_seed) tau_seed[q] = ts;
+        if (tau_init) tau_init[q] = ts;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -262,7 +324,8 @@ template <int NS, int KS, int LCAP, bool SAMPLE>
 __global__ __launch_bounds__((NCONS + NPROD + serv_waves(NS)) * 64) void knn_topk_f16(
     const uint16_t* __restrict__ Pq, const uint16_t* __restrict__ PrF, int first_begin, int range_len, int r_limit,
     int n_full, int nranges, int out_chunk0, int out_nchunks, uint32_t* __restrict__ tau_g, int32_t* __restrict__ cand,
-    float* __restrict__ cand_v, float* __restrict__ tau_out, const float* __restrict__ margin_g, int kq) {
+    float* __restrict__ cand_v, float* __restrict__ tau_out, const float* __restrict__ margin_g, int kq,
+    const uint32_t* __restrict__ tau_seed) {
     constexpr int TILE_BYTES = NS * 1024;
     constexpr int TP = tile_pairs_for(NS, KS);  // tile pairs per ring slot
     constexpr int SLOT_BYTES = TP * 2 * TILE_BYTES;
@@ -1038,7 +1101,8 @@ __global__ __launch_bounds__((NCONS + NPROD + serv_waves(NS)) * 64) void knn_top
                 if (tm == tm) start = min(start, f32_orderable(tm));  // (no k-th value yet: inf, nothing changes)
             }
         }
-        if (h == 0) tau_g[q] = start;
+        // (a seeded search: the tighter of the sampled threshold and the seed's, prep wrote the latter's image)
+        if (h == 0) tau_g[q] = tau_seed ? min(start, tau_seed[q]) : start;
 #ifdef BMX_STAMPS
         if (lane == 0) {
             atomicAdd(&bmx_dbg16[0], STAMP() - dbg_t0);
@@ -1091,11 +1155,11 @@ void launch(hipStream_t stream, KnnWorkspace& ws, const Bf16Launch& L) {
     if (L.sample)
         hipLaunchKernelGGL((knn_topk_f16<NS, KS, LCAP, true>), dim3(items), dim3((NCONS + NPROD + serv_waves(NS)) * 64), lds, stream,
                            L.pq, L.pr, L.first_begin, L.range_len, L.r_limit, L.n_full, L.nranges, L.out_chunk0,
-                           L.out_nchunks, L.tau_g, L.cand, L.cand_v, L.tau, L.margin, L.k);
+                           L.out_nchunks, L.tau_g, L.cand, L.cand_v, L.tau, L.margin, L.k, L.tau_seed);
     else
         hipLaunchKernelGGL((knn_topk_f16<NS, KS, LCAP, false>), dim3(items), dim3((NCONS + NPROD + serv_waves(NS)) * 64), lds, stream,
                            L.pq, L.pr, L.first_begin, L.range_len, L.r_limit, L.n_full, L.nranges, L.out_chunk0,
-                           L.out_nchunks, L.tau_g, L.cand, L.cand_v, L.tau, L.margin, L.k);
+                           L.out_nchunks, L.tau_g, L.cand, L.cand_v, L.tau, L.margin, L.k, (const uint32_t*)nullptr);
     BMX_LAUNCH_CHECK();
     if (ws.profile) BMX_HIP(hipEventRecord(ev.second, stream));
 #ifdef BMX_STAMPS
@@ -1129,27 +1193,18 @@ int f16_pick_ns(int d, int KS) {
     return 0;
 }
 
-__global__ void fold_max_slots16(const unsigned long long* __restrict__ slots, unsigned long long* __restrict__ out) {
-    double m = __longlong_as_double((long long)slots[(size_t)threadIdx.x * 16]);
-    for (int o = 1; o < 64; o <<= 1) m = fmax(m, __shfl_xor(m, o));
-    if (threadIdx.x == 0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
-}
-
-// references: two passes (norms + maximum, then the scaled image); queries: one
-void f16_prep(hipStream_t stream, const double* X, const int32_t* rows, int n, int n_pad, int d, int NS,
-              const double* mean, int is_query, uint16_t* P, double* n2, unsigned long long* maxbits,
-              unsigned long long* slots) {
+// References (norm pass, then the scaled image) and queries (image, norm, margin, seed threshold) of one search: two
+// launches.  `slots` (64 x 16 words) must be zero on entry -- knn_refine leaves them so for the next search.
+void f16_prep_all(hipStream_t stream, const double* X, const int32_t* rrows, int nr, int nr_pad, const double* Q,
+                  const int32_t* qrows, int nq, int nq_pad, int d, int NS, const double* mean, uint16_t* Pr, uint16_t* Pq,
+                  double* rn2, double* qn2, unsigned long long* maxbits, unsigned long long* slots, int32_t* flagged0,
+                  float* margin, const PassEps& pe, const float* seed_d2, uint32_t* tau_seed, uint32_t* tau_init) {
     const size_t lds = (size_t)32 * d * 4 + 128 + 16;
-    if (!is_query) {
-        BMX_HIP(hipMemsetAsync(slots, 0, 64 * 16 * sizeof(unsigned long long), stream));
-        hipLaunchKernelGGL(knn_prep_f16<0>, dim3(n_pad / 32), dim3(256), lds, stream, X, rows, n, d, NS, mean, 0, P, n2,
-                           slots, maxbits);
-        BMX_LAUNCH_CHECK();
-        hipLaunchKernelGGL(fold_max_slots16, dim3(1), dim3(64), 0, stream, slots, maxbits);
-        BMX_LAUNCH_CHECK();
-    }
-    hipLaunchKernelGGL(knn_prep_f16<1>, dim3(n_pad / 32), dim3(256), lds, stream, X, rows, n, d, NS, mean, is_query, P,
-                       n2, slots, maxbits);
+    hipLaunchKernelGGL(knn_prep_f16_norms, dim3(nr_pad / 32), dim3(256), lds, stream, X, rrows, nr, d, NS, mean, rn2, slots);
+    BMX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(knn_prep_f16_rq, dim3(nr_pad / 32 + nq_pad / 32), dim3(256), lds, stream, X, rrows, nr, nr_pad / 32, Q, qrows,
+                       nq, d, NS, mean, Pr, Pq, rn2, qn2, (const unsigned long long*)slots, maxbits, flagged0, margin, pe, seed_d2,
+                       tau_seed, tau_init);
     BMX_LAUNCH_CHECK();
 }
 

@@ -19,6 +19,53 @@ __device__ __forceinline__ float orderable_f32(uint32_t o) {
     return __uint_as_float(u);
 }
 
+// ---- error bound of a candidate pass (shared by the prep kernels, which hand the pass its margins and seeded thresholds,
+// and by knn_refine, which certifies with the same numbers) ----------------------------------------------------------
+struct PassEps {
+    double eps_k, eps_qr, eps_split, eps_den;
+    int scaled;  // fp16 tier: coordinates times the power of two pass_scale(max |r|^2)
+};
+
+// power-of-two scale that puts the largest reference norm into (24, 48]; 1 for degenerate input (= f16_scale, knn_f16.hip)
+__host__ __device__ __forceinline__ double pass_scale(double max_n2) {
+    const double rm = sqrt(max_n2);
+    if (!(rm > 1e-150) || !(rm < 1e150)) return 1.0;
+    int e = 0;
+    (void)frexp(48.0 / rm, &e);
+    return ldexp(1.0, e - 1);
+}
+
+// error bound of a candidate pass for one query (unscaled units): f32 rounding of the centred coordinates +
+// accumulation over eps_k terms, the low-order products the pass drops (eps_split |q||r|), and fp16 inputs below the
+// normal range taken as flushed to zero (eps_den, scaled units)
+__device__ __forceinline__ double pass_eps(double qn, double rm, double s, double eps_k, double eps_qr, double eps_split,
+                                           double eps_den) {
+    const double u = 5.9604644775390625e-8;  // 2^-24
+    return 1.5 * u * (2.0 * (qn + rm) * (qn + rm) + (eps_k + 1.0) * (rm * rm + eps_qr * qn * rm)) +
+           eps_split * qn * rm + eps_den * ((2.0 * qn + rm) * s + 1.0) / (s * s);
+}
+
+// Twice the pass's error bound for a query of squared norm qn2, in the pass's own (scaled) units, rounded up: a reference
+// whose approximate value exceeds the k-th best approximate value by more than this is farther, exactly, than each of
+// those k -- the cut knn_refine applies to the candidates, handed to the pass itself so that it stops collecting them.
+__device__ __forceinline__ float pass_margin(double qn2, double max_rn2, const PassEps& pe) {
+    const double s = pe.scaled ? pass_scale(max_rn2) : 1.0;
+    const double eps = pass_eps(sqrt(qn2), sqrt(max_rn2), s, pe.eps_k, pe.eps_qr, pe.eps_split, pe.eps_den);
+    const double x = 2.0 * eps * (s * s) * 1.0000002 + 1e-30;
+    return (float)(x * 1.000001);  // (the f32 rounding cannot land below x)
+}
+
+// Seeded search: the starting threshold of a query in the pass's own units, as its order-preserving image.  A reference
+// within seed_d2 of the query has an approximate value below (seed - |q~|^2 + eps) s^2, so nothing the caller cares about is
+// filtered out.
+__device__ __forceinline__ uint32_t pass_seed_tau(double seed_d2, double qn2, double max_rn2, const PassEps& pe) {
+    const double s = pe.scaled ? pass_scale(max_rn2) : 1.0;
+    const double eps = pass_eps(sqrt(qn2), sqrt(max_rn2), s, pe.eps_k, pe.eps_qr, pe.eps_split, pe.eps_den);
+    const double x = (seed_d2 - qn2 + eps) * (s * s);
+    const float t = (float)(x + fabs(x) * 9.5367431640625e-7 + 1e-30);  // + 2^-20 relative: the f32 rounding cannot land below x
+    return f32_orderable(t);
+}
+
 // Per query slot the LDS holds KS "kept" entries (sorted, shared by the two lanes that own the query's two K-halves)
 // followed by two lane-private pending lists of PL entries each: a lane appends with a plain ds_write (no atomics, no
 // returned value to wait for).  When a pending list fills, one wave merges kept + both pending lists by rank-counting

@@ -2,64 +2,96 @@
 // per-row sort + binary search (rows are <= a few dozen ids, a linear probe of the partner's row is cheaper), plus
 // the ordered stream compaction that reproduces the reference's pair order (left ascending, then neighbour rank).
 #include "bmx_ops.hpp"
+#include "scan_lookback.hpp"
 
 namespace bmx {
 namespace {
 
-constexpr int SCAN_ITEMS = 8;                     // per thread
-constexpr int SCAN_BLOCK = 256 * SCAN_ITEMS;      // per block
-
-__global__ __launch_bounds__(256) void scan_blocks(const int32_t* __restrict__ in, int32_t* __restrict__ out, int n,
-                                                   int32_t* __restrict__ block_sums) {
-    __shared__ int32_t wave_tot[4];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int base = blockIdx.x * SCAN_BLOCK + tid * SCAN_ITEMS;
-    int32_t v[SCAN_ITEMS];
-    int32_t s = 0;
+// ---- compactions as single launches (scan_lookback.hpp) -------------------------------------------------------------
+// One list: value(i) in {0, 1, ...}; off[i] = exclusive prefix, off[n] = total; optionally the positions of the non-zero
+// entries (sel), and per selected position the reset of what the next steps accumulate into (seed, mask).
+// MODE 0: value = (stamp[i] == gen)   (rows some neighbour list names: mark_listed stamps them with the search's number)
+// MODE 1: value = popcount(mask[i])   (pairs per selected left cell)
+// MODE 2: value = in[i]               (counts)
+// MODE 3: value = in[i] > 0           (right cells with at least one pair)
+template <int MODE>
+__device__ __forceinline__ void compact_block(const scan::Chain ch, int bid, int nblocks, const int32_t* __restrict__ in,
+                                              const unsigned long long* __restrict__ mask, int gen, int n,
+                                              int32_t* __restrict__ off, int32_t* __restrict__ sel,
+                                              int32_t* __restrict__ total_out, uint32_t* __restrict__ zero32,
+                                              unsigned long long* __restrict__ zero64, unsigned int* sh4) {
+    const int base = bid * scan::BLOCK + threadIdx.x * scan::ITEMS;
+    unsigned int v[scan::ITEMS], mine = 0;
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i) {
-        v[i] = base + i < n ? in[base + i] : 0;
-        s += v[i];
+    for (int i = 0; i < scan::ITEMS; ++i) {
+        unsigned int x = 0;
+        if (base + i < n) {
+            if (MODE == 0) x = in[base + i] == gen ? 1u : 0u;
+            if (MODE == 1) x = (unsigned int)__popcll(mask[base + i]);
+            if (MODE == 2) x = (unsigned int)in[base + i];
+            if (MODE == 3) x = in[base + i] > 0 ? 1u : 0u;
+        }
+        v[i] = x;
+        mine += x;
     }
-    int32_t inc = s;  // inclusive scan of per-thread sums across the wave
-    for (int o = 1; o < 64; o <<= 1) {
-        const int32_t t = __shfl_up(inc, o);
-        if (lane >= o) inc += t;
-    }
-    if (lane == 63) wave_tot[w] = inc;
-    __syncthreads();
-    int32_t woff = 0;
-    for (int i = 0; i < w; ++i) woff += wave_tot[i];
-    int32_t run = woff + inc - s;
+    unsigned int total = 0;
+    bool last = false;
+    unsigned int run = scan::exclusive_prefix(ch, bid, nblocks, mine, sh4, &total, &last);
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i) {
-        if (base + i < n) out[base + i] = run;
+    for (int i = 0; i < scan::ITEMS; ++i) {
+        if (base + i < n) {
+            if (off) off[base + i] = (int32_t)run;
+            if ((MODE == 0 || MODE == 3) && v[i]) {
+                if (sel) sel[run] = base + i;
+                if (zero32) zero32[run] = 0u;
+                if (zero64) zero64[run] = 0ull;
+            }
+        }
         run += v[i];
     }
-    if (tid == 255) block_sums[blockIdx.x] = woff + inc;
+    if (last && threadIdx.x == 0) {
+        if (off) off[n] = (int32_t)total;
+        if (total_out) *total_out = (int32_t)total;
+    }
 }
 
-__global__ void scan_block_sums(const int32_t* __restrict__ sums, int32_t* __restrict__ offs, int nblocks,
-                                int32_t* __restrict__ total_slot) {
-    // one thread: nblocks is n / 2048 (a few thousand at most)
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    int32_t run = 0;
-    for (int b = 0; b < nblocks; ++b) {
-        offs[b] = run;
-        run += sums[b];
-    }
-    *total_slot = run;
+__global__ __launch_bounds__(256) void select_listed_kernel(scan::Chain ch, const int32_t* __restrict__ stamp, int gen, int n,
+                                                            int32_t* __restrict__ off, int32_t* __restrict__ sel,
+                                                            int32_t* __restrict__ total_out, uint32_t* __restrict__ seed,
+                                                            unsigned long long* __restrict__ mask) {
+    __shared__ unsigned int sh4[8];
+    __shared__ int sh_b;
+    const int bid = scan::take_ticket(ch, &sh_b);
+    compact_block<0>(ch, bid, gridDim.x, stamp, nullptr, gen, n, off, sel, total_out, seed, mask, sh4);
 }
 
-__global__ __launch_bounds__(256) void scan_add_offsets(int32_t* __restrict__ out, int n,
-                                                        const int32_t* __restrict__ offs) {
-    const int i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
-    const int32_t o = offs[blockIdx.x];
-#pragma unroll
-    for (int t = 0; t < SCAN_ITEMS; ++t) {
-        const int idx = i + t * 256;
-        if (idx < n) out[idx] += o;
+// Two lists in one launch: workgroups [0, nbA) scan the pairs per selected left cell (popcount of its mask, or cntL where
+// k2 > 64 has no masks), workgroups [nbA, nbA + nbB) compact the right cells that have a pair.
+__global__ __launch_bounds__(256) void pair_scans_kernel(scan::Chain chA, int nbA, const unsigned long long* __restrict__ maskL,
+                                                         const int32_t* __restrict__ cntL, int nsel, int32_t* __restrict__ offL,
+                                                         int32_t* __restrict__ totalP, scan::Chain chB, int nbB,
+                                                         const int32_t* __restrict__ cntR, int nR, int32_t* __restrict__ offR,
+                                                         int32_t* __restrict__ second_u, int32_t* __restrict__ totalU) {
+    __shared__ unsigned int sh4[8];
+    __shared__ int sh_b;
+    if ((int)blockIdx.x < nbA) {  // (physical block ranges only pick the list; logical numbers come from the list's ticket)
+        const int bid = scan::take_ticket(chA, &sh_b);
+        if (maskL)
+            compact_block<1>(chA, bid, nbA, nullptr, maskL, 0, nsel, offL, nullptr, totalP, nullptr, nullptr, sh4);
+        else
+            compact_block<2>(chA, bid, nbA, cntL, nullptr, 0, nsel, offL, nullptr, totalP, nullptr, nullptr, sh4);
+    } else {
+        const int bid = scan::take_ticket(chB, &sh_b);
+        compact_block<3>(chB, bid, nbB, cntR, nullptr, 0, nR, offR, second_u, totalU, nullptr, nullptr, sh4);
     }
+}
+
+__global__ __launch_bounds__(256) void scan_counts_kernel(scan::Chain ch, const int32_t* __restrict__ in, int n,
+                                                          int32_t* __restrict__ off) {
+    __shared__ unsigned int sh4[8];
+    __shared__ int sh_b;
+    const int bid = scan::take_ticket(ch, &sh_b);
+    compact_block<2>(ch, bid, gridDim.x, in, nullptr, 0, n, off, nullptr, nullptr, nullptr, nullptr, sh4);
 }
 
 __device__ __forceinline__ bool row_contains(const int32_t* __restrict__ row, int k, int32_t want) {
@@ -149,11 +181,6 @@ __global__ __launch_bounds__(256) void mutual_right_wide(const int32_t* __restri
     if (r < nR && j == 0) cntR[r] = m;
 }
 
-__global__ void popcount_rows(const unsigned long long* __restrict__ mask, int n, int32_t* __restrict__ cnt) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) cnt[i] = __popcll(mask[i]);
-}
-
 __global__ void emit_pairs_kernel(const int32_t* __restrict__ idxLR, int nL, int k2, const int32_t* __restrict__ idxRL,
                                   int k1, const int32_t* __restrict__ offL, const int32_t* __restrict__ lsel,
                                   const int32_t* __restrict__ lrows, const int32_t* __restrict__ rrows,
@@ -176,14 +203,10 @@ __global__ void emit_pairs_kernel(const int32_t* __restrict__ idxLR, int nL, int
     }
 }
 
-__global__ void flag_positive(const int32_t* __restrict__ cnt, int n, int32_t* __restrict__ flag) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) flag[i] = cnt[i] > 0 ? 1 : 0;
-}
-
-__global__ void mark_listed(const int32_t* __restrict__ idx, int64_t n, int32_t* __restrict__ flag) {
+// stamp[row] = gen for every row some list names (the stamps are never cleared: each search brings its own number)
+__global__ void mark_listed(const int32_t* __restrict__ idx, int64_t n, int32_t* __restrict__ stamp, int gen) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) flag[idx[i]] = 1;  // same value from every writer: no atomics needed
+    if (i < n) stamp[idx[i]] = gen;  // same value from every writer: no atomics needed
 }
 
 // seed[c] = max over the right cells r that list left cell l (c = row of l among the selected left cells) of
@@ -204,35 +227,35 @@ __global__ void compose_rows(const int32_t* __restrict__ sel, int n, const int32
     if (i < n) out[i] = rows[sel[i]];
 }
 
-__global__ void scatter_positions(const int32_t* __restrict__ flag, const int32_t* __restrict__ off, int n,
-                                  int32_t* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && flag[i]) out[off[i]] = i;
-}
-
 }  // namespace
 
-void exclusive_scan_i32(hipStream_t stream, ScanWorkspace& ws, const int32_t* in, int32_t* out, int n) {
-    const int nb = std::max(1, cdiv(n, SCAN_BLOCK));
-    int32_t* sums = ws.block_sums.reserve(nb);
-    int32_t* offs = ws.block_offs.reserve(nb);
-    hipLaunchKernelGGL(scan_blocks, dim3(nb), dim3(256), 0, stream, in, out, n, sums);
-    BMX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(scan_block_sums, dim3(1), dim3(64), 0, stream, sums, offs, nb, out + n);
-    BMX_LAUNCH_CHECK();
-    if (nb > 1) {
-        hipLaunchKernelGGL(scan_add_offsets, dim3(nb), dim3(256), 0, stream, out, n, offs);
-        BMX_LAUNCH_CHECK();
+scan::Chain ScanWorkspace::chain(hipStream_t stream, int which, int nblocks) {
+    if (!ticket.p) {
+        ticket.reserve(8);
+        BMX_HIP(hipMemsetAsync(ticket.p, 0, 8 * sizeof(unsigned int), stream));
     }
+    if ((size_t)nblocks > chain_cap) {  // both chains grow together (stale words carry old epochs: harmless, but a fresh
+        chain_cap = (size_t)nblocks + 64;  // block holds anything -- clear it once)
+        status.reserve(2 * chain_cap);
+        BMX_HIP(hipMemsetAsync(status.p, 0, 2 * chain_cap * sizeof(unsigned long long), stream));
+    }
+    epoch = epoch >= 0x3FFFFFF0u ? 1u : epoch + 1u;
+    return scan::Chain{status.p + (size_t)which * chain_cap, ticket.p + which, epoch};
+}
+
+void exclusive_scan_i32(hipStream_t stream, ScanWorkspace& ws, const int32_t* in, int32_t* out, int n) {
+    const int nb = std::max(1, cdiv(n, scan::BLOCK));
+    hipLaunchKernelGGL(scan_counts_kernel, dim3(nb), dim3(256), 0, stream, ws.chain(stream, 0, nb), in, n, out);
+    BMX_LAUNCH_CHECK();
 }
 
 void mutual_counts(hipStream_t stream, const int32_t* idxLR, int nL, int k2, const int32_t* idxRL, int nR, int k1,
                    int32_t* cntL, int32_t* partR, int32_t* cntR, const int32_t* lsel, const int32_t* lpos2c,
-                   unsigned long long* maskL) {
-    // k2 <= 64 (and a mask buffer): the right cells' probe finds every mutual pair once and marks it on both sides;
-    // otherwise the left side is probed separately
+                   unsigned long long* maskL, bool mask_is_clear) {
+    // k2 <= 64 (and a mask buffer): the right cells' probe finds every mutual pair once and marks it on both sides (the
+    // pairs of a left cell are then the popcount of its mask); otherwise the left side is probed separately into cntL
     const bool fused = maskL != nullptr && k2 <= 64;
-    if (fused && nL > 0) BMX_HIP(hipMemsetAsync(maskL, 0, (size_t)nL * sizeof(unsigned long long), stream));
+    if (fused && nL > 0 && !mask_is_clear) BMX_HIP(hipMemsetAsync(maskL, 0, (size_t)nL * sizeof(unsigned long long), stream));
     if (!fused && nL > 0) {
         hipLaunchKernelGGL(mutual_left, dim3(cdiv(nL, 256)), dim3(256), 0, stream, idxLR, nL, k2, idxRL, k1, lsel,
                            cntL, (unsigned long long*)nullptr);
@@ -247,11 +270,17 @@ void mutual_counts(hipStream_t stream, const int32_t* idxLR, int nL, int k2, con
                                partR, cntR, fused ? maskL : nullptr);
         BMX_LAUNCH_CHECK();
     }
-    if (fused && nL > 0) {
-        hipLaunchKernelGGL(popcount_rows, dim3(cdiv(nL, 256)), dim3(256), 0, stream, (const unsigned long long*)maskL, nL,
-                           cntL);
-        BMX_LAUNCH_CHECK();
-    }
+}
+
+void pair_scans(hipStream_t stream, ScanWorkspace& ws, const unsigned long long* maskL, const int32_t* cntL, int nsel, int k2,
+                int32_t* offL, int32_t* totalP, const int32_t* cntR, int nR, int32_t* offR, int32_t* second_u,
+                int32_t* totalU) {
+    const int nbA = std::max(1, cdiv(nsel, scan::BLOCK)), nbB = std::max(1, cdiv(nR, scan::BLOCK));
+    const scan::Chain chA = ws.chain(stream, 0, std::max(nbA, nbB));
+    const scan::Chain chB = ws.chain(stream, 1, std::max(nbA, nbB));
+    hipLaunchKernelGGL(pair_scans_kernel, dim3(nbA + nbB), dim3(256), 0, stream, chA, nbA, k2 <= 64 ? maskL : nullptr, cntL, nsel,
+                       offL, totalP, chB, nbB, cntR, nR, offR, second_u, totalU);
+    BMX_LAUNCH_CHECK();
 }
 
 void emit_pairs(hipStream_t stream, const int32_t* idxLR, int nL, int k2, const int32_t* idxRL, int k1,
@@ -264,22 +293,22 @@ void emit_pairs(hipStream_t stream, const int32_t* idxLR, int nL, int k2, const 
 }
 
 void select_listed_rows(hipStream_t stream, ScanWorkspace& ws, const int32_t* idx, int64_t n_entries, int n_rows,
-                        int32_t* flag, int32_t* off, int32_t* sel) {
-    BMX_HIP(hipMemsetAsync(flag, 0, (size_t)n_rows * sizeof(int32_t), stream));
+                        int32_t* stamp, int gen, int32_t* off, int32_t* sel, int32_t* total_out, float* seed_zero,
+                        unsigned long long* mask_zero) {
     if (n_entries > 0) {
-        hipLaunchKernelGGL(mark_listed, dim3(cdiv(n_entries, 256)), dim3(256), 0, stream, idx, n_entries, flag);
+        hipLaunchKernelGGL(mark_listed, dim3(cdiv(n_entries, 256)), dim3(256), 0, stream, idx, n_entries, stamp, gen);
         BMX_LAUNCH_CHECK();
     }
-    exclusive_scan_i32(stream, ws, flag, off, n_rows);
-    hipLaunchKernelGGL(scatter_positions, dim3(cdiv(n_rows, 256)), dim3(256), 0, stream, flag, off, n_rows, sel);
+    const int nb = std::max(1, cdiv(n_rows, scan::BLOCK));
+    hipLaunchKernelGGL(select_listed_kernel, dim3(nb), dim3(256), 0, stream, ws.chain(stream, 0, nb), (const int32_t*)stamp, gen,
+                       n_rows, off, sel, total_out, reinterpret_cast<uint32_t*>(seed_zero), mask_zero);
     BMX_LAUNCH_CHECK();
 }
 
 void seed_thresholds(hipStream_t stream, const int32_t* idxRL, const double* distRL, int64_t n_entries,
                      const int32_t* lpos2c, int nsel, float* seed) {
     if (nsel <= 0) return;
-    BMX_HIP(hipMemsetAsync(seed, 0, (size_t)nsel * sizeof(float), stream));
-    if (n_entries > 0) {
+    if (n_entries > 0) {  // (seed[0, nsel) was zeroed by select_listed_rows)
         hipLaunchKernelGGL(seed_from_lists, dim3(cdiv(n_entries, 256)), dim3(256), 0, stream, idxRL, distRL, n_entries,
                            lpos2c, reinterpret_cast<uint32_t*>(seed));
         BMX_LAUNCH_CHECK();
@@ -289,16 +318,6 @@ void seed_thresholds(hipStream_t stream, const int32_t* idxRL, const double* dis
 void compose_row_list(hipStream_t stream, const int32_t* sel, int n, const int32_t* rows, int32_t* out) {
     if (n <= 0) return;
     hipLaunchKernelGGL(compose_rows, dim3(cdiv(n, 256)), dim3(256), 0, stream, sel, n, rows, out);
-    BMX_LAUNCH_CHECK();
-}
-
-void compact_mnn_cells(hipStream_t stream, ScanWorkspace& ws, const int32_t* cntR, int nR, int32_t* flagR,
-                       int32_t* offR, int32_t* second_u) {
-    if (nR <= 0) return;
-    hipLaunchKernelGGL(flag_positive, dim3(cdiv(nR, 256)), dim3(256), 0, stream, cntR, nR, flagR);
-    BMX_LAUNCH_CHECK();
-    exclusive_scan_i32(stream, ws, flagR, offR, nR);
-    hipLaunchKernelGGL(scatter_positions, dim3(cdiv(nR, 256)), dim3(256), 0, stream, flagR, offR, nR, second_u);
     BMX_LAUNCH_CHECK();
 }
 
