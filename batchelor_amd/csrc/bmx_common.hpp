@@ -55,7 +55,6 @@ struct DevKnobs {
     int no_margin = 0;        // fp16 tier: lists cut at their KS-th best only (round 2's rule)
     int asv_fast = 0;         // adjust_shift_variance: the tiled form whatever the size
     int exchange_always = 0;  // a single rank goes through its exchange transport too (an all-gather of one)
-    int refine_full = 0;      // knn_refine: full ranking for every search (no membership-only mode)
 };
 DevKnobs& dev_knobs();
 bool debug_prints();  // BMX_DEBUG set in the environment (read once)

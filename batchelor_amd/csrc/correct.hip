@@ -227,32 +227,31 @@ __global__ __launch_bounds__(256) void average_correction_half(
 
 // overall.batch = colMeans(averaged) and colMeans(averaged^2) from average_correction_half's partials, then
 // .get_batch_magnitude (R/fastMNN.R:582-595) -- one workgroup
-__global__ __launch_bounds__(256) void average_final(const double* __restrict__ partial, int nblocks, int d, double scale,
-                                                     double* __restrict__ out_sum, double* __restrict__ out_sq,
-                                                     double* __restrict__ magnitude) {
-    __shared__ double sm[4][64];
-    __shared__ double fin[2][256];
-    const int c0 = threadIdx.x & 63, g = threadIdx.x >> 6;
-    for (int which = 0; which < 2; ++which)
-        for (int cb = 0; cb < d; cb += 64) {
-            const int c = cb + c0;
-            double s = 0.0;
-            if (c < d)
-                for (int b = g; b < nblocks; b += 4) s += partial[(int64_t)b * 2 * d + which * d + c];
-            sm[g][c0] = s;
-            __syncthreads();
-            if (g == 0 && c < d) {
-                const double v = ((sm[0][c0] + sm[1][c0]) + (sm[2][c0] + sm[3][c0])) * scale;
-                (which ? out_sq : out_sum)[c] = v;
-                fin[which][c] = v;
-            }
-            __syncthreads();
-        }
+__global__ __launch_bounds__(1024) void average_final(const double* __restrict__ partial, int nblocks, int d, double scale,
+                                                      double* __restrict__ out_sum, double* __restrict__ out_sq,
+                                                      double* __restrict__ magnitude) {
+    // 2 d <= 128 columns x 8 thread groups that share each column's partials, combined in a fixed order (deterministic)
+    __shared__ double sm[8][128];
+    const int e = threadIdx.x & 127, g = threadIdx.x >> 7;
+    double s = 0.0;
+    if (e < 2 * d) {
+        const double* p = partial + e;
+#pragma unroll 8
+        for (int b = g; b < nblocks; b += 8) s += p[(int64_t)b * 2 * d];
+    }
+    sm[g][e] = s;
+    __syncthreads();
+    if (g == 0 && e < 2 * d) {
+        const double v = (((sm[0][e] + sm[1][e]) + (sm[2][e] + sm[3][e])) + ((sm[4][e] + sm[5][e]) + (sm[6][e] + sm[7][e]))) * scale;
+        (e < d ? out_sum : out_sq)[e < d ? e : e - d] = v;
+        sm[0][e] = v;
+    }
+    __syncthreads();
     if (threadIdx.x == 0 && magnitude) {
         double l2sq = 0.0, ave = 0.0;
         for (int c = 0; c < d; ++c) {
-            ave += fin[1][c];
-            l2sq += fin[0][c] * fin[0][c];
+            ave += sm[0][d + c];
+            l2sq += sm[0][c] * sm[0][c];
         }
         *magnitude = ave == 0.0 ? 0.0 : sqrt(l2sq / ave);
     }
@@ -709,7 +708,7 @@ bool average_correction(hipStream_t stream, ReduceWorkspace& ws, const double* L
                            cntR, k1, averaged, partial, srows);
         BMX_LAUNCH_CHECK();
         if (with_sums) {
-            hipLaunchKernelGGL(average_final, dim3(1), dim3(256), 0, stream, (const double*)partial, grid, d, 1.0 / (double)U,
+            hipLaunchKernelGGL(average_final, dim3(1), dim3(1024), 0, stream, (const double*)partial, grid, d, 1.0 / (double)U,
                                overall, msq, magnitude);
             BMX_LAUNCH_CHECK();
         }

@@ -506,23 +506,26 @@ void Engine::node_means(const Node& left, const Node& right, double* mu_l, doubl
 
 void Engine::centre_both(Node& left, Node& right, int vid, const double* mu_l, const double* mu_r) {
     // .center_along_batch_vector on both sides (R/fastMNN.R:496-497) with the "new" variances (:498-499) out of the same
-    // pass; every segment has current statistics here (ensure_stats2 ran, the orthogonalised side was refreshed), so its
-    // old mean is the shift of its one-pass variance
-    ensure_stats2(left, &right);
+    // pass.  The shift of a segment's one-pass variance: its old mean where its statistics are current, else (the side that
+    // has just been orthogonalised) its node's mean -- any fixed vector inside the cloud serves
     std::vector<RowSeg> segs;
     for (Node* node : {&left, &right}) {
         int r0 = 0;
         for (size_t i = 0; i < node->origin.size(); ++i) {
             if (n_slots_ + 1 > slot_cap_) throw Error(BMX_ERR_ARG, "internal: statistics slots exhausted");
-            segs.push_back(RowSeg{node->data.p, r0, node->origin[i].n, node == &left ? mu_l : mu_r,
-                                  means_pool_.p + (size_t)node->stat_slot[i] * d_, n_slots_++});
+            const double* mu = node == &left ? mu_l : mu_r;
+            const bool cur = node->stat_slot.size() == node->origin.size() && node->stat_slot[i] >= 0;
+            segs.push_back(RowSeg{node->data.p, r0, node->origin[i].n, mu,
+                                  cur ? means_pool_.p + (size_t)node->stat_slot[i] * d_ : mu, n_slots_++});
             r0 += node->origin[i].n;
         }
     }
     rows_multi(stream_, red_ws_, d_, segs.data(), (int)segs.size(), vecs_.p, &vid, 1, true, means_pool_.p, scal_.p);
     size_t j = 0;
-    for (Node* node : {&left, &right})
+    for (Node* node : {&left, &right}) {
+        node->stat_slot.assign(node->origin.size(), -1);
         for (size_t i = 0; i < node->origin.size(); ++i) node->stat_slot[i] = segs[j++].slot;
+    }
 }
 
 void Engine::orthogonalize(Node& node, const std::vector<int>& extras) {
@@ -578,9 +581,8 @@ void Engine::merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p,
 
     std::unique_ptr<Section> sec = std::make_unique<Section>(this);  // streaming section 1: statistics, orthogonalisation
     // "old" variances (R/fastMNN.R:467-468): a segment untouched since its last statistics keeps them (the left
-    // node's segments carry the "new" variances of the merge that made it)
-    ensure_stats(left);
-    ensure_stats(right);
+    // node's segments carry the "new" variances of the merge that made it); the stale ones of both nodes in one pass
+    ensure_stats2(left, &right);
     rec.old_slot = left.stat_slot;
     rec.old_slot.insert(rec.old_slot.end(), right.stat_slot.begin(), right.stat_slot.end());
 
@@ -588,8 +590,7 @@ void Engine::merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p,
     // (from the fresh segment statistics where there is no restriction) serve every pass of this merge
     double* mu_l = vecs_.p + (size_t)(2 * B_ + 6) * d_;
     double* mu_r = vecs_.p + (size_t)(2 * B_ + 7) * d_;
-    node_mean(left, mu_l);
-    node_mean(right, mu_r);
+    node_means(left, right, mu_l, mu_r);
     row_pass(right, left.extras, false, mu_r);  // .orthogonalize_other, R/fastMNN.R:473-474
     row_pass(left, right.extras, false, mu_l);
 
@@ -621,56 +622,61 @@ void Engine::merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p,
     emit_pairs(stream_, idxLR_.p, mo.nsel, mo.k2, idxRL_.p, mo.k1, offL_.p, lrows, rrows, first, second, lsel_.p,
                maskL_.p);
 
-    // .average_correction + overall.batch (R/fastMNN.R:480-481)
+    // .average_correction + overall.batch (R/fastMNN.R:480-481); the column means of the averaged vectors, the mean squares
+    // .get_batch_magnitude wants (R/fastMNN.R:582-595) and the magnitude itself come out of the same pass where its fused
+    // form applies
     double* averaged = averaged_.reserve((size_t)mo.U * d_);
-    average_correction(stream_, left.data.p, lrows, right.data.p, rrows, d_, second_u_.p, mo.U, partR_.p, cntR_.p,
-                       mo.k1, averaged);
     const int vid = n_extras_;  // slot of this merge's overall.batch in the pool
     double* overall = vecs_.p + (size_t)vid * d_;
     double* msq = vecs_.p + (size_t)(2 * B_ + 4) * d_;
     rec.batch_size_na = std::isnan(p.min_batch_skip);
-    if (rec.batch_size_na)
-        col_reduce(stream_, red_ws_, averaged, nullptr, 0, mo.U, d_, 0, nullptr, 1.0 / (double)mo.U, overall);
-    else  // the mean squares .get_batch_magnitude wants come out of the same pass
-        col_reduce2(stream_, red_ws_, averaged, mo.U, d_, 1.0 / (double)mo.U, overall, msq);
-
-    bool do_correct = true;
     rec.skipped = false;
     rec.bs_slot = -1;
     if (!rec.batch_size_na) {
-        // .get_batch_magnitude (R/fastMNN.R:582-595) on the device; the host only looks at it here when a merge can
-        // actually be skipped (min.batch.skip > 0), otherwise with everything else at the end of the run
         if (n_slots_ + 1 > slot_cap_) throw Error(BMX_ERR_ARG, "internal: statistics slots exhausted");
         rec.bs_slot = n_slots_++;
-        batch_magnitude(stream_, overall, msq, d_, scal_.p + rec.bs_slot);
-        if (p.min_batch_skip > 0.0) {
-            double* hp = reinterpret_cast<double*>(knn_ws_.pinned_words() + 4);
-            BMX_HIP(hipMemcpyAsync(hp, scal_.p + rec.bs_slot, sizeof(double), hipMemcpyDeviceToHost, stream_));
-            wait();
-            const double h = *hp;
-            if (h < p.min_batch_skip) {
-                do_correct = false;
-                rec.skipped = true;
-            }
+    }
+    double* mag = rec.bs_slot >= 0 ? scal_.p + rec.bs_slot : nullptr;
+    if (!average_correction(stream_, red_ws_, left.data.p, lrows, right.data.p, rrows, d_, second_u_.p, mo.U, partR_.p, cntR_.p,
+                            mo.k1, averaged, true, overall, msq, mag)) {
+        if (rec.batch_size_na) {
+            col_reduce(stream_, red_ws_, averaged, nullptr, 0, mo.U, d_, 0, nullptr, 1.0 / (double)mo.U, overall);
+        } else {
+            col_reduce2(stream_, red_ws_, averaged, mo.U, d_, 1.0 / (double)mo.U, overall, msq);
+            batch_magnitude(stream_, overall, msq, d_, mag);
+        }
+    }
+
+    bool do_correct = true;
+    if (!rec.batch_size_na && p.min_batch_skip > 0.0) {
+        // the host only looks at the magnitude here when a merge can actually be skipped (min.batch.skip > 0), otherwise
+        // with everything else at the end of the run
+        double* hp = reinterpret_cast<double*>(knn_ws_.pinned_words() + 4);
+        BMX_HIP(hipMemcpyAsync(hp, scal_.p + rec.bs_slot, sizeof(double), hipMemcpyDeviceToHost, stream_));
+        wait();
+        const double h = *hp;
+        if (h < p.min_batch_skip) {
+            do_correct = false;
+            rec.skipped = true;
         }
     }
 
     if (do_correct) {
         // R/fastMNN.R:496-501: centre both sides along the batch vector; the "new" variances come out of the same pass
-        row_pass(left, {vid}, true, mu_l);
-        row_pass(right, {vid}, true, mu_r);
+        centre_both(left, right, vid, mu_l, mu_r);
         rec.new_slot = left.stat_slot;
         rec.new_slot.insert(rec.new_slot.end(), right.stat_slot.begin(), right.stat_slot.end());
 
-        // R/fastMNN.R:505-507: re-average on the centred data, then the tricube-smoothed correction of the right batch
-        average_correction(stream_, left.data.p, lrows, right.data.p, rrows, d_, second_u_.p, mo.U, partR_.p,
-                           cntR_.p, mo.k1, averaged);
+        // R/fastMNN.R:505-507: re-average on the centred data, then the tricube-smoothed correction of the right batch;
+        // the rows of the MNN-involved right cells (the reference list of the tricube search) are written on the way
+        int32_t* srows = second_rows_.reserve(mo.U);
+        if (!average_correction(stream_, red_ws_, left.data.p, lrows, right.data.p, rrows, d_, second_u_.p, mo.U, partR_.p,
+                                cntR_.p, mo.k1, averaged, false, nullptr, nullptr, nullptr, srows)) {
+            hipLaunchKernelGGL(gather_rows_i32, dim3(cdiv(mo.U, 256)), dim3(256), 0, stream_, second_u_.p, mo.U, rrows, srows);
+            BMX_LAUNCH_CHECK();
+        }
         const int k_tc = choose_k(p.k, p.prop_k, right.n);  // unrestricted size of the right batch
         const int safe_k = std::min(k_tc, mo.U);
-        int32_t* srows = second_rows_.reserve(mo.U);
-        hipLaunchKernelGGL(gather_rows_i32, dim3(cdiv(mo.U, 256)), dim3(256), 0, stream_, second_u_.p, mo.U, rrows,
-                           srows);
-        BMX_LAUNCH_CHECK();
         const int64_t per = bmx_shard_rows_per_rank(right.n, world_) * (int64_t)world_;
         int32_t* idxT = idxT_.reserve((size_t)per * safe_k);
         double* distT = distT_.reserve((size_t)per * safe_k);

@@ -865,7 +865,7 @@ void search_tiers(hipStream_t stream, KnnWorkspace& ws, const Tier* tiers, int n
         int32_t* xi = ws.xi.reserve((size_t)KnnWorkspace::OPT_CAP * XF_CAP);
         const size_t lds = (size_t)XF_TILE * (d + 1) * sizeof(double);
         ensure_dynamic_lds(reinterpret_cast<const void*>(&knn_exact_filter), lds);
-        hipLaunchKernelGGL(knn_exact_filter, dim3(std::min(cdiv(nr, XF_TILE), 2048)), dim3(256), lds, stream, X, ref_rows, nr, Qs,
+        hipLaunchKernelGGL(knn_exact_filter, dim3(std::min(cdiv(nr, XF_TILE), 16384)), dim3(256), lds, stream, X, ref_rows, nr, Qs,
                            qrs, d, flagged, bound, 0, KnnWorkspace::OPT_CAP, xcnt, xd, xi);
         BMX_LAUNCH_CHECK();
         hipLaunchKernelGGL(knn_exact_pick, dim3(KnnWorkspace::OPT_CAP / 4), dim3(256), 0, stream, flagged, 0,
