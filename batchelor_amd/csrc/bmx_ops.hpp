@@ -111,7 +111,9 @@ void sum_vector(hipStream_t stream, const double* in, int d, double scale, doubl
 bool average_correction(hipStream_t stream, ReduceWorkspace& ws, const double* L, const int32_t* lrows, const double* R,
                         const int32_t* rrows, int d, const int32_t* second_u, int U, const int32_t* partR, const int32_t* cntR,
                         int k1, double* averaged, bool with_sums = false, double* overall = nullptr, double* msq = nullptr,
-                        double* magnitude = nullptr, int32_t* srows = nullptr);
+                        double* magnitude = nullptr, int32_t* srows = nullptr, const int32_t* dup_next = nullptr);
+// (dup_next, nullable: right cells named by several positions of the restrict list -- position r's cell continues at
+// dup_next[r], -1 ends the chain; second_u then holds first positions only and a cell's pairs are those of its whole chain)
 
 // .compute_tricube_average + add (R/utils_tricube.R:1-27, R/fastMNN.R:606-607) in place on X [n][d].
 // idx [n][k] positions into `averaged` rows, dist [n][k] ascending Euclidean distances.

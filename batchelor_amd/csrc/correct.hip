@@ -130,20 +130,26 @@ __global__ void sum_vector_kernel(const double* __restrict__ in, int d, double s
 __global__ __launch_bounds__(256) void average_correction_kernel(
     const double* __restrict__ L, const int32_t* __restrict__ lrows, const double* __restrict__ R,
     const int32_t* __restrict__ rrows, int d, const int32_t* __restrict__ second_u, int U,
-    const int32_t* __restrict__ partR, const int32_t* __restrict__ cntR, int k1, double* __restrict__ averaged) {
+    const int32_t* __restrict__ partR, const int32_t* __restrict__ cntR, int k1, double* __restrict__ averaged,
+    const int32_t* __restrict__ dup_next) {
     const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (u >= U) return;
     const int r = second_u[u];
-    const int m = cntR[r];
     const double* rv = R + (int64_t)(rrows ? rrows[r] : r) * d;
-    const int32_t* part = partR + (int64_t)r * k1;
     for (int c = lane; c < d; c += 64) {
         const double rc = rv[c];
         double s = 0.0;
-        for (int p = 0; p < m; ++p) {
-            const int l = part[p];
-            s += L[(int64_t)(lrows ? lrows[l] : l) * d + c] - rc;
+        int m = 0;
+        // (dup_next: the right cell is named by several positions of the restrict list -- its pairs are those of all of them)
+        for (int q = r; q >= 0; q = dup_next ? dup_next[q] : -1) {
+            const int mq = cntR[q];
+            const int32_t* part = partR + (int64_t)q * k1;
+            for (int p = 0; p < mq; ++p) {
+                const int l = part[p];
+                s += L[(int64_t)(lrows ? lrows[l] : l) * d + c] - rc;
+            }
+            m += mq;
         }
         averaged[(int64_t)u * d + c] = s / (double)m;
     }
@@ -699,9 +705,9 @@ void sum_vector(hipStream_t stream, const double* in, int d, double scale, doubl
 bool average_correction(hipStream_t stream, ReduceWorkspace& ws, const double* L, const int32_t* lrows, const double* R,
                         const int32_t* rrows, int d, const int32_t* second_u, int U, const int32_t* partR, const int32_t* cntR,
                         int k1, double* averaged, bool with_sums, double* overall, double* msq, double* magnitude,
-                        int32_t* srows) {
+                        int32_t* srows, const int32_t* dup_next) {
     if (U <= 0) return false;
-    if ((d & 1) == 0 && d <= 64 && k1 <= 32) {
+    if ((d & 1) == 0 && d <= 64 && k1 <= 32 && !dup_next) {
         const int grid = std::min(cdiv(U, 8), 1024);
         double* partial = with_sums ? ws.partial.reserve((size_t)grid * 2 * d) : nullptr;
         hipLaunchKernelGGL(average_correction_half, dim3(grid), dim3(256), 0, stream, L, lrows, R, rrows, d, second_u, U, partR,
@@ -715,7 +721,7 @@ bool average_correction(hipStream_t stream, ReduceWorkspace& ws, const double* L
         return true;
     }
     hipLaunchKernelGGL(average_correction_kernel, dim3(cdiv(U, 4)), dim3(256), 0, stream, L, lrows, R, rrows, d, second_u, U,
-                       partR, cntR, k1, averaged);
+                       partR, cntR, k1, averaged, dup_next);
     BMX_LAUNCH_CHECK();
     return false;  // (the caller takes the column sums / the row list in passes of their own)
 }

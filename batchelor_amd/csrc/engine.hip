@@ -45,6 +45,34 @@ __global__ void iota_offset(int32_t* __restrict__ out, int n, int off) {
     if (i < n) out[i] = off + i;
 }
 
+// dup_next / dup_head of a merged node's restrict list = those of its children, the right child's positions shifted
+__global__ void combine_dup_chains(const int32_t* __restrict__ lnext, const int32_t* __restrict__ lhead, int nl,
+                                   const int32_t* __restrict__ rnext, const int32_t* __restrict__ rhead, int nr,
+                                   int32_t* __restrict__ next, int32_t* __restrict__ head) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nl + nr) return;
+    if (i < nl) {
+        next[i] = lnext ? lnext[i] : -1;
+        head[i] = lhead ? lhead[i] : 1;
+    } else {
+        const int32_t t = rnext ? rnext[i - nl] : -1;
+        next[i] = t >= 0 ? t + nl : -1;
+        head[i] = rhead ? rhead[i - nl] : 1;
+    }
+}
+
+// right cells named more than once: the pairs of all positions of a cell belong to the cell (rowsum groups by cell,
+// R/fastMNN.R:571-579): fold[r] = the cell's pairs at its first position, 0 at the others
+__global__ void fold_dup_counts(const int32_t* __restrict__ cnt, const int32_t* __restrict__ next, const int32_t* __restrict__ head,
+                                int n, int32_t* __restrict__ fold) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    int t = 0;
+    if (head[r])
+        for (int p = r; p >= 0; p = next[p]) t += cnt[p];
+    fold[r] = t;
+}
+
 __global__ void add_offset_copy(const int32_t* __restrict__ in, int n, int off, int32_t* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = in[i] + off;
@@ -236,6 +264,9 @@ void Engine::upload(int nbatches, int d, const double* const* data, const int32_
     inputs_cm_.resize(nbatches);
     inputs_restrict_.clear();
     inputs_restrict_.resize(nbatches);
+    inputs_dup_.clear();
+    inputs_dup_.resize(nbatches);
+    has_dups_.assign(nbatches, 0);
     n_restrict_.assign(nbatches, -1);
     lazy_ = lazy;
     host_data_.assign(data, data + nbatches);
@@ -255,20 +286,30 @@ void Engine::upload(int nbatches, int d, const double* const* data, const int32_
         if (has) {
             const int m = n_restrict[b];
             if (m == 0) throw Error(BMX_ERR_ARG, "no cells remaining in a batch after restriction");  // R/checkInputs.R:116
-            // an R subsetting vector in the caller's order (R/checkInputs.R:96-120 keeps it as given).  Repeated cells
-            // are refused: the reference would search them as separate points but average them as one cell.
+            // an R subsetting vector in the caller's order (R/checkInputs.R:96-120 keeps it as given); a cell may be named
+            // more than once (see Node::restrict_dups)
             std::vector<int32_t> z(m);
-            std::vector<char> seen((size_t)nrows[b], 0);
+            std::vector<int32_t> last((size_t)nrows[b], -1), chain((size_t)2 * m, -1);
+            bool dups = false;
             for (int i = 0; i < m; ++i) {
                 const int32_t v = restrict_idx[b][i];
                 if (v < 1 || v > nrows[b]) throw Error(BMX_ERR_SUBSET, "subset indices out of range");
-                if (seen[v - 1]) throw Error(BMX_ERR_ARG, "'restrict' names a cell more than once");
-                seen[v - 1] = 1;
                 z[i] = v - 1;
+                chain[(size_t)m + i] = last[v - 1] < 0 ? 1 : 0;  // head
+                if (last[v - 1] >= 0) {
+                    chain[last[v - 1]] = i;  // next
+                    dups = true;
+                }
+                last[v - 1] = i;
             }
             int32_t* rp = inputs_restrict_[b].reserve(m);
             BMX_HIP(hipMemcpyAsync(rp, z.data(), (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
-            BMX_HIP(hipStreamSynchronize(stream_));  // z goes out of scope
+            if (dups) {
+                int32_t* dp = inputs_dup_[b].reserve((size_t)2 * m);
+                BMX_HIP(hipMemcpyAsync(dp, chain.data(), (size_t)2 * m * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+            }
+            has_dups_[b] = dups ? 1 : 0;
+            BMX_HIP(hipStreamSynchronize(stream_));  // z, chain go out of scope
             n_restrict_[b] = m;
         }
     }
@@ -406,7 +447,15 @@ Engine::MnnOut Engine::find_mnn(const Node& left, const Node& right, int k, doub
     int32_t* offR = offR_.reserve((size_t)nR + 1);
     int32_t* second_u = second_u_.reserve(nR);
     mutual_counts(stream_, idxLR, nsel, o.k2, idxRL, nR, o.k1, cntL, partR, cntR, lsel, offSel, maskL, /* mask_is_clear */ true);
-    pair_scans(stream_, scan_ws_, maskL, cntL, nsel, o.k2, offL, st + 3, cntR, nR, offR, second_u, st + 4);
+    const int32_t* cntR_cells = cntR;
+    if (right.restrict_dups) {
+        int32_t* fold = cntFold_.reserve(nR);
+        hipLaunchKernelGGL(fold_dup_counts, dim3(cdiv(nR, 256)), dim3(256), 0, stream_, (const int32_t*)cntR,
+                           (const int32_t*)right.dup_next.p, (const int32_t*)right.dup_head.p, nR, fold);
+        BMX_LAUNCH_CHECK();
+        cntR_cells = fold;
+    }
+    pair_scans(stream_, scan_ws_, maskL, cntL, nsel, o.k2, offL, st + 3, cntR_cells, nR, offR, second_u, st + 4);
     const int32_t* pin = read_state();
     o.P = pin[3];
     o.U = pin[4];
@@ -548,6 +597,12 @@ std::unique_ptr<Node> Engine::clone_node(const Node& src) {
         int32_t* r = n->restrict_rows.reserve(src.n_restrict);
         BMX_HIP(hipMemcpyAsync(r, src.restrict_rows.p, (size_t)src.n_restrict * sizeof(int32_t),
                                hipMemcpyDeviceToDevice, stream_));
+        if (src.restrict_dups) {
+            n->restrict_dups = true;
+            const size_t m = (size_t)src.n_restrict;
+            BMX_HIP(hipMemcpyAsync(n->dup_next.reserve(m), src.dup_next.p, m * sizeof(int32_t), hipMemcpyDeviceToDevice, stream_));
+            BMX_HIP(hipMemcpyAsync(n->dup_head.reserve(m), src.dup_head.p, m * sizeof(int32_t), hipMemcpyDeviceToDevice, stream_));
+        }
     }
     return n;
 }
@@ -637,8 +692,9 @@ void Engine::merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p,
         rec.bs_slot = n_slots_++;
     }
     double* mag = rec.bs_slot >= 0 ? scal_.p + rec.bs_slot : nullptr;
+    const int32_t* rnext = right.restrict_dups ? right.dup_next.p : nullptr;
     if (!average_correction(stream_, red_ws_, left.data.p, lrows, right.data.p, rrows, d_, second_u_.p, mo.U, partR_.p, cntR_.p,
-                            mo.k1, averaged, true, overall, msq, mag)) {
+                            mo.k1, averaged, true, overall, msq, mag, nullptr, rnext)) {
         if (rec.batch_size_na) {
             col_reduce(stream_, red_ws_, averaged, nullptr, 0, mo.U, d_, 0, nullptr, 1.0 / (double)mo.U, overall);
         } else {
@@ -671,7 +727,7 @@ void Engine::merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p,
         // the rows of the MNN-involved right cells (the reference list of the tricube search) are written on the way
         int32_t* srows = second_rows_.reserve(mo.U);
         if (!average_correction(stream_, red_ws_, left.data.p, lrows, right.data.p, rrows, d_, second_u_.p, mo.U, partR_.p,
-                                cntR_.p, mo.k1, averaged, false, nullptr, nullptr, nullptr, srows)) {
+                                cntR_.p, mo.k1, averaged, false, nullptr, nullptr, nullptr, srows, rnext)) {
             hipLaunchKernelGGL(gather_rows_i32, dim3(cdiv(mo.U, 256)), dim3(256), 0, stream_, second_u_.p, mo.U, rrows, srows);
             BMX_LAUNCH_CHECK();
         }
@@ -766,6 +822,16 @@ void Engine::merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p,
         else
             hipLaunchKernelGGL(iota_offset, dim3(cdiv(nRs, 256)), dim3(256), 0, stream_, mr + nLs, nRs, left.n);
         BMX_LAUNCH_CHECK();
+        if (left.restrict_dups || right.restrict_dups) {  // the chains of repeated cells: positions of the right part shift by nLs
+            m.restrict_dups = true;
+            int32_t* nx = m.dup_next.reserve(m.n_restrict);
+            int32_t* hd = m.dup_head.reserve(m.n_restrict);
+            hipLaunchKernelGGL(combine_dup_chains, dim3(cdiv(m.n_restrict, 256)), dim3(256), 0, stream_,
+                               left.restrict_dups ? left.dup_next.p : nullptr, left.restrict_dups ? left.dup_head.p : nullptr, nLs,
+                               right.restrict_dups ? right.dup_next.p : nullptr, right.restrict_dups ? right.dup_head.p : nullptr,
+                               nRs, nx, hd);
+            BMX_LAUNCH_CHECK();
+        }
     }
     // the copies above read left / right data: the caller releases those nodes into this engine's block cache, whose
     // next user is ordered behind the copies by the stream
@@ -846,6 +912,14 @@ void Engine::run_once(const bmx_params_t& p, const int32_t* tree, int tree_len) 
             int32_t* r = n->restrict_rows.reserve(n->n_restrict);
             BMX_HIP(hipMemcpyAsync(r, inputs_restrict_[b].p, (size_t)n->n_restrict * sizeof(int32_t),
                                    hipMemcpyDeviceToDevice, stream_));
+            if (has_dups_[b]) {
+                n->restrict_dups = true;
+                const size_t m = (size_t)n->n_restrict;
+                BMX_HIP(hipMemcpyAsync(n->dup_next.reserve(m), inputs_dup_[b].p, m * sizeof(int32_t), hipMemcpyDeviceToDevice,
+                                       stream_));
+                BMX_HIP(hipMemcpyAsync(n->dup_head.reserve(m), inputs_dup_[b].p + m, m * sizeof(int32_t),
+                                       hipMemcpyDeviceToDevice, stream_));
+            }
         }
         return n;
     };

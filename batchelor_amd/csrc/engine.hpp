@@ -19,8 +19,13 @@ struct Node {
     DevBuf<double> data;     // [n][d] row-major
     int n = 0;
     bool has_restrict = false;
-    DevBuf<int32_t> restrict_rows;  // 0-based, in the caller's order (any order, no cell twice)
+    DevBuf<int32_t> restrict_rows;  // 0-based, in the caller's order (any R subsetting vector: any order, cells may repeat)
     int n_restrict = 0;
+    // a cell named more than once is that many POINTS to the searches and to the centring mean (R/MNN_tree.R:113-127,
+    // R/fastMNN.R:633-637) but ONE cell to .average_correction's rowsum (R/fastMNN.R:571-579): positions of the same cell
+    // are chained -- dup_next[r] = the next position of the cell at position r (-1: none), dup_head[r] = 1 at its first
+    bool restrict_dups = false;
+    DevBuf<int32_t> dup_next, dup_head;
     std::vector<Segment> origin;  // MNN_treenode@origin as run lengths
     std::vector<int> stat_slot;   // per segment: slot of its current column means / total variance, -1 = stale
     std::vector<int> extras;      // ids of batch vectors in the engine's pool (MNN_treenode@extras)
@@ -116,7 +121,7 @@ class Engine {
     ScanWorkspace scan_ws_;
     ReduceWorkspace red_ws_;
     DevBuf<int32_t> idxLR_, idxRL_, cntL_, offL_, partR_, cntR_, flagR_, offR_, second_u_, second_rows_, idxT_;
-    DevBuf<int32_t> stampL_, offSel_, lsel_, qsel_;
+    DevBuf<int32_t> stampL_, offSel_, lsel_, qsel_, cntFold_;
     int state_seq_ = 0;  // sequence number of the last publish_state (read_state)
     int stamp_gen_ = 0;  // number of the last search whose listed rows were stamped (stampL_ is never cleared)
     DevBuf<unsigned long long> maskL_;
@@ -186,7 +191,9 @@ class Engine {
     std::vector<int> nrows_;
     std::vector<DevBuf<double>> inputs_cm_;        // resident inputs, column-major as uploaded
     std::vector<DevBuf<int32_t>> inputs_restrict_; // 0-based
+    std::vector<DevBuf<int32_t>> inputs_dup_;      // [2 n_restrict]: dup_next, dup_head of a batch whose restrict repeats cells
     std::vector<int> n_restrict_;                  // -1 = NULL
+    std::vector<char> has_dups_;
 
     // results of the last run
     std::unique_ptr<Node> root_;

@@ -65,8 +65,7 @@ def test_bmx_fast_mnn_one_shot_as_the_shim_calls_it(oracle):
 
 def test_restrict_is_an_r_subsetting_vector_in_any_order(oracle):
     # checkRestrictions() turns `restrict` into integer positions in the caller's order (R/checkInputs.R:96-120,
-    # R/utils_subset.R): an unsorted vector is legal and changes the order of the pairs.  A cell named twice is
-    # refused here (the reference would search it as two points and average it as one).
+    # R/utils_subset.R): an unsorted vector is legal and changes the order of the pairs.
     import batchelor_amd as bx
     from tests.test_gpu_engine import assert_same_result
     rng = np.random.default_rng(77)
@@ -75,9 +74,34 @@ def test_restrict_is_an_r_subsetting_vector_in_any_order(oracle):
     out = bx.reducedMNN(*B, restrict=keep)
     ref = oracle.reduced_mnn(*B, restrict=keep)
     assert_same_result(out, ref)
-    keep[2] = np.concatenate([keep[2], keep[2][:2]])
-    with pytest.raises(RuntimeError, match="more than once"):
-        bx.reducedMNN(*B, restrict=keep)
+
+
+@pytest.mark.parametrize("where", ["left", "right", "both"])
+def test_restrict_may_name_a_cell_more_than_once(oracle, where):
+    """Any R subsetting vector is a legal `restrict` (R/checkInputs.R:96-120), so a cell may be named twice: the searches and
+    the centring mean then see it as two points (R/MNN_tree.R:113-127, R/fastMNN.R:633-637), its pairs come out once per
+    point, and .average_correction's rowsum (R/fastMNN.R:571-579) still groups them by CELL.  Three batches, so that the
+    merged node of the first merge carries the repeated positions into the second."""
+    import batchelor_amd as bx
+    from tests.test_gpu_engine import assert_same_result
+    rng = np.random.default_rng(78)
+    B = synth_batches(9, [500, 400, 450], 15)
+    base = [rng.permutation(500)[:300] + 1, rng.permutation(400)[:250] + 1, rng.permutation(450)[:200] + 1]
+    keep = [b.copy() for b in base]
+    rep = lambda r, n: rng.permutation(np.concatenate([r, r[:n], r[:n // 3]]))  # some cells twice, some three times
+    if where in ("left", "both"):
+        keep[0] = rep(keep[0], 40)
+    if where in ("right", "both"):
+        keep[1] = rep(keep[1], 60)
+        keep[2] = rep(keep[2], 30)
+    out = bx.reducedMNN(*B, restrict=keep)
+    ref = oracle.reduced_mnn(*B, restrict=keep)
+    assert_same_result(out, ref)
+    # the same through the tree form, where a node with repeats also turns up as the RIGHT child
+    tree = [[3, 2], 1]
+    out = bx.reducedMNN(*B, restrict=keep, merge_order=tree)
+    ref = oracle.reduced_mnn(*B, restrict=keep, merge_order=tree)
+    assert_same_result(out, ref)
 
 
 def test_exact_path_with_more_queries_than_grid_y(oracle):
