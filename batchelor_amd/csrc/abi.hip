@@ -1,6 +1,7 @@
 // extern "C" boundary of libbatchelor_mi355x.so (declared in include/batchelor_mi355x.h).
 // Nothing throws across it: exceptions become return codes + a thread-local message.
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cstddef>
 #include <cmath>
@@ -691,9 +692,17 @@ int32_t bmx_fast_mnn(int32_t nbatches, int32_t d, const double* const* data, con
         h->impl->knn_ws_.force_exact = g_force_exact;
         // the caller's matrices stay valid for the whole call: their upload is pulled by the run itself, batch by batch
         // (the first two ahead of merge 1, the others while the GPU is busy searching)
+        const auto t0 = std::chrono::steady_clock::now();
         h->impl->upload(nbatches, d, data, nrows, restrict_idx, n_restrict, /* lazy */ true);
+        const auto t1 = std::chrono::steady_clock::now();
         h->impl->run(p, tree, tree_len);
+        const auto t2 = std::chrono::steady_clock::now();
         h->impl->download(corrected, batch, merge_left, merge_right, batch_size, skipped, lost_var);
+        if (bmx::debug_timings()) {
+            const auto t3 = std::chrono::steady_clock::now();
+            auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+            fprintf(stderr, "[bmx] one-shot: create+upload %.2f ms, run %.2f ms, download %.2f ms\n", ms(t0, t1), ms(t1, t2), ms(t2, t3));
+        }
         if (out_engine) *out_engine = h.release();
     });
 }

@@ -57,7 +57,8 @@ struct DevKnobs {
     int exchange_always = 0;  // a single rank goes through its exchange transport too (an all-gather of one)
 };
 DevKnobs& dev_knobs();
-bool debug_prints();  // BMX_DEBUG set in the environment (read once)
+bool debug_prints();   // BMX_DEBUG=1 in the environment (read once)
+bool debug_timings();  // BMX_DEBUG=t or 1
 
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }

@@ -147,6 +147,9 @@ Engine::~Engine() {
     }
     if (scal_pin_ && scal_pin_bytes_ > KnnWorkspace::kPinnedSmall) (void)hipHostFree(scal_pin_);
     else KnnWorkspace::pinned_small_give(scal_pin_);
+    if (stream_) (void)hipStreamSynchronize(stream_);  // (a pair-list copy may still be on its way into the pinned block)
+    if (pairs_ev_) (void)hipEventDestroy(pairs_ev_);
+    PinnedBlocks::give(PinnedBlocks::Blk{pairs_pin_, pairs_pin_bytes_});
     if (comm_ && rccl::api().CommDestroy) {
         if (stream_) (void)hipStreamSynchronize(stream_);
         (void)rccl::api().CommDestroy(comm_);
@@ -862,6 +865,7 @@ void Engine::run_once(const bmx_params_t& p, const int32_t* tree, int tree_len) 
     queued_work_s_ = 0.0;
     const int nmerges = B_ - 1;
     root_.reset();  // a run that fails half-way leaves nothing to download
+    pairs_pinned_ = false;
     merges_.clear();
     merges_.resize(nmerges);
     n_extras_ = 0;
@@ -1077,6 +1081,7 @@ void Engine::run_once(const bmx_params_t& p, const int32_t* tree, int tree_len) 
         lazy_ = false;
     }
     fallbacks_ = knn_ws_.exact_total;
+    stage_pairs();
 }
 
 void Engine::download(double* corrected, int32_t* batch, int32_t* merge_left, int32_t* merge_right,
@@ -1147,20 +1152,24 @@ int64_t Engine::pairs_count(int merge) const {
     return merges_[merge].npairs;
 }
 
-void Engine::pairs_into(int merge, int32_t* left, int32_t* right) {
-    CacheScope cache_scope(&cache_);
-    BMX_HIP(hipSetDevice(device_));
-    const int64_t P = pairs_count(merge);
-    if (P == 0) return;
-    const MergeRecord& rec = merges_[merge];
-    // shift to the node's place in the final merged order, then to the input batch order: a short table per side,
-    // applied on the device
+void Engine::stage_pairs() {
+    // shift every merge's pairs to their nodes' places in the final merged order, then to the input batch order
+    // (R/fastMNN.R:533-547): a short table per side, applied on the device; all merges into one block
+    pairs_pinned_ = false;
+    const int nmerges = (int)merges_.size();
+    pairs_off_.assign(nmerges + 1, 0);
+    for (int m = 0; m < nmerges; ++m) pairs_off_[m + 1] = pairs_off_[m] + 2 * merges_[m].npairs;
+    const int64_t total = pairs_off_[nmerges];
+    if (total == 0) return;
     std::vector<int64_t> in_start(B_ + 1, 0);
     for (int b = 0; b < B_; ++b) in_start[b + 1] = in_start[b] + nrows_[b];
-    const int nl = (int)rec.left_set.size(), nr = (int)rec.right_set.size();
-    std::vector<int32_t> tab((size_t)2 * (nl + nr) + 2);
-    auto fill = [&](const std::vector<int>& set, int32_t* t) {
+    std::vector<size_t> tab_off(nmerges, 0);
+    pairs_tab_host_.clear();
+    auto fill = [&](const std::vector<int>& set) {
         const int ns = (int)set.size();
+        const size_t base = pairs_tab_host_.size();
+        pairs_tab_host_.resize(base + 2 * ns + 1);
+        int32_t* t = pairs_tab_host_.data() + base;
         int64_t o = 0;
         for (int i = 0; i < ns; ++i) {
             t[i] = (int32_t)o;
@@ -1169,19 +1178,54 @@ void Engine::pairs_into(int merge, int32_t* left, int32_t* right) {
         }
         t[ns] = (int32_t)o;
     };
-    fill(rec.left_set, tab.data());
-    fill(rec.right_set, tab.data() + 2 * nl + 1);
-    DevBuf<int32_t> tmp, dtab;
-    int32_t* t = tmp.reserve((size_t)2 * P);
-    int32_t* dt = dtab.reserve(tab.size());
-    BMX_HIP(hipMemcpyAsync(dt, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
-    hipLaunchKernelGGL(remap_pairs_tab, dim3((unsigned)cdiv(P, 256)), dim3(256), 0, stream_, (const int32_t*)rec.first.p, P,
-                       (const int32_t*)dt, nl, t);
-    hipLaunchKernelGGL(remap_pairs_tab, dim3((unsigned)cdiv(P, 256)), dim3(256), 0, stream_, (const int32_t*)rec.second.p, P,
-                       (const int32_t*)(dt + 2 * nl + 1), nr, t + P);
+    for (int m = 0; m < nmerges; ++m) {
+        tab_off[m] = pairs_tab_host_.size();
+        fill(merges_[m].left_set);
+        fill(merges_[m].right_set);
+    }
+    int32_t* dt = pairs_tab_.reserve(pairs_tab_host_.size());
+    BMX_HIP(hipMemcpyAsync(dt, pairs_tab_host_.data(), pairs_tab_host_.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+    int32_t* all = pairs_all_.reserve((size_t)total);
+    for (int m = 0; m < nmerges; ++m) {
+        const MergeRecord& rec = merges_[m];
+        const int64_t P = rec.npairs;
+        if (P == 0) continue;
+        const int nl = (int)rec.left_set.size(), nr = (int)rec.right_set.size();
+        hipLaunchKernelGGL(remap_pairs_tab, dim3((unsigned)cdiv(P, 256)), dim3(256), 0, stream_, (const int32_t*)rec.first.p, P,
+                           (const int32_t*)(dt + tab_off[m]), nl, all + pairs_off_[m]);
+        hipLaunchKernelGGL(remap_pairs_tab, dim3((unsigned)cdiv(P, 256)), dim3(256), 0, stream_, (const int32_t*)rec.second.p, P,
+                           (const int32_t*)(dt + tab_off[m] + 2 * nl + 1), nr, all + pairs_off_[m] + P);
+    }
     BMX_LAUNCH_CHECK();
-    download_pageable(left, t, (size_t)P * sizeof(int32_t), stream_);   // (returns after the copy: tab may go)
-    download_pageable(right, t + P, (size_t)P * sizeof(int32_t), stream_);
+    const size_t bytes = (size_t)total * sizeof(int32_t);
+    if (bytes <= ((size_t)64 << 20)) {  // (beyond that the lists stay on the device and go out through the staging ring)
+        if (bytes > pairs_pin_bytes_) {
+            PinnedBlocks::give(PinnedBlocks::Blk{pairs_pin_, pairs_pin_bytes_});
+            const PinnedBlocks::Blk b = PinnedBlocks::take(bytes);
+            pairs_pin_ = b.p;
+            pairs_pin_bytes_ = b.bytes;
+        }
+        if (!pairs_ev_) BMX_HIP(hipEventCreateWithFlags(&pairs_ev_, hipEventDisableTiming));
+        BMX_HIP(hipMemcpyAsync(pairs_pin_, all, bytes, hipMemcpyDeviceToHost, stream_));
+        BMX_HIP(hipEventRecord(pairs_ev_, stream_));
+        pairs_pinned_ = true;
+    }
+}
+
+void Engine::pairs_into(int merge, int32_t* left, int32_t* right) {
+    CacheScope cache_scope(&cache_);
+    BMX_HIP(hipSetDevice(device_));
+    const int64_t P = pairs_count(merge);
+    if (P == 0) return;
+    if (pairs_pinned_) {  // the whole run's lists were sent to pinned memory when the run ended: a host copy
+        guarded_event_sync(pairs_ev_);
+        const int32_t* src = static_cast<const int32_t*>(pairs_pin_) + pairs_off_[merge];
+        host_parallel_memcpy(left, src, (size_t)P * sizeof(int32_t));
+        host_parallel_memcpy(right, src + P, (size_t)P * sizeof(int32_t));
+        return;
+    }
+    download_pageable(left, pairs_all_.p + pairs_off_[merge], (size_t)P * sizeof(int32_t), stream_);
+    download_pageable(right, pairs_all_.p + pairs_off_[merge] + P, (size_t)P * sizeof(int32_t), stream_);
 }
 
 void Engine::pairs(int merge, int32_t** left, int32_t** right, int64_t* npairs) {

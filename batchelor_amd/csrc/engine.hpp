@@ -160,6 +160,16 @@ class Engine {
     std::vector<int> need_order_;
     size_t need_pos_ = 0;
     bool lazy_ = false;
+    // Pair lists of the last run in OUTPUT-row numbering, all merges in one block (merge m: left ids at pairs_off_[m],
+    // right ids behind them), copied to pinned host memory at the end of the run: pairs_into is then a host copy
+    void stage_pairs();
+    DevBuf<int32_t> pairs_all_, pairs_tab_;
+    std::vector<int64_t> pairs_off_;
+    std::vector<int32_t> pairs_tab_host_;
+    void* pairs_pin_ = nullptr;
+    size_t pairs_pin_bytes_ = 0;
+    bool pairs_pinned_ = false;  // the last run's lists are (on their way) in pairs_pin_
+    hipEvent_t pairs_ev_ = nullptr;
     void check_alive() const;
     void mark_dead();
     double wd_base_s_ = 60.0;

@@ -100,7 +100,7 @@ class HostPool {
 };
 
 inline void host_parallel_memcpy(void* dst, const void* src, size_t bytes) {
-    constexpr size_t kPiece = (size_t)1 << 20;
+    constexpr size_t kPiece = (size_t)256 << 10;
     if (bytes <= 2 * kPiece) {
         std::memcpy(dst, src, bytes);
         return;
@@ -131,7 +131,6 @@ class PinnedRing {
         return *r;
     }
     static PinnedRing& upload_ring() { return for_device(0); }
-    static PinnedRing& download_ring() { return for_device(1); }
     std::mutex mu;
     void* buf[2] = {nullptr, nullptr};
     hipEvent_t ev[2] = {nullptr, nullptr};
@@ -143,6 +142,57 @@ class PinnedRing {
             BMX_HIP(hipHostMalloc(&buf[i], kChunk, hipHostMallocDefault));
             BMX_HIP(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
         }
+    }
+};
+
+// Pinned blocks of a few MB (the pair lists of a run on their way to the host), kept in a small process-wide free list:
+// hipHostMalloc / hipHostFree cost milliseconds, and the .Call boundary makes an engine per call.
+struct PinnedBlocks {
+    struct Blk {
+        void* p;
+        size_t bytes;
+    };
+    static std::mutex& mu() {
+        static std::mutex* m = new std::mutex();
+        return *m;
+    }
+    static std::vector<Blk>& pool() {
+        static std::vector<Blk>* v = new std::vector<Blk>();
+        return *v;
+    }
+    static Blk take(size_t bytes) {
+        {
+            std::lock_guard<std::mutex> lk(mu());
+            auto& v = pool();
+            int best = -1;
+            for (int i = 0; i < (int)v.size(); ++i)
+                if (v[i].bytes >= bytes && (best < 0 || v[i].bytes < v[best].bytes)) best = i;
+            if (best >= 0) {
+                const Blk b = v[best];
+                v.erase(v.begin() + best);
+                return b;
+            }
+        }
+        Blk b{nullptr, std::max(bytes + bytes / 4, (size_t)1 << 20)};
+        BMX_HIP(hipHostMalloc(&b.p, b.bytes, hipHostMallocDefault));
+        return b;
+    }
+    static void give(Blk b) {
+        if (!b.p) return;
+        std::lock_guard<std::mutex> lk(mu());
+        auto& v = pool();
+        if (v.size() >= 4) {  // keep the largest few
+            int smallest = 0;
+            for (int i = 1; i < (int)v.size(); ++i)
+                if (v[i].bytes < v[smallest].bytes) smallest = i;
+            if (v[smallest].bytes >= b.bytes) {
+                (void)hipHostFree(b.p);
+                return;
+            }
+            (void)hipHostFree(v[smallest].p);
+            v.erase(v.begin() + smallest);
+        }
+        v.push_back(b);
     }
 };
 
@@ -190,28 +240,73 @@ inline void upload_pageable(void* dev, const void* host, size_t bytes, hipStream
 }
 
 // device -> host (pageable) on `stream`; returns when the caller's memory holds the bytes.  The device-side work the
-// copy depends on must already be queued on `stream`.
-inline void download_pageable(void* host, const void* dev, size_t bytes, hipStream_t stream) {
-    if (bytes == 0) return;
-    PinnedRing& r = PinnedRing::download_ring();
+// copies depend on must already be queued on `stream`.  The pieces (any number, any sizes) go through a ring of FOUR pinned
+// slots of 8 MB: up to three DMAs are in flight while the host threads empty the fourth into the caller's memory (which also
+// spreads the first-touch page faults of a freshly allocated result) -- with two slots of 32 MB the first DMA and the last
+// host copy, 0.6 ms + 1.3 ms, were exposed at either end of every call.
+struct XferPiece {
+    void* host;
+    const void* dev;
+    size_t bytes;
+};
+
+class DownloadRing {
+  public:
+    static constexpr int kSlots = 4;
+    static constexpr size_t kSlot = (size_t)8 << 20;
+    static DownloadRing& for_device() {
+        static std::mutex mu;
+        static std::map<int, DownloadRing*>* rings = new std::map<int, DownloadRing*>();
+        int dev = 0;
+        BMX_HIP(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> lk(mu);
+        DownloadRing*& r = (*rings)[dev];
+        if (!r) r = new DownloadRing();  // never destroyed: no hipHostFree after the runtime is torn down
+        return *r;
+    }
+    std::mutex mu;
+    void* buf[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+    void ensure() {
+        if (buf[0]) return;
+        for (int i = 0; i < kSlots; ++i) {
+            BMX_HIP(hipHostMalloc(&buf[i], kSlot, hipHostMallocDefault));
+            BMX_HIP(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+        }
+    }
+};
+
+inline void download_pieces(const XferPiece* pieces, size_t npieces, hipStream_t stream) {
+    // cut into slot-sized jobs
+    std::vector<XferPiece> jobs;
+    for (size_t i = 0; i < npieces; ++i)
+        for (size_t o = 0; o < pieces[i].bytes; o += DownloadRing::kSlot)
+            jobs.push_back(XferPiece{static_cast<char*>(pieces[i].host) + o, static_cast<const char*>(pieces[i].dev) + o,
+                                     std::min(DownloadRing::kSlot, pieces[i].bytes - o)});
+    if (jobs.empty()) return;
+    DownloadRing& r = DownloadRing::for_device();
     std::lock_guard<std::mutex> lk(r.mu);
     r.ensure();
-    char* dst = static_cast<char*>(host);
-    const char* src = static_cast<const char*>(dev);
-    const size_t nchunks = (bytes + PinnedRing::kChunk - 1) / PinnedRing::kChunk;
+    const size_t n = jobs.size();
     auto issue = [&](size_t i) {
-        const size_t o = i * PinnedRing::kChunk, m = std::min(PinnedRing::kChunk, bytes - o);
-        BMX_HIP(hipMemcpyAsync(r.buf[i & 1], src + o, m, hipMemcpyDeviceToHost, stream));
-        BMX_HIP(hipEventRecord(r.ev[i & 1], stream));
+        const int s = (int)(i % DownloadRing::kSlots);
+        BMX_HIP(hipMemcpyAsync(r.buf[s], jobs[i].dev, jobs[i].bytes, hipMemcpyDeviceToHost, stream));
+        BMX_HIP(hipEventRecord(r.ev[s], stream));
     };
-    issue(0);
-    for (size_t i = 0; i < nchunks; ++i) {
-        guarded_event_sync(r.ev[i & 1]);
-        if (i + 1 < nchunks) issue(i + 1);  // the other buffer fills while this one is copied out
-        const size_t o = i * PinnedRing::kChunk, m = std::min(PinnedRing::kChunk, bytes - o);
-        host_parallel_memcpy(dst + o, r.buf[i & 1], m);
+    const size_t ahead = DownloadRing::kSlots - 1;
+    for (size_t i = 0; i < std::min(ahead, n); ++i) issue(i);
+    for (size_t i = 0; i < n; ++i) {
+        const int s = (int)(i % DownloadRing::kSlots);
+        guarded_event_sync(r.ev[s]);
+        if (i + ahead < n) issue(i + ahead);  // (its slot was emptied in the previous round)
+        host_parallel_memcpy(jobs[i].host, r.buf[s], jobs[i].bytes);
     }
-    r.busy[0] = r.busy[1] = false;
+}
+
+inline void download_pageable(void* host, const void* dev, size_t bytes, hipStream_t stream) {
+    if (bytes == 0) return;
+    const XferPiece p{host, dev, bytes};
+    download_pieces(&p, 1, stream);
 }
 
 }  // namespace bmx

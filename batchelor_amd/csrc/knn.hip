@@ -759,7 +759,12 @@ DevKnobs& dev_knobs() {
     return k;
 }
 
-bool debug_prints() {
+bool debug_prints() {  // BMX_DEBUG=1: the shape decisions of every search (slow: lists are copied back for their counts)
+    static const bool on = std::getenv("BMX_DEBUG") != nullptr && std::getenv("BMX_DEBUG")[0] != 't';
+    return on;
+}
+
+bool debug_timings() {  // BMX_DEBUG=t (or 1): host-side timings of the one-shot call
     static const bool on = std::getenv("BMX_DEBUG") != nullptr;
     return on;
 }
