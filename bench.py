@@ -140,34 +140,42 @@ def cpu_baselines(batches, stats, d, k):
                            f"{100 * st['visited']:.1f}% of the reference visited per query ({rate_a:.3g} pair "
                            f"evaluations/s); extrapolated by pair evaluations to the whole job, "
                            f"{time.perf_counter() - t0:.0f} s of CPU time spent")}
-    # B: BLAS brute force, sized for ~10 s
+    # B: BLAS brute force over worker threads.  One WHOLE block of the job (every right cell against the first batch) when a
+    # short trial says it fits the budget of ~25 s, else as many queries as do
+    flop_per_pair = 2.0 * d
     t0 = time.perf_counter()
-    nq_b = 2048
-    cb.blas_knn(L, R[:nq_b], k)
+    nq_b = min(R.shape[0], 8192)
+    _, _, info_b = cb.blas_knn(L, R[:nq_b], k)
     dt0 = time.perf_counter() - t0
-    nq_b = int(min(R.shape[0], max(2048, 2048 * 8.0 / max(dt0, 1e-3))))
+    nq_b = int(min(R.shape[0], max(8192, 8192 * 25.0 / max(dt0, 1e-3))))
     t0 = time.perf_counter()
     cb.blas_knn(L, R[:nq_b], k)
     dt = time.perf_counter() - t0
     rate_b = nq_b * L.shape[0] / dt
-    out["B"] = {"value": n_cells / (total_pairs / rate_b), "unit": "cells/s", "cores": cores, "kind": "port",
-                "sample": (f"blocked brute force on the host BLAS (numpy, FP64 DGEMM + exact re-evaluation of the kept), "
-                           f"{cores} host threads available: {nq_b} queries x {L.shape[0]} reference cells in {dt:.1f} s "
-                           f"({rate_b:.3g} pair evaluations/s); extrapolated by pair evaluations to the whole job")}
+    whole_b = "one whole block of the job" if nq_b == R.shape[0] else "a sample of the block"
+    out["B"] = {"value": n_cells / (total_pairs / rate_b), "unit": "cells/s", "cores": info_b["workers"], "kind": "port",
+                "gflops": rate_b * flop_per_pair / 1e9,
+                "sample": (f"blocked brute force on the host BLAS ({info_b['blas']}; FP64 DGEMM + argpartition + exact "
+                           f"re-evaluation of the kept), {info_b['workers']} worker threads x {info_b['blas_threads_per_worker']} "
+                           f"BLAS thread(s) of {cores} host threads: {whole_b}, {nq_b} queries x {L.shape[0]} reference cells in "
+                           f"{dt:.1f} s ({rate_b:.3g} pair evaluations/s = {rate_b * flop_per_pair / 1e9:.0f} GFLOP/s); scaled by "
+                           f"pair evaluations to the whole job")}
     # C: the oracle's own OpenMP brute force (FP64, no BLAS), all cores -- round 1's baseline, kept for continuity
     from oracle import fastmnn_oracle as orc
     t0 = time.perf_counter()
     orc.query_knn(L, R[:4096], k, nthreads=cores)
     dt0 = time.perf_counter() - t0
-    nq_c = int(min(R.shape[0], max(4096, 4096 * 8.0 / max(dt0, 1e-3))))
+    nq_c = int(min(R.shape[0], max(4096, 4096 * 15.0 / max(dt0, 1e-3))))
     t0 = time.perf_counter()
     orc.query_knn(L, R[:nq_c], k, nthreads=cores)
     dt = time.perf_counter() - t0
     rate_c = nq_c * L.shape[0] / dt
+    whole_c = "one whole block of the job" if nq_c == R.shape[0] else "a sample of the block"
     out["C"] = {"value": n_cells / (total_pairs / rate_c), "unit": "cells/s", "cores": cores, "kind": "port",
-                "sample": (f"oracle exact FP64 brute force (oracle/mnn_oracle.c, OpenMP, {cores} threads): {nq_c} queries x "
-                           f"{L.shape[0]} reference cells in {dt:.1f} s ({rate_c:.3g} pair evaluations/s); extrapolated "
-                           f"by pair evaluations to the whole job")}
+                "gflops": rate_c * flop_per_pair / 1e9,
+                "sample": (f"oracle exact FP64 brute force (oracle/mnn_oracle.c, OpenMP, {cores} threads): {whole_c}, {nq_c} "
+                           f"queries x {L.shape[0]} reference cells in {dt:.1f} s ({rate_c:.3g} pair evaluations/s = "
+                           f"{rate_c * flop_per_pair / 1e9:.0f} GFLOP/s); scaled by pair evaluations to the whole job")}
     main = dict(max(out.values(), key=lambda r: r["value"]))
     return main, out
 
@@ -191,7 +199,9 @@ def run_config4(args):
         * (1.0 / np.sqrt(1.0 + np.arange(d) / 5.0))
 
     def make_block(b, c0):
-        m = min(blk, n - c0)
+        return make_block_n(b, c0, min(blk, n - c0))
+
+    def make_block_n(b, c0, m):
         rng = np.random.Generator(np.random.PCG64([20250314 + 4000, b, c0]))
         z = rng.standard_normal((d, m))
         x = np.empty((G, m), order="F")
@@ -200,8 +210,32 @@ def run_config4(args):
         x += 4.0 + 0.3 * b
         return x
 
+    # accuracy first, at a size the dense CPU decomposition takes seconds for (4 x 2 000 cells of the same generator):
+    # rotation, corrected coordinates and MNN pairs of the whole device pipeline against oracle/pca_oracle.py
+    from oracle import pca_oracle
+    ns = 2000
+    small = [np.hstack([make_block_n(b, c0, min(blk, ns - c0)) for c0 in range(0, ns, blk)]) for b in range(nb)]
+    dev = bx.fastMNN(*small, d=d)
+    ref, meta = pca_oracle.fast_mnn(*small, d=d, pca_method="gram")
+    sgn = np.sign((dev.rotation * meta["rotation"]).sum(axis=0))
+    rot_err = float(np.abs(dev.rotation * sgn[None, :] - meta["rotation"]).max() / np.abs(meta["rotation"]).max())
+    cor_err = float(np.abs(dev.corrected * sgn[None, :] - ref.corrected).max() / np.abs(ref.corrected).max())
+    pairs_equal = all(np.array_equal(a[0], b_[0]) and np.array_equal(a[1], b_[1])
+                      for a, b_ in zip(dev.merge_info.pairs, ref.merge_info.pairs))
+    accuracy = {"cells_per_batch": ns, "rotation_max_rel_err": rot_err, "corrected_max_rel_err": cor_err,
+                "mnn_pairs_bit_exact": bool(pairs_equal), "checker": "oracle/pca_oracle.py (dense Gram decomposition, numpy)"}
+    assert rot_err < 1e-5 and cor_err < 1e-5 and pairs_equal, accuracy
+    del small, dev, ref, meta
+
     times = {"generation_wait_ms": 0.0, "ingest_ms": 0.0}
-    workers = max(2, min(24, (os.cpu_count() or 4) // 2))
+    # the generators run numpy with the BLAS pinned to one thread each (24 multi-threaded matmuls at once starved the
+    # library's copy threads in round 3: 8.6 GB/s of ingest at 200 000 cells against 19.8 at 25 000)
+    workers = max(2, min(args.gen_threads, (os.cpu_count() or 4) // 2))
+    try:
+        from threadpoolctl import threadpool_limits
+        blas_limit = threadpool_limits(limits=1, user_api="blas")
+    except Exception:
+        blas_limit = None
     jobs = [(b, c0) for b in range(nb) for c0 in range(0, n, blk)]
     pca = bx.DevicePCA(G, 0)
     t_all = time.perf_counter()
@@ -226,6 +260,8 @@ def run_config4(args):
             times["ingest_ms"] += 1e3 * (time.perf_counter() - t0)
             del x
     torch.cuda.synchronize()
+    if blas_limit is not None:
+        blas_limit.restore_original_limits()
     times["generation_and_ingest_wall_ms"] = 1e3 * (time.perf_counter() - t_all)
     t0 = time.perf_counter()
     fit = pca.fit(d=d, tol=args.pca_tol, max_iters=500)
@@ -248,7 +284,7 @@ def run_config4(args):
                                    f"({in_bytes / 1e9:.0f} GB), host result out" + ("" if n == 200000 else
                                    "; the configuration as named has 200000 cells per batch"),
                        "generator_threads": workers, "mnn_pairs": [int(p[0].size) for p in out.merge_info.pairs]},
-            "stages_ms": times,
+            "stages_ms": times, "accuracy": accuracy,
             "ingest_GBps": in_bytes / 1e9 / (times["ingest_ms"] * 1e-3),
             "pca": {"operator_applications": fit["iters_used"], "relative_ritz_residual": fit["residual"],
                     "tolerance": args.pca_tol, "algorithmic_flops": flops_pca,
@@ -305,6 +341,7 @@ def main():
     ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS) + ["config4", "sgk"])
     ap.add_argument("--cells", type=int, default=25000, help="config4: cells per batch (200000 = the configuration as named)")
     ap.add_argument("--pca-tol", type=float, default=1e-9, help="config4: relative Ritz residual the PCA iterates to")
+    ap.add_argument("--gen-threads", type=int, default=16, help="config4: host threads generating the input blocks")
     ap.add_argument("--var-adj", action="store_true", help="config5: mnnCorrect-style variance adjustment in the merges")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-to-host", action="store_true")

@@ -446,6 +446,6 @@ def test_cpu_baselines_are_exact(oracle):
     ia, da, st = cb.kmknn_knn(X, Q, 12)
     assert np.array_equal(ia, oi) and np.array_equal(da, od)
     assert 0.0 < st["visited"] <= 1.0
-    ib, db = cb.blas_knn(X, Q, 12)
+    ib, db, _ = cb.blas_knn(X, Q, 12)
     assert np.array_equal(ib, oi)
     np.testing.assert_allclose(db, od, rtol=1e-12)
