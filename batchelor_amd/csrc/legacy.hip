@@ -387,6 +387,7 @@ constexpr int AT_CAP = 2048;    // collected entries of the crossing bin
 constexpr int AT_U = 8;         // scratch elements per thread and batch in the per-cell passes (two batches in flight)
 
 constexpr int AT_NP = 2 * AT_R; // the stream is padded to whole pairs of steps (zero rows)
+constexpr int AT_SM = 4 * AT_C * 6;  // doubles of the block-reduction area: six values per (wave, cell) after the stream (>= T)
 
 __host__ __device__ inline int asv_tile_gp(int g) { return (g + AT_KC - 1) / AT_KC * AT_KC + 2; }
 inline int asv_tile_nb8(int g) { return g <= 128 ? (g + 7) / 8 : 0; }  // 8-dimension blocks of a row; 0: the staged form
@@ -397,7 +398,7 @@ inline size_t asv_tile_lds_bytes(int g) {
     const int nb8 = asv_tile_nb8(g);
     // (the tile's cells / gradients and the collected bin share a region: the one is dead before the other is written)
     return (std::max<size_t>((size_t)2 * AT_C * asv_tile_gp(g), (size_t)2 * AT_CAP) +
-            (nb8 == 0 ? (size_t)AT_R * (AT_KC + 2) : 0) + 8 * AT_C + T) * sizeof(double) +
+            (nb8 == 0 ? (size_t)AT_R * (AT_KC + 2) : 0) + 8 * AT_C + AT_SM) * sizeof(double) +
            (size_t)AT_NB * sizeof(unsigned long long) + (nb8 > 8 ? (size_t)2 * nb8 * 2 * 64 * sizeof(double) : 0);
 }
 
@@ -542,8 +543,8 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
     double* sc_lo = sc_mx2 + AT_C;
     double* sc_hi = sc_lo + AT_C;
     double* sc_tmp = sc_hi + AT_C;
-    double* sm = sc_tmp + AT_C;                         // [T] block reductions
-    unsigned long long* hist = reinterpret_cast<unsigned long long*>(sm + T);  // [NB]
+    double* sm = sc_tmp + AT_C;                         // [AT_SM] block reductions
+    unsigned long long* hist = reinterpret_cast<unsigned long long*>(sm + AT_SM);  // [NB]
     double* cxp = reinterpret_cast<double*>(hist + AT_NB);  // [2 NB8][64] the cells' coordinates as the lanes read them
     double* cgp = cxp + (NB8 > 8 ? NB8 * 2 * 64 : 0);       // [2 NB8][64] the unit gradients likewise (NB8 > 8)
     __shared__ int sh_cnt, sh_bin;
@@ -592,9 +593,15 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
         }
         __syncthreads();
         // ---- pass over the streamed cells: projections and log-weights of every (cell, streamed cell) pair
+        // own batch: log-sum-exp of every cell's weights, all of them and those at or below its projection (:74-112), taken
+        // ONLINE in the stream's epilogue -- running maximum om, sums relative to it -- so that the own batch's 40 % of the
+        // (cell, streamed cell) pairs never go to the scratch and are not read back (round 3: 16 + 16 bytes per pair)
+        double om[4], oa[4], ob[4];
         double mx1[4], mx2[4], lo[4], hi[4], cp[4], cn[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            om[i] = NEG;
+            oa[i] = ob[i] = 0.0;
             mx1[i] = mx2[i] = NEG;
             lo[i] = POS;
             hi[i] = NEG;
@@ -681,13 +688,24 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                     lw = self ? 0.0 : lw;
                     pr = self ? NEG : pr;
                     // (selects, not branches: the padding rows of the stream belong to neither batch)
-                    mx2[i] = fmax(mx2[i], own ? lw : NEG);
                     mx1[i] = fmax(mx1[i], ref ? lw : NEG);
                     lo[i] = fmin(lo[i], ref ? pr : POS);
                     hi[i] = fmax(hi[i], ref ? pr : NEG);
-                    const int slot = (kq + 4 * i + blk + rot0) & (AT_C - 1);  // == at(kq + 4 i, jo)
-                    sp_[slot * 64] = pr;
-                    sw_[slot * 64] = lw;
+                    if (own) {  // (whole waves but for the one step where the own batch ends)
+                        if (lw > om[i]) {  // a new maximum: rare once the cell itself (log-weight 0) has gone by
+                            const double f = exp(om[i] - lw);  // exp(-inf) = 0 the first time
+                            oa[i] *= f;
+                            ob[i] *= f;
+                            om[i] = lw;
+                        }
+                        const double e = exp(lw - om[i]);
+                        oa[i] += e;
+                        ob[i] += !(pr > cp[i]) ? e : 0.0;
+                    } else {
+                        const int slot = (kq + 4 * i + blk + rot0) & (AT_C - 1);  // == at(kq + 4 i, jo)
+                        sp_[slot * 64] = pr;
+                        sw_[slot * 64] = lw;
+                    }
                 }
             };
             double ba[NST], bb[NST];
@@ -768,12 +786,23 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                         lw = 0.0;
                         pr = NEG;
                     }
-                    mx2[i] = fmax(mx2[i], own ? lw : NEG);
                     mx1[i] = fmax(mx1[i], own ? NEG : lw);
                     lo[i] = fmin(lo[i], own ? POS : pr);
                     hi[i] = fmax(hi[i], own ? NEG : pr);
-                    SP[at(c, jo)] = pr;
-                    SW[at(c, jo)] = lw;
+                    if (own) {
+                        if (lw > om[i]) {
+                            const double f = exp(om[i] - lw);
+                            oa[i] *= f;
+                            ob[i] *= f;
+                            om[i] = lw;
+                        }
+                        const double e = exp(lw - om[i]);
+                        oa[i] += e;
+                        ob[i] += !(pr > cp[i]) ? e : 0.0;
+                    } else {
+                        SP[at(c, jo)] = pr;
+                        SW[at(c, jo)] = lw;
+                    }
                 }
             }
         }
@@ -783,9 +812,15 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
         for (int i = 0; i < 4; ++i) {
             for (int o = 1; o < 16; o <<= 1) {
                 mx1[i] = fmax(mx1[i], __shfl_xor(mx1[i], o));
-                mx2[i] = fmax(mx2[i], __shfl_xor(mx2[i], o));
                 lo[i] = fmin(lo[i], __shfl_xor(lo[i], o));
                 hi[i] = fmax(hi[i], __shfl_xor(hi[i], o));
+                // the partial log-sum-exps of the 16 lanes that share the cell: to their common maximum, then added
+                const double pm = __shfl_xor(om[i], o), pa = __shfl_xor(oa[i], o), pb = __shfl_xor(ob[i], o);
+                const double mm = fmax(om[i], pm);
+                const double f0 = om[i] == mm ? 1.0 : exp(om[i] - mm), f1 = pm == mm ? 1.0 : exp(pm - mm);
+                oa[i] = oa[i] * f0 + pa * f1;
+                ob[i] = ob[i] * f0 + pb * f1;
+                om[i] = mm;
             }
         }
         __syncthreads();
@@ -793,23 +828,34 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int c = (lane >> 4) + 4 * i;
-                sm[(w * AT_C + c) * 4 + 0] = mx1[i];
-                sm[(w * AT_C + c) * 4 + 1] = mx2[i];
-                sm[(w * AT_C + c) * 4 + 2] = lo[i];
-                sm[(w * AT_C + c) * 4 + 3] = hi[i];
+                sm[(w * AT_C + c) * 6 + 0] = mx1[i];
+                sm[(w * AT_C + c) * 6 + 1] = lo[i];
+                sm[(w * AT_C + c) * 6 + 2] = hi[i];
+                sm[(w * AT_C + c) * 6 + 3] = om[i];
+                sm[(w * AT_C + c) * 6 + 4] = oa[i];
+                sm[(w * AT_C + c) * 6 + 5] = ob[i];
             }
         }
         __syncthreads();
         if (tid < AT_C) {
-            double a = NEG, b = NEG, l = POS, h = NEG;
+            double a = NEG, l = POS, h = NEG, m2 = NEG;
             for (int ww = 0; ww < 4; ++ww) {
-                a = fmax(a, sm[(ww * AT_C + tid) * 4 + 0]);
-                b = fmax(b, sm[(ww * AT_C + tid) * 4 + 1]);
-                l = fmin(l, sm[(ww * AT_C + tid) * 4 + 2]);
-                h = fmax(h, sm[(ww * AT_C + tid) * 4 + 3]);
+                a = fmax(a, sm[(ww * AT_C + tid) * 6 + 0]);
+                l = fmin(l, sm[(ww * AT_C + tid) * 6 + 1]);
+                h = fmax(h, sm[(ww * AT_C + tid) * 6 + 2]);
+                m2 = fmax(m2, sm[(ww * AT_C + tid) * 6 + 3]);
+            }
+            double all = 0.0, below = 0.0;  // the four waves' partial sums to the common maximum, in wave order
+            for (int ww = 0; ww < 4; ++ww) {
+                const double pm = sm[(ww * AT_C + tid) * 6 + 3];
+                const double f = pm == m2 ? 1.0 : exp(pm - m2);
+                all += sm[(ww * AT_C + tid) * 6 + 4] * f;
+                below += sm[(ww * AT_C + tid) * 6 + 5] * f;
             }
             sc_mx1[tid] = a;
-            sc_mx2[tid] = b;
+            // prob2 (:74-112): log-sum of the cells at or below the projection minus the log-sum of all of them; 0 - the
+            // latter when none is at or below (:76: prob2 then keeps its starting value)
+            sc_mx2[tid] = nr2 > 0 ? (below > 0.0 ? m2 + log(below) : 0.0) - (m2 + log(all)) : 0.0;
             sc_lo[tid] = l;
             sc_hi[tid] = h;
         }
@@ -823,19 +869,7 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
             auto w1 = [&](int64_t o_) { return SW[at(c, nr2 + o_)]; };
             const int last_block = (int)(Npad >> 6) - 1;
             const double curproj = sc_proj[c], l2 = sc_l2[c];
-            double prob2 = 0.0;
-            if (nr2 > 0) {
-                const double mx = sc_mx2[c];
-                double below = 0.0, all = 0.0;
-                asv_row_scan<true>(SP, SW, 0, nr2, c + rot0, last_block, tid, [&](double pr, double lw, int s_) {
-                    const double ww = s_ < nr2 ? exp(lw - mx) : 0.0;
-                    all += ww;
-                    below += !(pr > curproj) ? ww : 0.0;
-                });
-                below = block_sum(below, sm);
-                all = block_sum(all, sm);
-                prob2 = (below > 0.0 ? mx + log(below) : 0.0) - (mx + log(all));
-            }
+            const double prob2 = sc_mx2[c];  // (taken online by the stream, see above)
             double ref_quan = __builtin_nan("");
             if (nr1 > 0) {
                 const double mx = sc_mx1[c];

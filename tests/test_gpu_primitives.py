@@ -154,13 +154,17 @@ def test_portable_logspace_add_is_the_oracles(oracle, nat):
 def test_adjust_shift_variance_scalable_form_agrees_off_the_ill_conditioned_cells(oracle, nat, dev):
     """The testing hook "asv_fast" selects the form used beyond 4e7 (cell, restricted cell) pairs (16-cell tiles on the FP64
     matrix cores + a sort-free histogram quantile): it may pick a different cell only where the walk decides on the last
-    bit (a few per cent at sigma = 0.1)."""
+    bit.  On the reference's own test shapes (tests/testthat/test-mnn-correct.R:96-98) that is no cell at sigma 1 .. 0.03
+    (scripts/asv_parity_probe.py: 1.0000 each); where the bandwidth is small against the data's distances -- 100
+    dimensions, sigma <= 0.3: the weights sit on a handful of cells, every walk ends where a 53-bit sum stops changing --
+    the two forms part on up to 60 % of the cells, which is why the exact form is the one every
+    size a test can check is given."""
     dev("asv_fast", 1)
     rng = np.random.default_rng(100032)
     data1 = rng.standard_normal((25, 400)) * 0.1
     data2 = rng.standard_normal((25, 1000)) * 0.1
     corvect = rng.random((1000, 25))
-    for sigma, bar in ((1.0, 0.999), (0.1, 0.95)):
+    for sigma, bar in ((1.0, 0.999), (0.1, 0.999)):
         out = nat.adjust_shift_variance(data1, data2, corvect, sigma, np.arange(400), np.arange(1000))
         ref = oracle.adjust_shift_variance(data1, data2, corvect, sigma, np.arange(400), np.arange(1000))
         close = np.isclose(out, ref, rtol=1e-8, atol=1e-12)
@@ -178,7 +182,7 @@ def test_adjust_shift_variance_scalable_form_agrees_off_the_ill_conditioned_cell
     out = nat.adjust_shift_variance(d1, d2, cv, 1.0, r1, r2)
     ref = oracle.adjust_shift_variance(d1, d2, cv, 1.0, r1, r2)
     close = np.isclose(out, ref, rtol=1e-8, atol=1e-12, equal_nan=True)
-    assert close.mean() > 0.995, close.mean()
+    assert close.mean() > 0.999, close.mean()
     assert np.isnan(out[17]) and np.isnan(ref[17])                  # 0 / 0, as the reference (:160)
 
 
