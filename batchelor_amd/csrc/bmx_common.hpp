@@ -324,6 +324,7 @@ struct KnnWorkspace {
         pinned_small_pool().push_back(p);
     }
     int64_t* pin_ = nullptr;
+    int read_seq = 0;              // sequence number of the last word published to pin_ (knn.hip: read_count)
     bool abandon = false;          // the stream is stuck (watchdog): nothing that would wait for the device may be called
     // diagnostics of the last search / totals since the engine reset them
     int64_t last_exact = 0;             // queries that took the exact FP64 path

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <thread>
 
@@ -848,7 +849,9 @@ void Engine::run(const bmx_params_t& p, const int32_t* tree, int tree_len) {
     // host round trip (knn.hip: search_tiers).  A search that cannot be completed that way (hundreds of uncertified queries,
     // lists overflowing with exact ties) raises a device flag the waits of the merge loop look at; the run then starts over
     // from the resident inputs with host-checked searches.  Nothing of a merge is visible outside before the run returns.
-    knn_ws_.optimistic = !knn_ws_.force_exact;
+    // (one rank only: with several, a flag raised on one of them would have to restart all -- their searches keep the host
+    // in the loop instead, the way every search did before: five cheap read-backs per merge, no flag to agree on)
+    knn_ws_.optimistic = !knn_ws_.force_exact && world_ == 1;
     try {
         run_once(p, tree, tree_len);
     } catch (const OptimisticRetry&) {
@@ -857,6 +860,45 @@ void Engine::run(const bmx_params_t& p, const int32_t* tree, int tree_len) {
         run_once(p, tree, tree_len);
     }
     knn_ws_.optimistic = false;
+}
+
+// counts[t] is known on rank t % world only (0 elsewhere): every rank gets them all (an all-gather of the padded slices)
+std::vector<int32_t> Engine::gather_counts(const std::vector<int32_t>& mine) {
+    if (world_ == 1) return mine;
+    const int n = (int)mine.size();
+    const int per = (n + world_ - 1) / world_;
+    std::vector<int32_t> slice((size_t)per * world_, 0);
+    for (int t = rank_; t < n; t += world_) slice[(size_t)rank_ * per + t / world_] = mine[t];
+    int32_t* dev = count_xchg_.reserve((size_t)per * world_);
+    BMX_HIP(hipMemcpyAsync(dev, slice.data(), slice.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+    BMX_HIP(hipStreamSynchronize(stream_));
+    exchange(dev, (int64_t)per * (int64_t)sizeof(int32_t));
+    BMX_HIP(hipMemcpyAsync(slice.data(), dev, slice.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+    wait();
+    std::vector<int32_t> out((size_t)n);
+    for (int t = 0; t < n; ++t) out[t] = slice[(size_t)(t % world_) * per + t / world_];
+    return out;
+}
+
+std::vector<int32_t> Engine::solo_counts(int n, const std::function<int(int)>& count, bool dry) {
+    std::vector<int32_t> mine((size_t)n, 0);
+    if (dry) return mine;
+    const int rk = rank_, wd = world_;
+    for (int t = 0; t < n; ++t) {
+        if (t % wd != rk) continue;
+        rank_ = 0;
+        world_ = 1;  // an unsharded search on this rank alone
+        try {
+            mine[t] = count(t);
+        } catch (...) {
+            rank_ = rk;
+            world_ = wd;
+            throw;
+        }
+        rank_ = rk;
+        world_ = wd;
+    }
+    return gather_counts(mine);
 }
 
 void Engine::run_once(const bmx_params_t& p, const int32_t* tree, int tree_len) {
@@ -1006,8 +1048,18 @@ void Engine::run_once(const bmx_params_t& p, const int32_t* tree, int tree_len) 
         std::vector<std::unique_ptr<Node>> rem;
         for (int b = 0; b < B_; ++b) rem.push_back(make_leaf(b, 0));
         std::vector<std::vector<int64_t>> stats(B_, std::vector<int64_t>(B_, 0));
-        for (int i = 0; i < B_; ++i)
-            for (int j = 0; j < i; ++j) stats[i][j] = count_mnn_pairs(*rem[i], *rem[j], p);
+        {
+            // .initialize_auto_search (R/MNN_tree.R:160-164): B (B - 1) / 2 independent counts.  With several ranks they are
+            // dealt round robin -- each a whole, unsharded search on its rank: no gathers inside, all ranks busy -- and the
+            // numbers all-gathered at the end, instead of every rank walking every count with row-split searches
+            std::vector<std::pair<int, int>> todo;
+            for (int i = 0; i < B_; ++i)
+                for (int j = 0; j < i; ++j) todo.emplace_back(i, j);
+            std::vector<int32_t> counts = solo_counts((int)todo.size(), [&](int t) {
+                return count_mnn_pairs(*rem[todo[t].first], *rem[todo[t].second], p);
+            });
+            for (size_t t = 0; t < todo.size(); ++t) stats[todo[t].first][todo[t].second] = counts[t];
+        }
         for (int mdx = 0; mdx < nmerges; ++mdx) {
             // .pick_best_merge: first maximum in column-major order; left = row, right = column
             const int R = (int)rem.size();
@@ -1037,8 +1089,13 @@ void Engine::run_once(const bmx_params_t& p, const int32_t* tree, int tree_len) 
                 for (int c = 0; c < K; ++c) ns[a][c] = stats[keep[a]][keep[c]];
             if (K > 0) {
                 // upstream keeps orthogonalising the SAME left copy across j (R/MNN_tree.R:185-186)
+                // (.update_remainders, R/MNN_tree.R:205-226: the K counts are dealt over the ranks like the initial ones; the
+                // orthogonalisations of the shared left copy are cheap row passes every rank applies in order)
                 std::unique_ptr<Node> lcopy = clone_node(*merged);
+                std::vector<int32_t> mine((size_t)K, 0);
                 for (int c = 0; c < K; ++c) {
+                    orthogonalize(*lcopy, nrem[c]->extras);
+                    if (c % world_ != rank_) continue;
                     const Node* r = nrem[c].get();
                     std::unique_ptr<Node> rc;
                     if (!merged->extras.empty()) {
@@ -1046,9 +1103,21 @@ void Engine::run_once(const bmx_params_t& p, const int32_t* tree, int tree_len) 
                         orthogonalize(*rc, merged->extras);
                         r = rc.get();
                     }
-                    orthogonalize(*lcopy, nrem[c]->extras);
-                    ns[K][c] = find_mnn(*lcopy, *r, p.k, p.prop_k).P;
+                    const int rk = rank_, wd = world_;
+                    rank_ = 0;
+                    world_ = 1;  // an unsharded search on this rank alone
+                    try {
+                        mine[c] = (int32_t)find_mnn(*lcopy, *r, p.k, p.prop_k).P;
+                    } catch (...) {
+                        rank_ = rk;
+                        world_ = wd;
+                        throw;
+                    }
+                    rank_ = rk;
+                    world_ = wd;
                 }
+                const std::vector<int32_t> all = gather_counts(mine);
+                for (int c = 0; c < K; ++c) ns[K][c] = all[c];
             }
             nrem.push_back(std::move(merged));
             rem = std::move(nrem);

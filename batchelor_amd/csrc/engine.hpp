@@ -2,6 +2,7 @@
 // R/MNN_tree.R, driven from one host thread.  Host code only decides sizes and control flow (the merge order, k,
 // whether a merge is skipped); every cell x dimension value stays in HBM from upload to download.
 #pragma once
+#include <functional>
 #include <memory>
 
 #include "bmx_common.hpp"
@@ -134,6 +135,10 @@ class Engine {
 
   private:
     void run_once(const bmx_params_t& p, const int32_t* tree, int tree_len);
+    // auto-merge: n independent pair counts dealt round robin over the ranks (each an unsharded search), then all-gathered
+    std::vector<int32_t> solo_counts(int n, const std::function<int(int)>& count, bool dry = false);
+    std::vector<int32_t> gather_counts(const std::vector<int32_t>& mine);
+    DevBuf<int32_t> count_xchg_;
     const int32_t* read_state();  // one wait: the run's device words in pinned memory; throws OptimisticRetry
     void merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p, std::unique_ptr<Node>& merged);
     // statistics (column means + total variance) of the segments whose slot is stale

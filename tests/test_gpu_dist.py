@@ -41,6 +41,34 @@ def test_n_rank_engine_equals_single_rank(tmp_path, world, var_adj):
         assert int(got["calls"]) == 2 * (3 + 2 + (1 if var_adj else 0))
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_auto_merge_counts_are_dealt_over_the_ranks(tmp_path, world):
+    """auto.merge = TRUE (R/MNN_tree.R:154-226): the B (B - 1) / 2 initial MNN-pair counts and the recounts after every merge are
+    independent searches -- with several ranks each count runs whole on one rank (round robin) and the numbers are
+    all-gathered; the merges themselves are row-sharded as ever.  Same merge order, same pairs, same coordinates as one rank."""
+    import batchelor_amd as bx
+    from tests.conftest import synth_batches
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_gpu_shard_worker.py"), str(r), str(world),
+                               str(port), str(tmp_path), "auto"], env=env) for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=900) == 0
+    B = synth_batches(14, [900, 1400, 700, 1100, 800], 20)
+    ref = bx.reducedMNN(*B, auto_merge=True)
+    for r in range(world):
+        got = np.load(tmp_path / f"rank{r}.npz")
+        assert list(got["left"]) == [sum(1 << (b - 1) for b in s_) for s_ in ref.merge_info.left]
+        assert list(got["right"]) == [sum(1 << (b - 1) for b in s_) for s_ in ref.merge_info.right]
+        assert np.array_equal(got["corrected"], ref.corrected)
+        for m in range(2):
+            assert np.array_equal(got[f"pl{m}"], ref.merge_info.pairs[m][0])
+            assert np.array_equal(got[f"pr{m}"], ref.merge_info.pairs[m][1])
+
+
 def test_nccl_exchange_aliases_raw_device_pointer():
     """World-size-1 RCCL group: the production transport (all_gather_into_tensor on a tensor aliasing a raw device
     pointer handed over by the engine) runs and really aliases the buffer."""
