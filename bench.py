@@ -343,10 +343,17 @@ def main():
     ap.add_argument("--pca-tol", type=float, default=1e-9, help="config4: relative Ritz residual the PCA iterates to")
     ap.add_argument("--gen-threads", type=int, default=16, help="config4: host threads generating the input blocks")
     ap.add_argument("--var-adj", action="store_true", help="config5: mnnCorrect-style variance adjustment in the merges")
+    ap.add_argument("--dev", action="append", default=[], metavar="KNOB=VALUE",
+                    help="developer A/B runs: a testing hook of the library (bmx_dev_set), e.g. --dev f16_cons=8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-to-host", action="store_true")
     args = ap.parse_args()
 
+    if args.dev:
+        from batchelor_amd import _lib as _bl
+        for kv in args.dev:
+            name, val = kv.split("=")
+            _bl.dev_set(name, int(val))
     if args.workload == "config4":
         return run_config4(args)
     if args.workload == "sgk":
