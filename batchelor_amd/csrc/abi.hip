@@ -146,6 +146,7 @@ int32_t bmx_dev_set(const char* name, int32_t value) {
     else if (n == "no_margin") k.no_margin = value;
     else if (n == "asv_fast") k.asv_fast = value;
     else if (n == "exchange_always") k.exchange_always = value;
+    else if (n == "refine_wave") k.refine_wave = value;
     else if (n == "reset") k = bmx::DevKnobs();
     else {
         g_last_error = "bmx_dev_set: unknown knob '" + n + "'";

@@ -166,13 +166,13 @@ __global__ __launch_bounds__(256) void knn_refine(const double* __restrict__ X, 
                                                   const float* __restrict__ seed_d2, int32_t* __restrict__ idx_out,
                                                   double* __restrict__ dist_out, int32_t* __restrict__ flagged,
                                                   double* __restrict__ flag_bound,
-                                                  unsigned long long* __restrict__ zero_slots) {
+                                                  unsigned long long* __restrict__ zero_slots, int q0) {
     __shared__ __attribute__((aligned(16))) double sd[4][REFINE_MAXM];
     __shared__ int si[4][REFINE_MAXM];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     // (the prep kernels' 64 slot maxima have been folded by now: left zeroed for the next search's norm pass)
     if (zero_slots && blockIdx.x == 0 && threadIdx.x < 64) zero_slots[(size_t)threadIdx.x * 16] = 0ull;
-    const int q = blockIdx.x * 4 + w;
+    const int q = q0 + blockIdx.x * 4 + w;  // (queries [q0, nq): the ones in front go through knn_refine_half)
     if (q >= nq) return;
     const int Mall = nchunks * KS;
     const double* qv = Q + (int64_t)(q_rows ? q_rows[q] : q) * d;
@@ -343,6 +343,178 @@ __global__ __launch_bounds__(256) void knn_refine(const double* __restrict__ X, 
             const int pos = atomicAdd(&flagged[0], 1);
             flagged[1 + pos] = q;
             flag_bound[pos] = kth;  // the true k-th neighbour is no farther than the k-th candidate
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The same for queries with ONE list of at most 32 candidates (the query blocks that swept the whole reference as a single
+// range with KS = 32: two thirds to nine tenths of a search's queries): HALF a wave per query.  A query's candidates fill
+// at most 32 lanes, so a whole wave spent most of the gather, both ranking loops and the certificate on idle lanes; with
+// two queries per wave those parts cost half as much per query (the FP64 distance chain -- a quad of lanes per candidate
+// row, 8 rows per half and trip -- costs the same).  Same arithmetic, same order, same outputs as knn_refine.
+// Layout: query q's list is cand[q * stride .. + 32) (stride = nchunks * KS: the other ranges' columns of such a query hold
+// nothing), its threshold tau[q * nchunks].
+// ---------------------------------------------------------------------------------------------------
+template <int REFINE_NC>
+__global__ __launch_bounds__(256) void knn_refine_half(const double* __restrict__ X, const int32_t* __restrict__ ref_rows,
+                                                       const double* __restrict__ Q, const int32_t* __restrict__ q_rows,
+                                                       int nq, int d, int k, int nchunks, double eps_k, double eps_qr,
+                                                       double eps_split, double eps_den, int scaled,
+                                                       const int32_t* __restrict__ cand, const float* __restrict__ cand_v,
+                                                       const float* __restrict__ tau, const double* __restrict__ qn2,
+                                                       const unsigned long long* __restrict__ max_rn2_bits,
+                                                       const float* __restrict__ seed_d2, int32_t* __restrict__ idx_out,
+                                                       double* __restrict__ dist_out, int32_t* __restrict__ flagged,
+                                                       double* __restrict__ flag_bound,
+                                                       unsigned long long* __restrict__ zero_slots) {
+    constexpr int KS = 32;
+    __shared__ __attribute__((aligned(16))) double sd[8][KS];
+    __shared__ int si[8][KS];
+    const int lane = threadIdx.x & 63, hl = lane & 31, half = lane >> 5;
+    const int w = (threadIdx.x >> 6) * 2 + half;  // the half-wave's row of the LDS arrays
+    if (zero_slots && blockIdx.x == 0 && threadIdx.x < 64) zero_slots[(size_t)threadIdx.x * 16] = 0ull;
+    const int qraw = blockIdx.x * 8 + w;
+    const bool live = qraw < nq;
+    const int q = live ? qraw : nq - 1;  // (an idle half follows the last query and writes nothing: shuffles stay convergent)
+    const int64_t stride = (int64_t)nchunks * KS;
+    const double* qv = Q + (int64_t)(q_rows ? q_rows[q] : q) * d;
+    const double max_rn2 = __longlong_as_double((long long)*max_rn2_bits);
+    const double s = scaled ? pass_scale(max_rn2) : 1.0;
+    const double s2inv = 1.0 / (s * s);
+    const double eps = pass_eps(sqrt(qn2[q]), sqrt(max_rn2), s, eps_k, eps_qr, eps_split, eps_den);
+    auto half_ballot = [&](bool p) { return (uint32_t)(__builtin_amdgcn_ballot_w64(p) >> (half << 5)); };
+    // 1. dense list of the valid candidates
+    unsigned long long* sk = reinterpret_cast<unsigned long long*>(&sd[w][0]);
+    int M;
+    {
+        const int id = cand[(int64_t)q * stride + hl];
+        const uint32_t mask = half_ballot(id >= 0);
+        const int pos = __builtin_popcount(mask & ((1u << hl) - 1u));
+        if (id >= 0) {
+            si[w][pos] = id;
+            if (cand_v) sk[pos] = ((unsigned long long)f32_orderable(cand_v[(int64_t)q * stride + hl]) << 32) | (uint32_t)id;
+        }
+        M = __builtin_popcount(mask);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // 2. rank by approximate value; only the candidates within twice the error bound of the k-th best go on
+    const int Mo = max(M, __shfl_xor(M, 32));  // (loops run to the longer of the wave's two lists)
+    if (cand_v) {
+        const bool rankit = M > k;
+        int rank = 0x7FFFFFFF, id = 0;
+        float vm = 0.f, vk = __builtin_inff();
+        if (hl < M) {
+            const unsigned long long km = sk[hl];
+            vm = orderable_f32((uint32_t)(km >> 32));
+            id = (int)(uint32_t)km;
+            rank = 0;
+        }
+        for (int f = 0; f + 2 <= Mo; f += 2) {
+            typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+            const u64x2 kf = *reinterpret_cast<const u64x2*>(sk + f);
+            if (hl < M) {
+                const unsigned long long km = ((unsigned long long)f32_orderable(vm) << 32) | (uint32_t)id;
+                rank += (f < M && kf[0] < km ? 1 : 0) + (f + 1 < M && kf[1] < km ? 1 : 0);
+            }
+        }
+        if ((Mo & 1) && hl < M && Mo - 1 < M) {
+            const unsigned long long km = ((unsigned long long)f32_orderable(vm) << 32) | (uint32_t)id;
+            rank += sk[Mo - 1] < km ? 1 : 0;
+        }
+        if (hl < M && rank == k - 1) vk = vm;
+        for (int o = 16; o > 0; o >>= 1) vk = fminf(vk, __shfl_xor(vk, o));
+        const float cut = (float)((double)vk + 2.0 * eps * (s * s) * 1.0000002 + 1e-30);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (rankit) {
+            const bool keep = hl < M && vm <= cut;
+            const uint32_t mask = half_ballot(keep);
+            if (keep) si[w][__builtin_popcount(mask & ((1u << hl) - 1u))] = id;
+            M = __builtin_popcount(mask);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    // 3. exact distances: a quad of lanes per candidate row, 8 rows per half and trip (see knn_refine)
+    const int M3 = max(M, __shfl_xor(M, 32));
+    if constexpr (REFINE_NC > 0) {
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        const int g = hl >> 2, p = hl & 3;
+        const int np = d >> 1;
+        const d2* q2 = reinterpret_cast<const d2*>(qv);
+        d2 x[REFINE_NC];
+#pragma unroll
+        for (int c = 0; c < REFINE_NC; ++c) {
+            x[c] = d2{0.0, 0.0};
+            if (4 * c + p < np) x[c] = q2[4 * c + p];
+        }
+        const int p_last = (np - 1) & 3;
+        for (int r0 = 0; r0 < M3; r0 += 8) {
+            const int m = r0 + g;
+            const int id = M > 0 ? si[w][m < M ? m : 0] : 0;  // (the other half's list may be the longer one: a valid row)
+            const d2* row2 = reinterpret_cast<const d2*>(X + (int64_t)(ref_rows ? ref_rows[id] : id) * d);
+            d2 y[REFINE_NC];
+#pragma unroll
+            for (int c = 0; c < REFINE_NC; ++c) {
+                y[c] = d2{0.0, 0.0};
+                if (4 * c + p < np) y[c] = row2[4 * c + p];
+            }
+#pragma unroll
+            for (int c = 0; c < REFINE_NC; ++c) {
+                const double t0 = x[c][0] - y[c][0], t1 = x[c][1] - y[c][1];
+                y[c][0] = t0 * t0;
+                y[c][1] = t1 * t1;
+            }
+            double acc = 0.0;
+#pragma unroll
+            for (int c = 0; c < REFINE_NC; ++c) {
+                if (4 * c < np) {  // (wave-uniform)
+#pragma unroll
+                    for (int ph = 0; ph < 4; ++ph) {
+                        const unsigned long long bits = (unsigned long long)__double_as_longlong(acc);
+                        const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)bits, 0x93, 0xF, 0xF, false);
+                        const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(bits >> 32), 0x93, 0xF, 0xF, false);
+                        const double prev = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+                        double run = prev + y[c][0];
+                        run += y[c][1];
+                        if (p == ph && 4 * c + ph < np) acc = run;
+                    }
+                }
+            }
+            if (p == p_last && m < M) sd[w][m] = acc;
+        }
+    } else {
+        if (hl < M) {
+            const int id = si[w][hl];
+            sd[w][hl] = exact_d2(qv, X + (int64_t)(ref_rows ? ref_rows[id] : id) * d, d);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const double seed = seed_d2 ? (double)seed_d2[q] : __builtin_inf();
+    double kth = M >= k ? 0.0 : seed;
+    if (seed_d2 && live)
+        for (int m = M + hl; m < k; m += 32) idx_out[(int64_t)q * k + m] = -1;
+    {
+        const double dm = hl < M ? sd[w][hl] : 0.0;
+        const int im = hl < M ? si[w][hl] : 0;
+        int rank = 0;
+        for (int f = 0; f < M3; ++f) {
+            if (f < M) rank += key_less(sd[w][f], si[w][f], dm, im) ? 1 : 0;
+        }
+        if (hl < M && rank < k && live) {
+            idx_out[(int64_t)q * k + rank] = im;
+            if (dist_out) dist_out[(int64_t)q * k + rank] = sqrt(dm);
+        }
+        if (hl < M && rank == k - 1) kth = dm;
+    }
+    // 4. certificate
+    for (int o = 16; o > 0; o >>= 1) kth = fmax(kth, __shfl_xor(kth, o));
+    kth = fmin(kth, seed);
+    if (hl == 0 && live) {
+        const bool proven = kth < (double)tau[(int64_t)q * nchunks] * s2inv + qn2[q] - eps;
+        if (!proven) {
+            const int pos = atomicAdd(&flagged[0], 1);
+            flagged[1 + pos] = q;
+            flag_bound[pos] = kth;
         }
     }
 }
@@ -718,12 +890,22 @@ void candidate_pass(hipStream_t stream, KnnWorkspace& ws, const Tier& T, const d
     ok = ok && go(L);
     if (!ok) throw Error(BMX_ERR_ARG, "kNN: unsupported padded dimension");
     {
-        // rows of an even number of doubles are 16-byte aligned: the quad gather, instantiated for the row length
+        // rows of an even number of doubles are 16-byte aligned: the quad gather, instantiated for the row length.  The queries
+        // of the whole-range blocks (one list of <= 32 candidates each) take half a wave each, the others a wave
         const int need = (d & 1) ? 0 : cdiv(d, 8);
-#define BMX_REFINE(NC) \
-    hipLaunchKernelGGL(knn_refine<NC>, dim3(cdiv(nq, 4)), dim3(256), 0, stream, X, ref_rows, Qs, qrs, nq, d, k, KS, nchunks, \
-                       eps_k, eps_qr, eps_split, eps_den, T.id == 1 ? 1 : 0, cand, cand_v, tau, qn2, maxbits, seed_d2, io, \
-                       dout, flagged, flag_bound, zero_slots)
+        const int unit_q = T.id == 1 ? 256 : 32 * bf16_ncons(NS, KS);
+        const int nq_half = KS == 32 && !dev_knobs().refine_wave ? (C > 1 ? std::min(nq, n_full * unit_q) : nq) : 0;
+#define BMX_REFINE(NC)                                                                                                              \
+    do {                                                                                                                            \
+        if (nq_half > 0)                                                                                                            \
+            hipLaunchKernelGGL(knn_refine_half<NC>, dim3(cdiv(nq_half, 8)), dim3(256), 0, stream, X, ref_rows, Qs, qrs, nq_half, d, k, \
+                               nchunks, eps_k, eps_qr, eps_split, eps_den, T.id == 1 ? 1 : 0, cand, cand_v, tau, qn2, maxbits,       \
+                               seed_d2, io, dout, flagged, flag_bound, zero_slots);                                                 \
+        if (nq > nq_half)                                                                                                           \
+            hipLaunchKernelGGL(knn_refine<NC>, dim3(cdiv(nq - nq_half, 4)), dim3(256), 0, stream, X, ref_rows, Qs, qrs, nq, d, k, KS,  \
+                               nchunks, eps_k, eps_qr, eps_split, eps_den, T.id == 1 ? 1 : 0, cand, cand_v, tau, qn2, maxbits,       \
+                               seed_d2, io, dout, flagged, flag_bound, nq_half > 0 ? nullptr : zero_slots, nq_half);                \
+    } while (0)
         if (need == 0 || need > 16) BMX_REFINE(0);
         else if (need <= 2) BMX_REFINE(2);
         else if (need <= 4) BMX_REFINE(4);

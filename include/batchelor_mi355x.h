@@ -89,7 +89,7 @@ void bmx_set_force_exact_knn(int32_t on);
  * FP64 scan only), "sample" (rows of a candidate pass's threshold sample, -1 = automatic), "split_c" / "force_c"
  * (reference ranges of the tail / of every query block), "no_margin" (fp16 tier: lists cut at their KS-th best only),
  * "asv_fast" (the tiled form of adjust_shift_variance at any size), "exchange_always" (a single rank goes through its
- * exchange transport too), "reset" (all back to their defaults).  Unknown name: BMX_ERR_ARG. */
+ * exchange transport too), "refine_wave" (the exact re-rank spends a whole wave on every query), "reset" (all back to their defaults).  Unknown name: BMX_ERR_ARG. */
 int32_t bmx_dev_set(const char* name, int32_t value);
 
 /* ------------------------------------------------------------------------------------------------------------------
