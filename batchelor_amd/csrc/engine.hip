@@ -856,6 +856,7 @@ void Engine::run(const bmx_params_t& p, const int32_t* tree, int tree_len) {
         run_once(p, tree, tree_len);
     } catch (const OptimisticRetry&) {
         if (debug_prints()) fprintf(stderr, "[bmx] optimistic run gave up; repeating with host-checked searches\n");
+        ++optimistic_retries_;
         knn_ws_.optimistic = false;
         run_once(p, tree, tree_len);
     }
@@ -1360,6 +1361,7 @@ void Engine::profile_detail(double* out10) {
     }
     out10[7] = (double)fallbacks_;
     out10[8] = (double)knn_ws_.tier2_total;
+    out10[9] = (double)optimistic_retries_;
 }
 
 void Engine::profile(double* topk_ms, int64_t* launches, int64_t* fallbacks) {

@@ -93,7 +93,8 @@ class Engine {
     void profile(double* topk_ms, int64_t* launches, int64_t* fallbacks);
     // out[0..9]: full-pass ms / launches of the fp16 kernel, of the split-bf16 kernel, sample-pass ms / launches,
     // streaming-section ms (everything of the merges that is not a kNN search), queries that took the exact path,
-    // queries handed from tier 1 to tier 2, all since the last run() started (profiling on)
+    // queries handed from tier 1 to tier 2, all since the last run() started (profiling on); out[9]: runs of this engine
+    // whose optimistic attempt gave up and was repeated with host-checked searches
     void profile_detail(double* out10);
     int nbatches() const { return B_; }
     int64_t total_cells() const { return N_; }
@@ -123,6 +124,7 @@ class Engine {
     ReduceWorkspace red_ws_;
     DevBuf<int32_t> idxLR_, idxRL_, cntL_, offL_, partR_, cntR_, flagR_, offR_, second_u_, second_rows_, idxT_;
     DevBuf<int32_t> stampL_, offSel_, lsel_, qsel_, cntFold_;
+    int64_t optimistic_retries_ = 0;  // runs of this engine that started over with host-checked searches (run())
     int state_seq_ = 0;  // sequence number of the last publish_state (read_state)
     int stamp_gen_ = 0;  // number of the last search whose listed rows were stamped (stampL_ is never cleared)
     DevBuf<unsigned long long> maskL_;

@@ -170,7 +170,8 @@ class MnnEngine:
         _lib.check(_lib.lib().bmx_engine_knn_kernel(self._h, buf, 128))
         return {"f16_ms": a[0], "f16_launches": int(a[1]), "bf16_ms": a[2], "bf16_launches": int(a[3]),
                 "sample_ms": a[4], "sample_launches": int(a[5]), "streaming_ms": a[6],
-                "exact_fallbacks": int(a[7]), "tier2_queries": int(a[8]), "kernel": buf.value.decode()}
+                "exact_fallbacks": int(a[7]), "tier2_queries": int(a[8]), "optimistic_retries": int(a[9]),
+                "kernel": buf.value.decode()}
 
     def merge_stats(self):
         out = []

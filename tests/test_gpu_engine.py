@@ -182,3 +182,25 @@ def test_engine_random_configurations(oracle, bx):
             kw["restrict"] = [np.sort(rng.choice(n, size=max(30, n // 2), replace=False)) + 1 for n in sizes]
         B = synth_batches(400 + case, sizes, d)
         assert_same_result(bx.reducedMNN(*B, **kw), oracle.reduced_mnn(*B, **kw))
+
+
+def test_optimistic_run_starts_over_when_a_search_cannot_be_completed_on_the_device(oracle, bx):
+    """A run first leaves the count of a search's uncertified queries on the device and sweeps them there (no host round
+    trip); more than 256 of them, or a list that overflows with near-ties, raises a device flag and the run is repeated with
+    host-checked searches (Engine::run).  Clusters of 150 near-duplicates put thousands of references inside the fp16 pass's
+    error margin of every query's k-th neighbour: the first tier certifies next to nothing -- the retry must happen and the
+    result must be the oracle's."""
+    rng = np.random.default_rng(4242)
+    centres = rng.standard_normal((30, 50)) * 2.0
+    B = [np.repeat(centres, 150, axis=0) + 1e-4 * rng.standard_normal((4500, 50)) + 0.3 * b for b in range(2)]
+    eng = bx.MnnEngine(0)
+    try:
+        eng.upload(B)
+        eng.set_profiling(True)
+        eng.run()
+        out = eng.download()
+        assert eng.profile_detail()["optimistic_retries"] >= 1
+    finally:
+        eng.close()
+    ref = oracle.reduced_mnn(*B)
+    assert_same_result(out, ref)
