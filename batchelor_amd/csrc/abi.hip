@@ -131,6 +131,15 @@ int32_t bmx_device_count(void) {
 
 void bmx_free(void* p) { std::free(p); }
 
+int32_t bmx_set_device(int32_t device) {
+    return guarded([&] { BMX_HIP(hipSetDevice(device)); });
+}
+
+void bmx_trim_caches(void) {
+    // device blocks parked by engines that are gone (up to 16 GB are kept for the next engine on the device)
+    bmx::DevBlockCache::release_global();
+}
+
 int64_t bmx_last_knn_exact_fallbacks(void) { return g_last_fallbacks; }
 
 void bmx_set_force_exact_knn(int32_t on) { g_force_exact = on; }

@@ -34,6 +34,13 @@ const char* bmx_last_error(void);
 int32_t bmx_device_count(void);
 /* Frees arrays returned through `int32_t**` / `double**` out-parameters. */
 void bmx_free(void* p);
+/* The one-shot entry points (bmx_fast_mnn, the single primitives) run on the calling thread's CURRENT HIP device; a host
+ * without HIP bindings of its own picks it here (hipSetDevice). */
+int32_t bmx_set_device(int32_t device);
+/* Engines park their device blocks in a process-wide pool when they go (at most 16 GB / 256 blocks: a host that calls
+ * fastMNN() again and again then pays its hipMallocs once); an allocation that fails inside the library empties the pool
+ * by itself, other allocators of the process (torch, RCCL, the host's own hipMalloc) call this when they need the memory. */
+void bmx_trim_caches(void);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Legacy .Call kernels (R_CallMethodDef table, src/RcppExports.cpp:48-58)
