@@ -392,10 +392,13 @@ int f16_rows_per_slot(int NS, int KS);  // reference rows a ring slot of the fp1
 // for neighbours.  The search then starts from that threshold instead of a sampled one and a row may come back with
 // fewer than k neighbours, padded with -1: exactly the references within the bound, or the k nearest if there are
 // more than k of them.
+// kth_out (nullable, [nq] device): the Euclidean distance of each row's k-th (last) neighbour where the row is full and
+// certified by the first tier, +inf otherwise -- what lets the mutual-pair probe reject a candidate without reading the row.
 // centre (nullable, [d] device): a point near the middle of the reference rows (the prepared images are taken relative to
 // it: any vector is valid, a good one keeps the error bound tight); null: the mean of a strided sample is computed here.
 void knn_device(hipStream_t stream, KnnWorkspace& ws, const double* X, const int32_t* ref_rows, int nr,
                 const double* Q, const int32_t* q_rows, int nq, int d, int k, int32_t* idx_out, double* dist_out,
-                int q_begin, int q_end, const float* seed_d2 = nullptr, const double* centre = nullptr);
+                int q_begin, int q_end, const float* seed_d2 = nullptr, const double* centre = nullptr,
+                double* kth_out = nullptr);
 
 }  // namespace bmx

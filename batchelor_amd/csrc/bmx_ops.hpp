@@ -31,7 +31,10 @@ void exclusive_scan_i32(hipStream_t stream, ScanWorkspace& ws, const int32_t* in
 // of a selected left cell l (both nullptr: one row per left cell).  nL = number of rows of idxLR.
 void mutual_counts(hipStream_t stream, const int32_t* idxLR, int nL, int k2, const int32_t* idxRL, int nR, int k1,
                    int32_t* cntL, int32_t* partR, int32_t* cntR, const int32_t* lsel = nullptr,
-                   const int32_t* lpos2c = nullptr, unsigned long long* maskL = nullptr, bool mask_is_clear = false);
+                   const int32_t* lpos2c = nullptr, unsigned long long* maskL = nullptr, bool mask_is_clear = false,
+                   const double* distRL = nullptr, const double* kthL = nullptr);
+// (distRL [nR][k1] + kthL [nL], both or neither: the right cells' exact distances to their listed left cells and each
+// left row's largest distance, +inf where unknown -- the probe then rejects without reading the row where it can)
 // ONE launch behind mutual_counts: offL [nsel + 1] = exclusive scan of the pairs per row of idxLR (popcount of maskL, or
 // cntL where k2 > 64), *totalP = their number; second_u = ascending positions r with cntR[r] > 0, offR [nR + 1] their
 // exclusive scan, *totalU their number (device words).

@@ -323,7 +323,7 @@ void Engine::upload(int nbatches, int d, const double* const* data, const int32_
 }
 
 void Engine::knn(const double* X, const int32_t* ref_rows, int nr, const double* Q, const int32_t* q_rows, int nq,
-                 int k, int32_t* idx, double* dist, const float* seed_d2, const double* centre) {
+                 int k, int32_t* idx, double* dist, const float* seed_d2, const double* centre, double* kth) {
     // query rows are split over ranks; the padded per-rank slices are contiguous, so the all-gather is in place
     int64_t b = 0, e = nq;
     bmx_shard_range_impl(nq, rank_, world_, &b, &e);
@@ -332,7 +332,7 @@ void Engine::knn(const double* X, const int32_t* ref_rows, int nr, const double*
     queued_work_s_ += 2e-10 * (double)nq * (double)nr * (double)d_ / 50.0;
     knn_ws_.wd_budget_s = wd_base_s_ > 0.0 ? wd_base_s_ + queued_work_s_ : 0.0;
     try {
-        knn_device(stream_, knn_ws_, X, ref_rows, nr, Q, q_rows, nq, d_, k, idx, dist, (int)b, (int)e, seed_d2, centre);
+        knn_device(stream_, knn_ws_, X, ref_rows, nr, Q, q_rows, nq, d_, k, idx, dist, (int)b, (int)e, seed_d2, centre, kth);
     } catch (const WatchdogTimeout&) {  // (the search's own waits go through knn_ws_.sync, not through wait())
         mark_dead();
         throw;
@@ -340,11 +340,12 @@ void Engine::knn(const double* X, const int32_t* ref_rows, int nr, const double*
     {
         const int64_t per = bmx_shard_rows_per_rank(nq, world_);
         // indices and distances of one search: grouped, RCCL sends them as one launch
-        const bool group = dist && comm_ && world_ > 1 && rccl::api().GroupStart && rccl::api().GroupEnd;
+        const bool group = (dist || kth) && comm_ && world_ > 1 && rccl::api().GroupStart && rccl::api().GroupEnd;
         if (group) (void)rccl::api().GroupStart();
         try {
             exchange(idx, per * k * (int64_t)sizeof(int32_t));
             if (dist) exchange(dist, per * k * (int64_t)sizeof(double));
+            if (kth) exchange(kth, per * (int64_t)sizeof(double));
         } catch (...) {
             if (group) (void)rccl::api().GroupEnd();  // never leave the group open behind an error
             throw;
@@ -443,14 +444,16 @@ Engine::MnnOut Engine::find_mnn(const Node& left, const Node& right, int k, doub
     }
     const int64_t perL = bmx_shard_rows_per_rank(nsel, world_) * (int64_t)world_;
     int32_t* idxLR = idxLR_.reserve((size_t)std::max<int64_t>(1, perL) * o.k2);
-    knn(right.data.p, rrows, nR, left.data.p, qsel, nsel, o.k2, idxLR, nullptr, seed, mu_right);
+    double* kthL = kthL_.reserve((size_t)std::max<int64_t>(1, perL));
+    knn(right.data.p, rrows, nR, left.data.p, qsel, nsel, o.k2, idxLR, nullptr, seed, mu_right, kthL);
     int32_t* cntL = o.k2 > 64 ? cntL_.reserve(std::max(1, nsel)) : nullptr;
     int32_t* offL = offL_.reserve((size_t)nsel + 1);
     int32_t* partR = partR_.reserve((size_t)nR * o.k1);
     int32_t* cntR = cntR_.reserve(nR);
     int32_t* offR = offR_.reserve((size_t)nR + 1);
     int32_t* second_u = second_u_.reserve(nR);
-    mutual_counts(stream_, idxLR, nsel, o.k2, idxRL, nR, o.k1, cntL, partR, cntR, lsel, offSel, maskL, /* mask_is_clear */ true);
+    mutual_counts(stream_, idxLR, nsel, o.k2, idxRL, nR, o.k1, cntL, partR, cntR, lsel, offSel, maskL, /* mask_is_clear */ true,
+                  distRL, kthL);
     const int32_t* cntR_cells = cntR;
     if (right.restrict_dups) {
         int32_t* fold = cntFold_.reserve(nR);

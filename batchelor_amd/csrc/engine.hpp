@@ -102,7 +102,8 @@ class Engine {
 
     // single primitives (also used by the host-pointer parity entry points)
     void knn(const double* X, const int32_t* ref_rows, int nr, const double* Q, const int32_t* q_rows, int nq, int k,
-             int32_t* idx, double* dist, const float* seed_d2 = nullptr, const double* centre = nullptr);
+             int32_t* idx, double* dist, const float* seed_d2 = nullptr, const double* centre = nullptr,
+             double* kth = nullptr);
     struct MnnOut {
         int64_t P = 0;
         int U = 0;
@@ -128,6 +129,7 @@ class Engine {
     int state_seq_ = 0;  // sequence number of the last publish_state (read_state)
     int stamp_gen_ = 0;  // number of the last search whose listed rows were stamped (stampL_ is never cleared)
     DevBuf<unsigned long long> maskL_;
+    DevBuf<double> kthL_;  // per selected left cell: the largest distance of its row of idxLR_ (+inf where unknown)
     DevBuf<double> distT_, distRL_, averaged_, loc_, vecs_, scal_, means_pool_;
     DevBuf<float> seedL_;
     DevBuf<double> corr_, asv_ws_, asv_scale_;

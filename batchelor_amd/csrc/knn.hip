@@ -166,7 +166,8 @@ __global__ __launch_bounds__(256) void knn_refine(const double* __restrict__ X, 
                                                   const float* __restrict__ seed_d2, int32_t* __restrict__ idx_out,
                                                   double* __restrict__ dist_out, int32_t* __restrict__ flagged,
                                                   double* __restrict__ flag_bound,
-                                                  unsigned long long* __restrict__ zero_slots, int q0) {
+                                                  unsigned long long* __restrict__ zero_slots, int q0,
+                                                  double* __restrict__ kth_out) {
     __shared__ __attribute__((aligned(16))) double sd[4][REFINE_MAXM];
     __shared__ int si[4][REFINE_MAXM];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -336,6 +337,7 @@ __global__ __launch_bounds__(256) void knn_refine(const double* __restrict__ X, 
         tmin = fminf(tmin, __shfl_xor(tmin, o));
         kth = fmax(kth, __shfl_xor(kth, o));
     }
+    const double kth_full = kth;  // the row's k-th distance (squared) where it has k entries
     // a seeded row only has to be right up to the seed distance: entries beyond it are of no use to the caller
     kth = fmin(kth, seed);
     if (lane == 0) {
@@ -345,6 +347,9 @@ __global__ __launch_bounds__(256) void knn_refine(const double* __restrict__ X, 
             flagged[1 + pos] = q;
             flag_bound[pos] = kth;  // the true k-th neighbour is no farther than the k-th candidate
         }
+        // the largest distance of a certified FULL row (what the intersection's probe rejects against without reading the
+        // row); +inf where the row is short or may still be rewritten: the probe then reads the row
+        if (kth_out) kth_out[q] = (proven && M >= k) ? sqrt(kth_full) : __builtin_inf();
     }
 }
 
@@ -368,7 +373,8 @@ __global__ __launch_bounds__(256) void knn_refine_half(const double* __restrict_
                                                        const float* __restrict__ seed_d2, int32_t* __restrict__ idx_out,
                                                        double* __restrict__ dist_out, int32_t* __restrict__ flagged,
                                                        double* __restrict__ flag_bound,
-                                                       unsigned long long* __restrict__ zero_slots) {
+                                                       unsigned long long* __restrict__ zero_slots,
+                                                       double* __restrict__ kth_out) {
     constexpr int KS = 32;
     __shared__ __attribute__((aligned(16))) double sd[8][KS];
     __shared__ int si[8][KS];
@@ -509,6 +515,7 @@ __global__ __launch_bounds__(256) void knn_refine_half(const double* __restrict_
     }
     // 4. certificate
     for (int o = 16; o > 0; o >>= 1) kth = fmax(kth, __shfl_xor(kth, o));
+    const double kth_full = kth;
     kth = fmin(kth, seed);
     if (hl == 0 && live) {
         const bool proven = kth < (double)tau[(int64_t)q * nchunks] * s2inv + qn2[q] - eps;
@@ -517,6 +524,7 @@ __global__ __launch_bounds__(256) void knn_refine_half(const double* __restrict_
             flagged[1 + pos] = q;
             flag_bound[pos] = kth;
         }
+        if (kth_out) kth_out[q] = (proven && M >= k) ? sqrt(kth_full) : __builtin_inf();
     }
 }
 
@@ -673,6 +681,11 @@ __global__ __launch_bounds__(256) void knn_exact_pick(const int32_t* __restrict_
         for (int m = n + lane; m < k; m += 64) idx_out[(int64_t)q * k + m] = -1;
 }
 
+__global__ void fill_f64(double* __restrict__ p, int n, double v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
 __global__ void fill_u32(uint32_t* __restrict__ p, int n, uint32_t v) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -726,7 +739,7 @@ int candidate_tiers(int d, int k, int nr, Tier out[2]) {
 // are listed in `flagged` (count in flagged[0]) with their k-th candidate distance in flag_bound.
 void candidate_pass(hipStream_t stream, KnnWorkspace& ws, const Tier& T, const double* X, const int32_t* ref_rows, int nr,
                     const double* Qs, const int32_t* qrs, int nq, int d, int k, int32_t* io, double* dout,
-                    int32_t* flagged, double* flag_bound, const float* seed_d2, const double* centre) {
+                    int32_t* flagged, double* flag_bound, const float* seed_d2, const double* centre, double* kth_out) {
     const int NS = T.NS, KS = T.KS;
     ws.last_variant = T.id == 1 ? 3 : 2;
     // queries per workgroup: 8 consumer waves of 32 in the fp16 kernel; 8 or 4 (long rows, long lists) in the bf16 kernel
@@ -887,11 +900,11 @@ void candidate_pass(hipStream_t stream, KnnWorkspace& ws, const Tier& T, const d
         if (nq_half > 0)                                                                                                            \
             hipLaunchKernelGGL(knn_refine_half<NC>, dim3(cdiv(nq_half, 8)), dim3(256), 0, stream, X, ref_rows, Qs, qrs, nq_half, d, k, \
                                nchunks, eps_k, eps_qr, eps_split, eps_den, T.id == 1 ? 1 : 0, cand, cand_v, tau, qn2, maxbits,       \
-                               seed_d2, io, dout, flagged, flag_bound, zero_slots);                                                 \
+                               seed_d2, io, dout, flagged, flag_bound, zero_slots, kth_out);                                        \
         if (nq > nq_half)                                                                                                           \
             hipLaunchKernelGGL(knn_refine<NC>, dim3(cdiv(nq - nq_half, 4)), dim3(256), 0, stream, X, ref_rows, Qs, qrs, nq, d, k, KS,  \
                                nchunks, eps_k, eps_qr, eps_split, eps_den, T.id == 1 ? 1 : 0, cand, cand_v, tau, qn2, maxbits,       \
-                               seed_d2, io, dout, flagged, flag_bound, nq_half > 0 ? nullptr : zero_slots, nq_half);                \
+                               seed_d2, io, dout, flagged, flag_bound, nq_half > 0 ? nullptr : zero_slots, nq_half, kth_out);       \
     } while (0)
         if (need == 0 || need > 16) BMX_REFINE(0);
         else if (need <= 2) BMX_REFINE(2);
@@ -1044,7 +1057,7 @@ void exact_search(hipStream_t stream, KnnWorkspace& ws, const double* X, const i
 // queries (Qs, qrs)[0, nq) through the tiers tiers[t ...]
 void search_tiers(hipStream_t stream, KnnWorkspace& ws, const Tier* tiers, int ntiers, int t, const double* X,
                   const int32_t* ref_rows, int nr, const double* Qs, const int32_t* qrs, int nq, int d, int k, int32_t* io,
-                  double* dout, const float* seed_d2 = nullptr, const double* centre = nullptr) {
+                  double* dout, const float* seed_d2 = nullptr, const double* centre = nullptr, double* kth_out = nullptr) {
     if (t >= ntiers) {
         exact_search(stream, ws, X, ref_rows, nr, Qs, qrs, d, k, io, dout, nullptr, nullptr, nq);
         return;
@@ -1052,7 +1065,10 @@ void search_tiers(hipStream_t stream, KnnWorkspace& ws, const Tier* tiers, int n
     int32_t* flagged = ws.flagged_t[t].reserve((size_t)nq + 1);
     double* bound = ws.flag_bound_t[t].reserve((size_t)nq + 1);
     // (what a seeded pass cannot settle goes on unseeded: the full k nearest serve the caller just as well)
-    candidate_pass(stream, ws, tiers[t], X, ref_rows, nr, Qs, qrs, nq, d, k, io, dout, flagged, bound, seed_d2, centre);
+    // (kth_out: the first tier's re-rank writes it for the rows it certifies; a row any later tier or the exact sweep rewrites
+    // keeps +inf there, which only costs the intersection's probe a row read)
+    candidate_pass(stream, ws, tiers[t], X, ref_rows, nr, Qs, qrs, nq, d, k, io, dout, flagged, bound, seed_d2, centre,
+                   t == 0 ? kth_out : nullptr);
     if (ws.optimistic && t == 0) {
         // Optimistic run (the merge engine): no read-back inside a search.  Practically every query is certified by the
         // first tier (config 3: 1-6 of 3 million per step are not), so the bounded FP64 sweep for the few that are not is
@@ -1102,7 +1118,7 @@ void search_tiers(hipStream_t stream, KnnWorkspace& ws, const Tier* tiers, int n
 
 void knn_device(hipStream_t stream, KnnWorkspace& ws, const double* X, const int32_t* ref_rows, int nr,
                 const double* Q, const int32_t* q_rows, int nq_total, int d, int k, int32_t* idx_out,
-                double* dist_out, int q_begin, int q_end, const float* seed_d2, const double* centre) {
+                double* dist_out, int q_begin, int q_end, const float* seed_d2, const double* centre, double* kth_out) {
     (void)nq_total;
     const int nq = q_end - q_begin;
     if (nq <= 0 || k <= 0) return;
@@ -1121,8 +1137,12 @@ void knn_device(hipStream_t stream, KnnWorkspace& ws, const double* X, const int
     const int ntiers = ws.force_exact ? 0 : candidate_tiers(d, k, nr, tiers);
     ws.last_exact = 0;
     ws.last_flagged_tier[0] = ws.last_flagged_tier[1] = 0;
+    if (kth_out && ntiers == 0) {  // no candidate tier takes the shape: every row read by the probe
+        hipLaunchKernelGGL(fill_f64, dim3(cdiv(nq, 256)), dim3(256), 0, stream, kth_out + q_begin, nq, __builtin_inf());
+        BMX_LAUNCH_CHECK();
+    }
     search_tiers(stream, ws, tiers, ntiers, 0, X, ref_rows, nr, Qs, qrs, nq, d, k, io, dout,
-                 seed_d2 ? seed_d2 + q_begin : nullptr, centre);
+                 seed_d2 ? seed_d2 + q_begin : nullptr, centre, kth_out ? kth_out + q_begin : nullptr);
     if (ntiers > 0) ws.exact_total += ws.last_exact;
     if (ntiers > 0) ws.tier2_total += ws.last_flagged_tier[0] * (ntiers > 1 ? 1 : 0);
 }

@@ -159,16 +159,22 @@ __global__ void mutual_right(const int32_t* __restrict__ idxLR, int k2, const in
 __global__ __launch_bounds__(256) void mutual_right_wide(const int32_t* __restrict__ idxLR, int k2,
                                                          const int32_t* __restrict__ idxRL, int nR, int k1,
                                                          const int32_t* __restrict__ lpos2c, int32_t* __restrict__ partR,
-                                                         int32_t* __restrict__ cntR, unsigned long long* __restrict__ maskL) {
+                                                         int32_t* __restrict__ cntR, unsigned long long* __restrict__ maskL,
+                                                         const double* __restrict__ distRL, const double* __restrict__ kthL) {
     const int r = blockIdx.x * 8 + (threadIdx.x >> 5), j = threadIdx.x & 31;
     const bool live = r < nR && j < k1;
     const int32_t l = live ? idxRL[(int64_t)r * k1 + j] : -1;
     bool hit = false;
     if (l >= 0) {
         const int64_t c = lpos2c ? lpos2c[l] : l;
-        const int j2 = row_find(idxLR + c * k2, k2, r);
-        hit = j2 >= 0;
-        if (hit && maskL) atomicOr(maskL + c, 1ull << j2);
+        // the left cell's row holds its k2 nearest right cells, the farthest at kthL[c]: a right cell farther than that is
+        // not in it -- 8 bytes read instead of the row's 4 k2 for the ~93 % of the probes that fail (the distance is the same
+        // double from either side: the FP64 sum is symmetric bit for bit).  At or inside it (ties included): the row decides.
+        if (!(kthL && distRL[(int64_t)r * k1 + j] > kthL[c])) {
+            const int j2 = row_find(idxLR + c * k2, k2, r);
+            hit = j2 >= 0;
+            if (hit && maskL) atomicOr(maskL + c, 1ull << j2);
+        }
     }
     int rank = 0, m = 0;
     for (int t = 0; t < k1; ++t) {  // (k1 is uniform: every lane of the half-wave takes part in the shuffles)
@@ -218,7 +224,11 @@ __global__ void seed_from_lists(const int32_t* __restrict__ idxRL, const double*
     const double dd = distRL[i] * distRL[i] * (1.0 + 1e-15);  // sqrt, then squared again: never below the true value
     float f = (float)dd;
     if ((double)f < dd) f = __uint_as_float(__float_as_uint(f) + 1u);  // dd >= 0: the next float up
-    atomicMax(seed_bits + lpos2c[idxRL[i]], __float_as_uint(f));       // non-negative floats order like their bits
+    // non-negative floats order like their bits.  A cell is listed ~25 times at the first merge; only the few entries that
+    // raise its running maximum need the atomic (a stale read merely sends one too many)
+    uint32_t* slot = seed_bits + lpos2c[idxRL[i]];
+    const uint32_t bits = __float_as_uint(f);
+    if (bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, bits);
 }
 
 __global__ void compose_rows(const int32_t* __restrict__ sel, int n, const int32_t* __restrict__ rows,
@@ -251,7 +261,7 @@ void exclusive_scan_i32(hipStream_t stream, ScanWorkspace& ws, const int32_t* in
 
 void mutual_counts(hipStream_t stream, const int32_t* idxLR, int nL, int k2, const int32_t* idxRL, int nR, int k1,
                    int32_t* cntL, int32_t* partR, int32_t* cntR, const int32_t* lsel, const int32_t* lpos2c,
-                   unsigned long long* maskL, bool mask_is_clear) {
+                   unsigned long long* maskL, bool mask_is_clear, const double* distRL, const double* kthL) {
     // k2 <= 64 (and a mask buffer): the right cells' probe finds every mutual pair once and marks it on both sides (the
     // pairs of a left cell are then the popcount of its mask); otherwise the left side is probed separately into cntL
     const bool fused = maskL != nullptr && k2 <= 64;
@@ -264,7 +274,7 @@ void mutual_counts(hipStream_t stream, const int32_t* idxLR, int nL, int k2, con
     if (nR > 0) {
         if (k1 <= 32)
             hipLaunchKernelGGL(mutual_right_wide, dim3(cdiv(nR, 8)), dim3(256), 0, stream, idxLR, k2, idxRL, nR, k1, lpos2c,
-                               partR, cntR, fused ? maskL : nullptr);
+                               partR, cntR, fused ? maskL : nullptr, distRL, kthL);
         else
             hipLaunchKernelGGL(mutual_right, dim3(cdiv(nR, 256)), dim3(256), 0, stream, idxLR, k2, idxRL, nR, k1, lpos2c,
                                partR, cntR, fused ? maskL : nullptr);

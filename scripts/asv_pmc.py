@@ -32,6 +32,6 @@ for i, d in enumerate(oa):
     rows.append(rec)
 rows.sort(key=lambda r: -r["GRBM_GUI_ACTIVE"])
 tot = {k: sum(r.get(k, 0.0) for r in rows) for k in ("hbm_read_bytes", "hbm_write_bytes")}
-json.dump({"kernel": "asv_tile_kernel<4>", "workload": "config5 --var-adj",
+json.dump({"kernel": "asv_tile_kernel<13>", "workload": "config5 --var-adj",
            "method": __doc__, "all_launches_total": tot, "dispatches": rows[:3]}, open(sys.argv[4], "w"), indent=1)
 print(json.dumps(rows[:3], indent=1)); print(tot)

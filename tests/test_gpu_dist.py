@@ -37,8 +37,9 @@ def test_n_rank_engine_equals_single_rank(tmp_path, world, var_adj):
             assert np.array_equal(got[f"pl{m}"], ref.merge_info.pairs[m][0])
             assert np.array_equal(got[f"pr{m}"], ref.merge_info.pairs[m][1])
         assert np.array_equal(got["lost_var"], ref.merge_info.lost_var)
-        # per merge: index + distance + index gathers, tricube index + distance (+ the scalings with var_adj)
-        assert int(got["calls"]) == 2 * (3 + 2 + (1 if var_adj else 0))
+        # per merge: index + distance gathers of the first search, index + k-th distance of the second, index + distance of
+        # the tricube search (+ the scalings with var_adj)
+        assert int(got["calls"]) == 2 * (2 + 2 + 2 + (1 if var_adj else 0))
 
 
 @pytest.mark.parametrize("world", [2, 3])
@@ -125,7 +126,7 @@ eng.upload(B)
 eng.run()
 got = eng.download()
 st = eng.exchange_stats()
-assert st["calls"] == 2 * (3 + 2), st      # per merge: index + distance + index gathers, tricube index + distance
+assert st["calls"] == 2 * (2 + 2 + 2), st  # per merge: index + distance, index + k-th distance, tricube index + distance
 assert np.array_equal(got.corrected, ref.corrected)
 for (a, b), (c, d) in zip(got.merge_info.pairs, ref.merge_info.pairs):
     assert np.array_equal(a, c) and np.array_equal(b, d)
