@@ -589,10 +589,12 @@ __global__ __launch_bounds__(256) void knn_exact_select(const double* __restrict
 
 // ---------------------------------------------------------------------------------------------------
 // 4b. fast exact path for a FEW flagged queries: the k-th candidate distance bounds the true k-th neighbour from
-//     above, so one pass that evaluates every reference row against every flagged query in FP64 and keeps the
-//     references within that bound (a handful per query) replaces the full per-query rescan.
+//     above, so one pass that stages each reference tile once in LDS, evaluates it against every flagged query in
+//     FP64 and keeps the references within that bound (a handful per query) replaces the full per-query rescan.
 //     A query whose list overflows (massive exact ties) is handed to the full scan.
 // ---------------------------------------------------------------------------------------------------
+constexpr int XF_TILE = 64;    // reference rows per staged tile
+constexpr int XF_QCH = 16;     // flagged queries staged at a time
 constexpr int XF_CAP = 256;    // kept references per flagged query
 
 __global__ __launch_bounds__(256) void knn_exact_filter(const double* __restrict__ X,
@@ -603,28 +605,90 @@ __global__ __launch_bounds__(256) void knn_exact_filter(const double* __restrict
                                                         const double* __restrict__ flag_bound, int nflag, int dev_cap,
                                                         int32_t* __restrict__ xcnt, double* __restrict__ xd,
                                                         int32_t* __restrict__ xi) {
-    if (dev_cap > 0) {  // launched without the host knowing the count: nothing flagged (the rule) -> nothing to do
+    extern __shared__ __attribute__((aligned(16))) char smem_x[];
+    if (dev_cap > 0) {  // launched without the host knowing the count: nothing flagged (the rule) -> nothing staged
         nflag = flagged[0];
         if (nflag <= 0 || nflag > dev_cap) return;  // (more than the cap: knn_exact_pick raises the run's invalid flag)
     }
-    // A thread per reference row, the row read straight from global memory (16-byte pieces where the rows allow; a thread's
-    // row is contiguous, so every cache line fetched is used in full) once per flagged query -- the second and later reads come
-    // out of the L2.  Round 3 staged 64-row tiles through the LDS element by element (an integer division per double):
-    // 380 us for a sweep of 700 000 rows that moves 280 MB.  The sum is exact_d2's: left to right, no contraction.
-    for (int r = blockIdx.x * 256 + threadIdx.x; r < nr; r += gridDim.x * 256) {
-        const double* xr = X + (int64_t)(ref_rows ? ref_rows[r] : r) * d;
-        for (int f = 0; f < nflag; ++f) {
-            const int q = flagged[1 + f];
-            const double* qv = Q + (int64_t)(q_rows ? q_rows[q] : q) * d;
-            const double s = exact_d2(qv, xr, d);
-            if (s <= flag_bound[f]) {
-                const int pos = atomicAdd(&xcnt[f], 1);
-                if (pos < XF_CAP) {
-                    xd[(int64_t)f * XF_CAP + pos] = s;
-                    xi[(int64_t)f * XF_CAP + pos] = r;
+    // Tiles of 64 reference rows through the LDS: a wave copies a row per instruction (lanes along the row: 16-byte pieces
+    // where the rows allow, one coalesced read of its 8 d bytes), then every thread takes one row of the tile against every
+    // flagged query -- exact_d2's sum, left to right.  (Round 3 staged element by element with an integer division per
+    // double: 380 us for a sweep of 700 000 rows that moves 280 MB; a thread per row straight from global memory: worse,
+    // 64 cache lines per load instruction.)
+    double* xs = reinterpret_cast<double*>(smem_x);  // [XF_TILE][d + 1]  (+1: breaks the bank stride)
+    const int ld = d + 1;
+    double* qs = xs + XF_TILE * ld;                  // [XF_QCH][d + 1] flagged queries
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const bool wide = (d & 1) == 0;
+    const int np = wide ? d >> 1 : d;  // pieces per row
+    for (int r0 = blockIdx.x * XF_TILE; r0 < nr; r0 += gridDim.x * XF_TILE) {
+        const int rows_here = min(XF_TILE, nr - r0);
+        if (wide && np <= 64) {
+            // all 16 rows of this wave asked for before the first is stored: their round trips overlap
+            typedef double d2 __attribute__((ext_vector_type(2)));
+            d2 v[XF_TILE / 4];
+#pragma unroll
+            for (int i = 0; i < XF_TILE / 4; ++i) {
+                const int rr = w + 4 * i;
+                v[i] = d2{0.0, 0.0};
+                if (rr < rows_here && lane < np)
+                    v[i] = reinterpret_cast<const d2*>(X + (int64_t)(ref_rows ? ref_rows[r0 + rr] : r0 + rr) * d)[lane];
+            }
+#pragma unroll
+            for (int i = 0; i < XF_TILE / 4; ++i) {
+                const int rr = w + 4 * i;
+                if (rr < rows_here && lane < np) {
+                    xs[rr * ld + 2 * lane] = v[i][0];
+                    xs[rr * ld + 2 * lane + 1] = v[i][1];
+                }
+            }
+        } else {
+            for (int rr = w; rr < rows_here; rr += 4) {
+                const double* src = X + (int64_t)(ref_rows ? ref_rows[r0 + rr] : r0 + rr) * d;
+                for (int p = lane; p < np; p += 64) {
+                    if (wide) {
+                        typedef double d2 __attribute__((ext_vector_type(2)));
+                        const d2 v = reinterpret_cast<const d2*>(src)[p];
+                        xs[rr * ld + 2 * p] = v[0];
+                        xs[rr * ld + 2 * p + 1] = v[1];
+                    } else {
+                        xs[rr * ld + p] = src[p];
+                    }
                 }
             }
         }
+        __syncthreads();
+        const int rr = tid & (XF_TILE - 1);
+        const double* xr = xs + rr * ld;
+        // the flagged queries, XF_QCH at a time, through the LDS as well: read from global memory inside the sum, every one of
+        // the d steps of every thread's chain waited for an L2 round trip (0.8 ms per config-3 step for ~25 queries)
+        for (int f0 = 0; f0 < nflag; f0 += XF_QCH) {
+            const int nq_here = min(XF_QCH, nflag - f0);
+            for (int e = tid; e < nq_here * d; e += 256) {
+                const int fq = e / d, c = e - fq * d;
+                const int q = flagged[1 + f0 + fq];
+                qs[fq * ld + c] = Q[(int64_t)(q_rows ? q_rows[q] : q) * d + c];
+            }
+            __syncthreads();
+            for (int fq = tid / XF_TILE; fq < nq_here && rr < rows_here; fq += 256 / XF_TILE) {
+                const double* qv = qs + fq * ld;
+                double s = 0.0;
+                for (int c = 0; c < d; ++c) {
+                    const double t = qv[c] - xr[c];
+                    s += t * t;
+                }
+                const int f = f0 + fq;
+                if (s <= flag_bound[f]) {
+                    const int pos = atomicAdd(&xcnt[f], 1);
+                    if (pos < XF_CAP) {
+                        xd[(int64_t)f * XF_CAP + pos] = s;
+                        xi[(int64_t)f * XF_CAP + pos] = r0 + rr;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        __syncthreads();  // the tile is restaged
     }
 }
 
@@ -1028,8 +1092,10 @@ void exact_search(hipStream_t stream, KnnWorkspace& ws, const double* X, const i
         ws.xcnt_clear = false;  // (the lists' counters are left as the sweep filled them)
         BMX_HIP(hipMemsetAsync(xcnt, 0, (size_t)count * sizeof(int32_t), stream));
         BMX_HIP(hipMemsetAsync(slow, 0, sizeof(int32_t), stream));
-        hipLaunchKernelGGL(knn_exact_filter, dim3(std::min(cdiv(nr, 256), 8192)), dim3(256), 0, stream, X, ref_rows, nr, Qs, qrs, d,
-                           list, bounds, count, 0, xcnt, xd, xi);
+        const size_t lds = (size_t)(XF_TILE + XF_QCH) * (d + 1) * sizeof(double);
+        ensure_dynamic_lds(reinterpret_cast<const void*>(&knn_exact_filter), lds);
+        hipLaunchKernelGGL(knn_exact_filter, dim3(std::min(cdiv(nr, XF_TILE), 16384)), dim3(256), lds, stream, X, ref_rows, nr, Qs, qrs,
+                           d, list, bounds, count, 0, xcnt, xd, xi);
         BMX_LAUNCH_CHECK();
         hipLaunchKernelGGL(knn_exact_pick, dim3(cdiv(count, 4)), dim3(256), 0, stream, list, count, 0, k, seeded ? 1 : 0, xcnt,
                            xd, xi, io, dout, slow, (int32_t*)nullptr);
@@ -1083,8 +1149,10 @@ void search_tiers(hipStream_t stream, KnnWorkspace& ws, const Tier* tiers, int n
         }
         double* xd = ws.xd.reserve((size_t)KnnWorkspace::OPT_CAP * XF_CAP);
         int32_t* xi = ws.xi.reserve((size_t)KnnWorkspace::OPT_CAP * XF_CAP);
-        hipLaunchKernelGGL(knn_exact_filter, dim3(std::min(cdiv(nr, 256), 8192)), dim3(256), 0, stream, X, ref_rows, nr, Qs, qrs, d,
-                           flagged, bound, 0, KnnWorkspace::OPT_CAP, xcnt, xd, xi);
+        const size_t lds = (size_t)(XF_TILE + XF_QCH) * (d + 1) * sizeof(double);
+        ensure_dynamic_lds(reinterpret_cast<const void*>(&knn_exact_filter), lds);
+        hipLaunchKernelGGL(knn_exact_filter, dim3(std::min(cdiv(nr, XF_TILE), 16384)), dim3(256), lds, stream, X, ref_rows, nr, Qs, qrs,
+                           d, flagged, bound, 0, KnnWorkspace::OPT_CAP, xcnt, xd, xi);
         BMX_LAUNCH_CHECK();
         hipLaunchKernelGGL(knn_exact_pick, dim3(KnnWorkspace::OPT_CAP / 4), dim3(256), 0, stream, flagged, 0,
                            KnnWorkspace::OPT_CAP, k, seed_d2 ? 1 : 0, xcnt, xd, xi, io, dout, (int32_t*)nullptr, opt);
