@@ -149,7 +149,9 @@ Engine::~Engine() {
     if (scal_pin_ && scal_pin_bytes_ > KnnWorkspace::kPinnedSmall) (void)hipHostFree(scal_pin_);
     else KnnWorkspace::pinned_small_give(scal_pin_);
     if (stream_) (void)hipStreamSynchronize(stream_);  // (a pair-list copy may still be on its way into the pinned block)
+    if (copy_stream_) (void)hipStreamSynchronize(copy_stream_);
     if (pairs_ev_) (void)hipEventDestroy(pairs_ev_);
+    if (pairs_ready_ev_) (void)hipEventDestroy(pairs_ready_ev_);
     PinnedBlocks::give(PinnedBlocks::Blk{pairs_pin_, pairs_pin_bytes_});
     if (comm_ && rccl::api().CommDestroy) {
         if (stream_) (void)hipStreamSynchronize(stream_);
@@ -1256,6 +1258,9 @@ void Engine::stage_pairs() {
         fill(merges_[m].left_set);
         fill(merges_[m].right_set);
     }
+    // (the previous run's lists may still be on their way out of pairs_all_)
+    if (pairs_copy_pending_ && pairs_ev_) BMX_HIP(hipStreamWaitEvent(stream_, pairs_ev_, 0));
+    pairs_copy_pending_ = false;
     int32_t* dt = pairs_tab_.reserve(pairs_tab_host_.size());
     BMX_HIP(hipMemcpyAsync(dt, pairs_tab_host_.data(), pairs_tab_host_.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
     int32_t* all = pairs_all_.reserve((size_t)total);
@@ -1273,15 +1278,22 @@ void Engine::stage_pairs() {
     const size_t bytes = (size_t)total * sizeof(int32_t);
     if (bytes <= ((size_t)64 << 20)) {  // (beyond that the lists stay on the device and go out through the staging ring)
         if (bytes > pairs_pin_bytes_) {
+            if (pairs_ev_ && pairs_pin_) guarded_event_sync(pairs_ev_);  // (an earlier run's copy into the block that goes away)
             PinnedBlocks::give(PinnedBlocks::Blk{pairs_pin_, pairs_pin_bytes_});
             const PinnedBlocks::Blk b = PinnedBlocks::take(bytes);
             pairs_pin_ = b.p;
             pairs_pin_bytes_ = b.bytes;
         }
+        // on the copy stream (a DMA engine), behind the remap kernels: the engine's stream is free for the next run
         if (!pairs_ev_) BMX_HIP(hipEventCreateWithFlags(&pairs_ev_, hipEventDisableTiming));
-        BMX_HIP(hipMemcpyAsync(pairs_pin_, all, bytes, hipMemcpyDeviceToHost, stream_));
-        BMX_HIP(hipEventRecord(pairs_ev_, stream_));
+        if (!pairs_ready_ev_) BMX_HIP(hipEventCreateWithFlags(&pairs_ready_ev_, hipEventDisableTiming));
+        if (!copy_stream_) BMX_HIP(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+        BMX_HIP(hipEventRecord(pairs_ready_ev_, stream_));
+        BMX_HIP(hipStreamWaitEvent(copy_stream_, pairs_ready_ev_, 0));
+        BMX_HIP(hipMemcpyAsync(pairs_pin_, all, bytes, hipMemcpyDeviceToHost, copy_stream_));
+        BMX_HIP(hipEventRecord(pairs_ev_, copy_stream_));
         pairs_pinned_ = true;
+        pairs_copy_pending_ = true;
     }
 }
 

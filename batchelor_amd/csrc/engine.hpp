@@ -178,7 +178,8 @@ class Engine {
     void* pairs_pin_ = nullptr;
     size_t pairs_pin_bytes_ = 0;
     bool pairs_pinned_ = false;  // the last run's lists are (on their way) in pairs_pin_
-    hipEvent_t pairs_ev_ = nullptr;
+    hipEvent_t pairs_ev_ = nullptr, pairs_ready_ev_ = nullptr;
+    bool pairs_copy_pending_ = false;
     void check_alive() const;
     void mark_dead();
     double wd_base_s_ = 60.0;
