@@ -204,7 +204,14 @@ inline void guarded_event_sync(hipEvent_t ev, double budget_s = 120.0) {
         const hipError_t e = hipEventQuery(ev);
         if (e == hipSuccess) return;
         (void)hipGetLastError();
-        if (e != hipErrorNotReady) throw Error(BMX_ERR_HIP, std::string("hipEventQuery failed: ") + hipGetErrorString(e));
+        if (e != hipErrorNotReady) {
+            // A ring's event outlives the engines that record it: one last recorded on the stream of an engine that is gone
+            // cannot be queried any more (the runtime answers with an error of its stream-capture family).  That engine
+            // drained its streams before it went, so there is nothing left to wait for; a blocking wait settles the rest.
+            (void)hipEventSynchronize(ev);
+            (void)hipGetLastError();
+            return;
+        }
         const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (el > budget_s) throw WatchdogTimeout("watchdog: a staged host transfer did not finish in time");
         if (el > 2e-3) std::this_thread::sleep_for(std::chrono::microseconds(50));

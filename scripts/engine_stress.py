@@ -20,7 +20,7 @@ for case in range(cases):
     sizes = [int(rng.choice([60, 150, 400, 900, 2000, 4500])) for _ in range(nb)]
     d = int(rng.choice([2, 5, 10, 20, 30, 50, 64, 80, 100]))
     kw = {}
-    mode = int(rng.integers(0, 6))
+    mode = int(rng.integers(0, 7))
     if mode == 1:
         # (k <= 2 with more than two batches is degenerate -- a cell with one pair lands on its partner up to an ulp and
         # the next merge has to tell the two apart: checked up to such twins, tests/test_gpu_degenerate_k.py)
@@ -33,6 +33,8 @@ for case in range(cases):
         kw["auto_merge"] = True
     elif mode == 5:
         kw["restrict"] = [np.sort(rng.choice(n, size=max(30, n // 2), replace=False)) + 1 for n in sizes]
+    elif mode == 6:  # any R subsetting vector: unsorted, cells named more than once
+        kw["restrict"] = [rng.choice(n, size=max(30, n // 2), replace=True) + 1 for n in sizes]
     print("case", case, sizes, d, {k: (v if k != "restrict" else "...") for k, v in kw.items()}, flush=True)
     B = synth_batches(2000 + seed * 1000 + case, sizes, d)
     try:
