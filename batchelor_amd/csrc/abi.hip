@@ -132,7 +132,13 @@ int32_t bmx_device_count(void) {
 void bmx_free(void* p) { std::free(p); }
 
 int32_t bmx_set_device(int32_t device) {
-    return guarded([&] { BMX_HIP(hipSetDevice(device)); });
+    return guarded([&] {
+        const hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();  // (the runtime keeps the error for the next hipGetLastError: a later launch check would trip)
+            throw bmx::Error(BMX_ERR_HIP, std::string("hipSetDevice failed: ") + hipGetErrorString(e));
+        }
+    });
 }
 
 void bmx_trim_caches(void) {

@@ -172,3 +172,38 @@ def test_watchdog_turns_a_stuck_stream_into_an_error():
     fresh.run()
     assert np.all(np.isfinite(fresh.download().corrected))
     fresh.close()
+
+
+def test_testing_hooks_device_choice_and_cache_trim():
+    """bmx_dev_set refuses knobs it does not know (a typo must not silently run the default), bmx_set_device reports the
+    runtime's error for a device that is not there, bmx_trim_caches hands the parked device blocks back and the next call
+    simply allocates again."""
+    import batchelor_amd as bx
+    from batchelor_amd import _lib
+    L = _lib.lib()
+    assert L.bmx_dev_set(b"no_such_knob", 1) != 0 and "unknown knob" in L.bmx_last_error().decode()
+    assert L.bmx_dev_set(b"force_c", 2) == 0 and L.bmx_dev_set(b"reset", 0) == 0
+    assert L.bmx_set_device(0) == 0
+    assert L.bmx_set_device(4096) != 0
+    assert L.bmx_set_device(0) == 0
+    B = synth_batches(21, [700, 600], 10)
+    a = bx.reducedMNN(*B)
+    L.bmx_trim_caches.restype = None
+    L.bmx_trim_caches()
+    b = bx.reducedMNN(*B)
+    assert np.array_equal(a.corrected, b.corrected)
+
+
+def test_restrict_with_repeats_under_variance_adjustment(oracle):
+    # repeated cells are repeated points to adjust_shift_variance's sums as well (the reference loops over the restrict
+    # vectors as they are, src/adjust_shift_variance.cpp:74,118)
+    import batchelor_amd as bx
+    rng = np.random.default_rng(79)
+    B = synth_batches(9, [500, 400], 15)
+    keep = [rng.choice(500, 300, replace=True) + 1, rng.choice(400, 250, replace=True) + 1]
+    out = bx.reducedMNN(*B, restrict=keep, var_adj=True, sigma=1.0)
+    ref = oracle.reduced_mnn(*B, restrict=keep, var_adj=True, sigma=1.0)
+    assert np.array_equal(out.merge_info.pairs[0][0], ref.merge_info.pairs[0][0])
+    assert np.array_equal(out.merge_info.pairs[0][1], ref.merge_info.pairs[0][1])
+    close = np.isclose(out.corrected, ref.corrected, rtol=1e-5, atol=1e-9).all(axis=1)
+    assert close.mean() > 0.99, close.mean()
