@@ -123,7 +123,7 @@ class Engine {
     KnnWorkspace knn_ws_;
     ScanWorkspace scan_ws_;
     ReduceWorkspace red_ws_;
-    DevBuf<int32_t> idxLR_, idxRL_, cntL_, offL_, partR_, cntR_, flagR_, offR_, second_u_, second_rows_, idxT_;
+    DevBuf<int32_t> idxLR_, idxRL_, cntL_, offL_, partR_, cntR_, offR_, second_u_, second_rows_, idxT_;
     DevBuf<int32_t> stampL_, offSel_, lsel_, qsel_, cntFold_;
     int64_t optimistic_retries_ = 0;  // runs of this engine that started over with host-checked searches (run())
     int state_seq_ = 0;  // sequence number of the last publish_state (read_state)

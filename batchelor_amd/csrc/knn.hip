@@ -148,13 +148,6 @@ __global__ void seed_tau_kernel(const float* __restrict__ seed_d2, const double*
     tau_g[q] = q < nq ? min(tau_g[q], o) : o;  // the image is order-preserving: min of images = image of the min
 }
 
-__global__ void margin_kernel(const double* __restrict__ qn2, const unsigned long long* __restrict__ max_rn2_bits, int nq,
-                              int nq_pad, PassEps pe, float* __restrict__ margin) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nq_pad) return;
-    margin[q] = q < nq ? pass_margin(qn2[q], __longlong_as_double((long long)*max_rn2_bits), pe) : 0.f;
-}
-
 template <int REFINE_NC>  // pieces of 8 doubles (one 16-byte load per lane of a quad) a row may have; 0: lane-per-row gather
 __global__ __launch_bounds__(256) void knn_refine(const double* __restrict__ X, const int32_t* __restrict__ ref_rows,
                                                   const double* __restrict__ Q, const int32_t* __restrict__ q_rows,
