@@ -653,6 +653,14 @@ int32_t bmx_engine_pairs_into(bmx_engine_t* e, int32_t merge, int32_t* left, int
     });
 }
 
+int32_t bmx_engine_pairs_all_into(bmx_engine_t* e, int32_t nmerges, int32_t* const* left, int32_t* const* right,
+                                  const int64_t* capacity) {
+    return guarded([&] {
+        if (!left || !right || !capacity) throw bmx::Error(BMX_ERR_ARG, "bmx_engine_pairs_all_into: null argument");
+        e->impl->pairs_all_into(nmerges, left, right, capacity);
+    });
+}
+
 int32_t bmx_engine_merge_stats(bmx_engine_t* e, int32_t merge, int64_t* out6) {
     return guarded([&] { e->impl->merge_stats(merge, out6); });
 }

@@ -171,6 +171,49 @@ struct CacheScope {
     CacheScope& operator=(const CacheScope&) = delete;
 };
 
+// Streams of engines that went away cleanly are parked (a few per device) for the next engine: creating and destroying the
+// two streams of an engine cost ~1 ms of every one-shot call.  A parked stream is idle: its owner synchronised it.
+struct StreamPool {
+    static std::mutex& mu() {
+        static std::mutex* m = new std::mutex();
+        return *m;
+    }
+    static std::map<int, std::vector<hipStream_t>>& parked() {
+        static auto* p = new std::map<int, std::vector<hipStream_t>>();  // never destroyed (no HIP calls at process exit)
+        return *p;
+    }
+    static hipStream_t take() {
+        int dev = 0;
+        BMX_HIP(hipGetDevice(&dev));
+        {
+            std::lock_guard<std::mutex> lk(mu());
+            auto& v = parked()[dev];
+            if (!v.empty()) {
+                hipStream_t s = v.back();
+                v.pop_back();
+                return s;
+            }
+        }
+        hipStream_t s = nullptr;
+        BMX_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        return s;
+    }
+    // `s` belongs to the current device and has been synchronised without an error
+    static void give(hipStream_t s) {
+        if (!s) return;
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            std::lock_guard<std::mutex> lk(mu());
+            auto& v = parked()[dev];
+            if (v.size() < 8) {
+                v.push_back(s);
+                return;
+            }
+        }
+        (void)hipStreamDestroy(s);
+    }
+};
+
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies per device: remember (function, device) pairs already raised.
 inline void ensure_dynamic_lds(const void* func, size_t bytes) {
     static std::mutex mu;

@@ -104,7 +104,7 @@ void bmx_shard_range_impl(int64_t n, int rank, int world, int64_t* begin, int64_
 Engine::Engine(int device) : device_(device) {
     CacheScope cache_scope(&cache_);
     BMX_HIP(hipSetDevice(device_));
-    BMX_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    stream_ = StreamPool::take();
     scal_.reserve(4096);
 }
 
@@ -159,13 +159,11 @@ Engine::~Engine() {
     }
     for (hipEvent_t ev : up_ev_)
         if (ev) (void)hipEventDestroy(ev);
-    if (copy_stream_) {
-        (void)hipStreamSynchronize(copy_stream_);
-        (void)hipStreamDestroy(copy_stream_);
-    }
-    if (stream_) {
-        (void)hipStreamSynchronize(stream_);
-        (void)hipStreamDestroy(stream_);
+    // (a stream that reports an error is destroyed, an idle one parked for the next engine on this device)
+    for (hipStream_t s : {copy_stream_, stream_}) {
+        if (!s) continue;
+        if (hipStreamSynchronize(s) == hipSuccess) StreamPool::give(s);
+        else (void)hipStreamDestroy(s);
     }
     // the members' DevBufs are released after this body: into this engine's cache, which its own destructor frees
     DevBlockCache::current() = &cache_;
@@ -236,7 +234,7 @@ void Engine::exchange(void* buf, int64_t bytes_per_rank) {
 void Engine::ensure_uploaded(int b) {
     if (uploaded_[b]) return;
     const size_t bytes = (size_t)nrows_[b] * d_ * sizeof(double);
-    if (!copy_stream_) BMX_HIP(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+    if (!copy_stream_) copy_stream_ = StreamPool::take();
     if ((int)up_ev_.size() < B_) {
         const size_t old = up_ev_.size();
         up_ev_.resize(B_, nullptr);
@@ -1287,7 +1285,7 @@ void Engine::stage_pairs() {
         // on the copy stream (a DMA engine), behind the remap kernels: the engine's stream is free for the next run
         if (!pairs_ev_) BMX_HIP(hipEventCreateWithFlags(&pairs_ev_, hipEventDisableTiming));
         if (!pairs_ready_ev_) BMX_HIP(hipEventCreateWithFlags(&pairs_ready_ev_, hipEventDisableTiming));
-        if (!copy_stream_) BMX_HIP(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+        if (!copy_stream_) copy_stream_ = StreamPool::take();
         BMX_HIP(hipEventRecord(pairs_ready_ev_, stream_));
         BMX_HIP(hipStreamWaitEvent(copy_stream_, pairs_ready_ev_, 0));
         BMX_HIP(hipMemcpyAsync(pairs_pin_, all, bytes, hipMemcpyDeviceToHost, copy_stream_));
@@ -1311,6 +1309,41 @@ void Engine::pairs_into(int merge, int32_t* left, int32_t* right) {
     }
     download_pageable(left, pairs_all_.p + pairs_off_[merge], (size_t)P * sizeof(int32_t), stream_);
     download_pageable(right, pairs_all_.p + pairs_off_[merge] + P, (size_t)P * sizeof(int32_t), stream_);
+}
+
+void Engine::pairs_all_into(int nmerges, int32_t* const* left, int32_t* const* right, const int64_t* capacity) {
+    check_alive();
+    if (!root_) throw Error(BMX_ERR_ARG, "no finished run to download");
+    if (nmerges != (int)merges_.size()) throw Error(BMX_ERR_ARG, "bmx_engine_pairs_all_into: the last run had another number of merges");
+    for (int m = 0; m < nmerges; ++m) {
+        if (capacity[m] < merges_[m].npairs) throw Error(BMX_ERR_ARG, "bmx_engine_pairs_all_into: an array is too short");
+        if (merges_[m].npairs > 0 && (!left[m] || !right[m])) throw Error(BMX_ERR_ARG, "bmx_engine_pairs_all_into: null array");
+    }
+    if (!pairs_pinned_) {  // (lists beyond the pinned block's bound: through the staging ring, one by one)
+        for (int m = 0; m < nmerges; ++m) pairs_into(m, left[m], right[m]);
+        return;
+    }
+    CacheScope cache_scope(&cache_);
+    BMX_HIP(hipSetDevice(device_));
+    guarded_event_sync(pairs_ev_);
+    // the whole run's lists sit in pinned memory: ONE job of the host threads over all of them, in pieces of 64 KB (the
+    // first touch of the caller's fresh pages spreads over the threads like the bytes do)
+    struct Piece {
+        char* dst;
+        const char* src;
+        size_t bytes;
+    };
+    constexpr size_t kPiece = (size_t)64 << 10;
+    std::vector<Piece> pieces;
+    for (int m = 0; m < nmerges; ++m) {
+        const size_t bytes = (size_t)merges_[m].npairs * sizeof(int32_t);
+        const char* src = reinterpret_cast<const char*>(static_cast<const int32_t*>(pairs_pin_) + pairs_off_[m]);
+        for (int side = 0; side < 2; ++side) {
+            char* dst = reinterpret_cast<char*>(side == 0 ? left[m] : right[m]);
+            for (size_t o = 0; o < bytes; o += kPiece) pieces.push_back({dst + o, src + side * bytes + o, std::min(kPiece, bytes - o)});
+        }
+    }
+    HostPool::get().parallel_for(pieces.size(), [&](size_t i) { std::memcpy(pieces[i].dst, pieces[i].src, pieces[i].bytes); });
 }
 
 void Engine::pairs(int merge, int32_t** left, int32_t** right, int64_t* npairs) {

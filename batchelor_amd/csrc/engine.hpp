@@ -78,6 +78,8 @@ class Engine {
     void pairs(int merge, int32_t** left, int32_t** right, int64_t* npairs);
     int64_t pairs_count(int merge) const;
     void pairs_into(int merge, int32_t* left, int32_t* right);  // caller-allocated, pairs_count(merge) entries each
+    // every merge's lists in one pass of the host threads (capacity[m] >= pairs_count(m))
+    void pairs_all_into(int nmerges, int32_t* const* left, int32_t* const* right, const int64_t* capacity);
     void merge_stats(int merge, int64_t* out6) const;
     void set_profiling(bool on) { knn_ws_.profile = on; }
     // Host-side watchdog (bmx_common.hpp: guarded_stream_sync): every wait of a run has a deadline of base_s plus a term

@@ -100,11 +100,13 @@ class HostPool {
 };
 
 inline void host_parallel_memcpy(void* dst, const void* src, size_t bytes) {
-    constexpr size_t kPiece = (size_t)256 << 10;
-    if (bytes <= 2 * kPiece) {
+    if (bytes <= ((size_t)128 << 10)) {
         std::memcpy(dst, src, bytes);
         return;
     }
+    // (mid-size copies -- a merge's pair list into a freshly allocated R vector -- in finer pieces: what they cost is the
+    // first touch of the destination's pages, which spreads over the threads like the bytes do)
+    const size_t kPiece = bytes <= ((size_t)8 << 20) ? (size_t)64 << 10 : (size_t)256 << 10;
     const size_t n = (bytes + kPiece - 1) / kPiece;
     char* d = static_cast<char*>(dst);
     const char* s = static_cast<const char*>(src);

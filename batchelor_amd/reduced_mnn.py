@@ -182,14 +182,17 @@ class MnnEngine:
         return out
 
     def _pairs(self):
-        pairs = []
-        for m in range(self.nbatches - 1):
+        """Every merge's pair list: size queries, the caller's arrays (R's integer vectors), one filling call."""
+        L, nm = _lib.lib(), self.nbatches - 1
+        pairs, cap = [], np.zeros(nm, dtype=np.int64)
+        for m in range(nm):
             n = ctypes.c_int64(0)
-            _lib.check(_lib.lib().bmx_engine_pairs_into(self._h, m, None, None, ctypes.c_int64(0), ctypes.byref(n)))
-            pl, pr = np.empty(n.value, dtype=np.int32), np.empty(n.value, dtype=np.int32)  # R's integer vectors
-            _lib.check(_lib.lib().bmx_engine_pairs_into(self._h, m, _lib.i32p(pl), _lib.i32p(pr),
-                                                        ctypes.c_int64(n.value), ctypes.byref(n)))
-            pairs.append((pl, pr))
+            _lib.check(L.bmx_engine_pairs_into(self._h, m, None, None, ctypes.c_int64(0), ctypes.byref(n)))
+            cap[m] = n.value
+            pairs.append((np.empty(n.value, dtype=np.int32), np.empty(n.value, dtype=np.int32)))
+        lp = (ctypes.c_void_p * nm)(*[p[0].ctypes.data for p in pairs])
+        rp = (ctypes.c_void_p * nm)(*[p[1].ctypes.data for p in pairs])
+        _lib.check(L.bmx_engine_pairs_all_into(self._h, nm, lp, rp, cap.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))))
         return pairs
 
     def download(self, with_pairs=True, c_order=True) -> MnnResult:

@@ -165,6 +165,12 @@ int32_t bmx_engine_pairs(bmx_engine_t* e, int32_t merge, int32_t** left, int32_t
  * number of pairs; with left == right == NULL nothing else happens (size query), else capacity must be >= *npairs. */
 int32_t bmx_engine_pairs_into(bmx_engine_t* e, int32_t merge, int32_t* left, int32_t* right, int64_t capacity,
                               int64_t* npairs);
+/* Every merge's pairs in one call (what the shim does after a run: merge.info's `pairs` list, R/fastMNN.R:550-561):
+ * left[m] / right[m] receive merge m's pairs, capacity[m] >= its pair count (bmx_engine_pairs_into's size query);
+ * nmerges must be the number of merges of the last run.  One pass of the host threads over all lists instead of one
+ * per list. */
+int32_t bmx_engine_pairs_all_into(bmx_engine_t* e, int32_t nmerges, int32_t* const* left, int32_t* const* right,
+                                  const int64_t* capacity);
 /* Sizes of merge `merge`: out[0..5] = {cells searched on the left, on the right, MNN-involved right cells U,
  * pairs P, all left cells, all right cells} -- the inputs of the algorithmic flop / byte counts. */
 int32_t bmx_engine_merge_stats(bmx_engine_t* e, int32_t merge, int64_t* out6);

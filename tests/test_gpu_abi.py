@@ -52,6 +52,23 @@ def test_bmx_fast_mnn_one_shot_as_the_shim_calls_it(oracle):
             _lib.check(L.bmx_engine_pairs(h, m, ctypes.byref(pl), ctypes.byref(pr), ctypes.byref(n)))
             gl, gr = _lib.take_i32(pl, n.value), _lib.take_i32(pr, n.value)
             assert np.array_equal(gl, ref.merge_info.pairs[m][0]) and np.array_equal(gr, ref.merge_info.pairs[m][1])
+        # every merge's lists in one call into the caller's arrays (what the shim does for merge.info's `pairs`)
+        nm = nb - 1
+        cap = np.asarray([ref.merge_info.pairs[m][0].size for m in range(nm)], dtype=np.int64)
+        mine = [(np.full(c + 3, -7, dtype=np.int32), np.full(c + 3, -7, dtype=np.int32)) for c in cap]
+        lp = (ctypes.c_void_p * nm)(*[a.ctypes.data for a, _ in mine])
+        rp = (ctypes.c_void_p * nm)(*[b.ctypes.data for _, b in mine])
+        i64p = ctypes.POINTER(ctypes.c_int64)
+        _lib.check(L.bmx_engine_pairs_all_into(h, nm, lp, rp, (cap + 3).ctypes.data_as(i64p)))
+        for m in range(nm):
+            for got, want in zip(mine[m], ref.merge_info.pairs[m]):
+                assert np.array_equal(got[:cap[m]], want) and (got[cap[m]:] == -7).all()
+        short = cap.copy()
+        short[nm - 1] -= 1
+        assert L.bmx_engine_pairs_all_into(h, nm, lp, rp, short.ctypes.data_as(i64p)) != 0
+        assert "too short" in L.bmx_last_error().decode()
+        assert L.bmx_engine_pairs_all_into(h, nm + 1, lp, rp, cap.ctypes.data_as(i64p)) != 0
+        assert "number of merges" in L.bmx_last_error().decode()
         # error path: the reference's message, no engine handed back
         bad = np.asarray([1, 2, 2, 0, 0], dtype=np.int32)
         h2 = ctypes.c_void_p()
