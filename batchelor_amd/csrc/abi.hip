@@ -755,7 +755,8 @@ int32_t bmx_fast_mnn(int32_t nbatches, int32_t d, const double* const* data, con
         if (bmx::debug_timings()) {
             const auto t3 = std::chrono::steady_clock::now();
             auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-            fprintf(stderr, "[bmx] one-shot: create+upload %.2f ms, run %.2f ms, download %.2f ms\n", ms(t0, t1), ms(t1, t2), ms(t2, t3));
+            fprintf(stderr, "[bmx] one-shot: create+upload %.2f ms, run %.2f ms, download %.2f ms; %ld hipMallocs so far\n", ms(t0, t1),
+                    ms(t1, t2), ms(t2, t3), bmx::dev_malloc_calls());
         }
         if (out_engine) *out_engine = h.release();
     });

@@ -228,6 +228,12 @@ inline void ensure_dynamic_lds(const void* func, size_t bytes) {
     }
 }
 
+// (how many hipMallocs the process has made for DevBufs: printed with the one-shot call's timings under BMX_DEBUG=t)
+inline long& dev_malloc_calls() {
+    static long n = 0;
+    return n;
+}
+
 // Grow-only device buffer: the engine keeps these across calls so a steady-state run allocates nothing.
 template <typename T>
 struct DevBuf {
@@ -276,6 +282,7 @@ struct DevBuf {
                 p = static_cast<T*>(q);
                 cap = got / sizeof(T);
             } else {
+                ++dev_malloc_calls();
                 hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
                 if (e == hipErrorOutOfMemory) {  // parked blocks of earlier engines count as free memory
                     (void)hipGetLastError();

@@ -1034,12 +1034,16 @@ void Engine::run_once(const bmx_params_t& p, const int32_t* tree, int tree_len) 
                 t.batch = -1;
             }
         };
+        const auto t_run = std::chrono::steady_clock::now();
         for (int mdx = 0; mdx < nmerges; ++mdx) {
             const int cur = next_merge(done);
             TreeSlot& s = slots[cur];
             materialise(slots[s.left]);
             materialise(slots[s.right]);
             std::unique_ptr<Node> merged;
+            if (debug_timings())  // (host clock: when the host got to queue this merge)
+                fprintf(stderr, "[bmx]   merge %d queued from %.2f ms\n", mdx + 1,
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_run).count());
             merge_step(mdx, *slots[s.left].node, *slots[s.right].node, p, merged);
             slots[s.left].node.reset();
             slots[s.right].node.reset();
