@@ -15,6 +15,7 @@
 #include "bmx_common.hpp"
 #include "bmx_ops.hpp"
 #include "engine.hpp"
+#include "host_xfer.hpp"
 #include "rccl_dyn.hpp"
 
 struct bmx_engine {
@@ -169,6 +170,12 @@ int32_t bmx_dev_set(const char* name, int32_t value) {
         g_last_error = "bmx_dev_set: unknown knob '" + n + "'";
         return BMX_ERR_ARG;
     }
+    return BMX_OK;
+}
+
+int32_t bmx_dev_host_copy(void* dst, const void* src, int64_t bytes) {
+    if (bytes < 0 || (bytes > 0 && (!dst || !src))) return BMX_ERR_ARG;
+    bmx::host_parallel_memcpy(dst, src, (size_t)bytes);
     return BMX_OK;
 }
 

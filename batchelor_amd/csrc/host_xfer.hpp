@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
@@ -24,7 +25,11 @@
 
 namespace bmx {
 
-// A small persistent pool (the helpers only ever run memcpy: they never touch the caller's runtime, R or Python)
+// A small persistent pool (the helpers only ever run memcpy: they never touch the caller's runtime, R or Python).
+// A transfer is a burst of short jobs (one per 8 MB slot of the ring, ~150 us apart), so (a) the pieces of a job are claimed
+// with one compare-and-swap on a (generation, next index) word instead of under the pool's mutex, and (b) a helper that has
+// run out of work keeps watching the generation for a short while before it goes to sleep on the condition variable: with
+// mutex + wake-up per job, 13 threads moved a result faster than 25 and 49 were slower still.
 class HostPool {
   public:
     static HostPool& get() {
@@ -35,27 +40,36 @@ class HostPool {
     // fn(i) for i in [0, n); the calling thread takes part; returns when all are done
     void parallel_for(size_t n, const std::function<void(size_t)>& fn) {
         if (n == 0) return;
-        if (n == 1 || threads_.empty()) {
+        if (n == 1 || threads_.empty() || n >= 0xffffffffull) {
             for (size_t i = 0; i < n; ++i) fn(i);
             return;
         }
         std::unique_lock<std::mutex> run_lock(run_mu_);  // one job at a time
+        unsigned long long gen;
         {
             std::lock_guard<std::mutex> lk(mu_);
             fn_ = &fn;
             n_ = n;
-            next_ = 0;
-            pending_ = n;
-            ++generation_;
+            pending_.store(n, std::memory_order_relaxed);
+            gen = ++generation_;
+            ticket_.store(gen << 32, std::memory_order_release);
+            published_.store(gen, std::memory_order_release);
         }
         cv_.notify_all();
-        work();
-        std::unique_lock<std::mutex> lk(mu_);
-        done_cv_.wait(lk, [&] { return pending_ == 0; });
-        fn_ = nullptr;
+        work(gen, &fn, n);
+        for (int spin = 0; pending_.load(std::memory_order_acquire) != 0; ++spin) {
+            if (spin < 4000) {
+                relax();
+            } else {
+                std::unique_lock<std::mutex> lk(mu_);
+                done_cv_.wait(lk, [&] { return pending_.load(std::memory_order_acquire) == 0; });
+                break;
+            }
+        }
     }
 
   private:
+    static void relax() { __builtin_ia32_pause(); }
     HostPool() {
         unsigned hw = std::thread::hardware_concurrency();
         int n = hw >= 96 ? 24 : (hw >= 32 ? 12 : (hw >= 8 ? 6 : (hw >= 4 ? 3 : 0)));
@@ -66,28 +80,38 @@ class HostPool {
     void loop() {
         unsigned long long seen = 0;
         for (;;) {
+            // stay awake for a moment after a job: the next one of a burst is picked up without a futex round trip
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int spin = 0; published_.load(std::memory_order_acquire) == seen; ++spin) {
+                relax();
+                if ((spin & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) break;
+            }
+            const std::function<void(size_t)>* fn;
+            size_t n;
             {
                 std::unique_lock<std::mutex> lk(mu_);
                 cv_.wait(lk, [&] { return generation_ != seen; });
                 seen = generation_;
+                fn = fn_;
+                n = n_;
             }
-            work();
+            work(seen, fn, n);
         }
     }
-    void work() {
+    // Pieces of job `gen` (whose fn / n the caller read together with gen under mu_).  The ticket carries the job's
+    // generation: a helper that arrives late fails the compare and never calls a function that has gone away -- a job's fn
+    // is alive until its last claimed piece has reported back, and all n pieces are claimed before that.
+    void work(unsigned long long gen, const std::function<void(size_t)>* fn, size_t n) {
         for (;;) {
-            size_t i;
-            const std::function<void(size_t)>* fn;
-            {
-                std::lock_guard<std::mutex> lk(mu_);
-                if (!fn_ || next_ >= n_) return;
-                i = next_++;
-                fn = fn_;
+            unsigned long long v = ticket_.load(std::memory_order_acquire);
+            for (;;) {
+                if ((v >> 32) != (gen & 0xffffffffull) || (v & 0xffffffffull) >= n) return;
+                if (ticket_.compare_exchange_weak(v, v + 1, std::memory_order_acq_rel)) break;
             }
-            (*fn)(i);
-            {
+            (*fn)((size_t)(v & 0xffffffffull));
+            if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
                 std::lock_guard<std::mutex> lk(mu_);
-                if (--pending_ == 0) done_cv_.notify_all();
+                done_cv_.notify_all();
             }
         }
     }
@@ -95,8 +119,11 @@ class HostPool {
     std::mutex mu_, run_mu_;
     std::condition_variable cv_, done_cv_;
     const std::function<void(size_t)>* fn_ = nullptr;
-    size_t n_ = 0, next_ = 0, pending_ = 0;
-    unsigned long long generation_ = 0;
+    size_t n_ = 0;
+    unsigned long long generation_ = 0;  // (under mu_)
+    alignas(64) std::atomic<unsigned long long> ticket_{0};     // (generation << 32) | next piece
+    alignas(64) std::atomic<size_t> pending_{0};                // pieces not yet reported back
+    alignas(64) std::atomic<unsigned long long> published_{0};  // the generation, for the helpers that are still awake
 };
 
 inline void host_parallel_memcpy(void* dst, const void* src, size_t bytes) {

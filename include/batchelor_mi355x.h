@@ -98,6 +98,10 @@ void bmx_set_force_exact_knn(int32_t on);
  * "asv_fast" (the tiled form of adjust_shift_variance at any size), "exchange_always" (a single rank goes through its
  * exchange transport too), "refine_wave" (the exact re-rank spends a whole wave on every query), "reset" (all back to their defaults).  Unknown name: BMX_ERR_ARG. */
 int32_t bmx_dev_set(const char* name, int32_t value);
+/* Testing hook, needs no GPU: dst[0, bytes) = src[0, bytes) by the pool of host threads that moves the boundary's
+ * matrices between the caller's memory and the pinned staging buffers (csrc/host_xfer.hpp) -- lets a CPU test hammer that
+ * pool from several threads at once. */
+int32_t bmx_dev_host_copy(void* dst, const void* src, int64_t bytes);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * The merge engine: replaces .fast_mnn / .fast_mnn_core (R/fastMNN.R:398-562) and everything they call

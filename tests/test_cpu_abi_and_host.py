@@ -59,6 +59,34 @@ def test_shard_range_partitions_rows(built):
             assert covered == list(range(n))
 
 
+def test_host_thread_pool_copies_exactly_under_concurrent_callers(built):
+    """The pool behind the pinned staging ring (csrc/host_xfer.hpp): jobs of every size class, from several caller threads at
+    once (ctypes releases the GIL), bursts of short jobs back to back -- every byte where it belongs, none beyond."""
+    import threading
+    lib = built.lib()
+    lib.bmx_dev_host_copy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
+    sizes = [0, 1, 4097, 128 << 10, (128 << 10) + 1, 700001, (8 << 20) - 3, (8 << 20) + 5, 23 << 20]
+    errors = []
+
+    def caller(seed):
+        rng = np.random.default_rng(seed)
+        for rep in range(40):
+            n = sizes[int(rng.integers(len(sizes)))] if rep % 4 else int(rng.integers(1, 3 << 20))
+            src = rng.integers(0, 256, n + 64, dtype=np.uint8)
+            dst = np.full(n + 64, 0xA5, dtype=np.uint8)
+            rc = lib.bmx_dev_host_copy(dst.ctypes.data + 32, src.ctypes.data + 32, n)
+            if rc != 0 or not np.array_equal(dst[32:32 + n], src[32:32 + n]) or (dst[:32] != 0xA5).any() or (dst[32 + n:] != 0xA5).any():
+                errors.append((seed, rep, n, rc))
+
+    threads = [threading.Thread(target=caller, args=(s,)) for s in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]
+    assert lib.bmx_dev_host_copy(None, None, 5) != 0 and lib.bmx_dev_host_copy(None, None, 0) == 0
+
+
 # ---------------------------------------------------------------- tests/testthat/test-tree.R:4-104 on the PRODUCT code
 def test_product_binarize_tree_kats():
     from batchelor_amd.merge_tree import binarize_tree, encode_postorder, resolve_merge_order
