@@ -41,6 +41,19 @@ __global__ void publish_state(const int32_t* __restrict__ st, int32_t* host, int
     __hip_atomic_store(&host[8], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Several ranks, optimistic searches: a rank's "this search could not be completed on the device" flag (opt_state[0]) is
+// all-gathered with the search's lists and OR-ed into every rank's own flag, so that the next wait of EVERY rank sees it and
+// all of them start the run over at the same point (a rank that restarted alone would leave the others in a collective).
+__global__ void stage_opt_flag(const int32_t* __restrict__ st, int32_t* __restrict__ slot) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) slot[0] = st[0];
+}
+__global__ void merge_opt_flags(const int32_t* __restrict__ flags, int world, int32_t* __restrict__ st) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int any = 0;
+    for (int r = 0; r < world; ++r) any |= flags[4 * r];
+    if (any) st[0] = 1;
+}
+
 __global__ void iota_offset(int32_t* __restrict__ out, int n, int off) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = off + i;
@@ -340,17 +353,31 @@ void Engine::knn(const double* X, const int32_t* ref_rows, int nr, const double*
     {
         const int64_t per = bmx_shard_rows_per_rank(nq, world_);
         // indices and distances of one search: grouped, RCCL sends them as one launch
-        const bool group = (dist || kth) && comm_ && world_ > 1 && rccl::api().GroupStart && rccl::api().GroupEnd;
+        const bool flags = world_ > 1 && knn_ws_.optimistic;  // (see stage_opt_flag)
+        int32_t* xf = nullptr;
+        if (flags) {
+            xf = xflags_.reserve((size_t)4 * world_);
+            hipLaunchKernelGGL(stage_opt_flag, dim3(1), dim3(64), 0, stream_, (const int32_t*)knn_ws_.opt_state_ptr(stream_),
+                               xf + 4 * rank_);
+            BMX_LAUNCH_CHECK();
+        }
+        const bool group = (dist || kth || flags) && comm_ && world_ > 1 && rccl::api().GroupStart && rccl::api().GroupEnd;
         if (group) (void)rccl::api().GroupStart();
         try {
             exchange(idx, per * k * (int64_t)sizeof(int32_t));
             if (dist) exchange(dist, per * k * (int64_t)sizeof(double));
             if (kth) exchange(kth, per * (int64_t)sizeof(double));
+            if (flags) exchange(xf, 4 * (int64_t)sizeof(int32_t));
         } catch (...) {
             if (group) (void)rccl::api().GroupEnd();  // never leave the group open behind an error
             throw;
         }
         if (group && rccl::api().GroupEnd() != 0) throw Error(BMX_ERR_EXCHANGE, "ncclGroupEnd failed");
+        if (flags) {
+            hipLaunchKernelGGL(merge_opt_flags, dim3(1), dim3(64), 0, stream_, (const int32_t*)xf, world_,
+                               knn_ws_.opt_state_ptr(stream_));
+            BMX_LAUNCH_CHECK();
+        }
     }
 }
 
@@ -388,7 +415,13 @@ const int32_t* Engine::read_state() {
     }
     std::atomic_thread_fence(std::memory_order_acquire);
     queued_work_s_ = 0.0;
-    if (pin[0] != 0) throw OptimisticRetry();
+    if (pin[0] != 0) {
+        // a search of this rank alone (auto-merge's counts, dealt over the ranks) must not restart this rank alone: note it,
+        // lower the device flag, go on; gather_counts tells everybody
+        if (!solo_) throw OptimisticRetry();
+        solo_flag_ = true;
+        BMX_HIP(hipMemsetAsync(st, 0, sizeof(int32_t), stream_));
+    }
     return pin;
 }
 
@@ -852,9 +885,10 @@ void Engine::run(const bmx_params_t& p, const int32_t* tree, int tree_len) {
     // host round trip (knn.hip: search_tiers).  A search that cannot be completed that way (hundreds of uncertified queries,
     // lists overflowing with exact ties) raises a device flag the waits of the merge loop look at; the run then starts over
     // from the resident inputs with host-checked searches.  Nothing of a merge is visible outside before the run returns.
-    // (one rank only: with several, a flag raised on one of them would have to restart all -- their searches keep the host
-    // in the loop instead, the way every search did before: five cheap read-backs per merge, no flag to agree on)
-    knn_ws_.optimistic = !knn_ws_.force_exact && world_ == 1;
+    // With several ranks the flag is agreed on: it travels with every search's lists (Engine::knn) and with the counts of the
+    // searches a rank runs alone (gather_counts), so all ranks see it at the same wait and start over together.
+    knn_ws_.optimistic = !knn_ws_.force_exact;
+    solo_ = solo_flag_ = false;
     try {
         run_once(p, tree, tree_len);
     } catch (const OptimisticRetry&) {
@@ -870,15 +904,19 @@ void Engine::run(const bmx_params_t& p, const int32_t* tree, int tree_len) {
 std::vector<int32_t> Engine::gather_counts(const std::vector<int32_t>& mine) {
     if (world_ == 1) return mine;
     const int n = (int)mine.size();
-    const int per = (n + world_ - 1) / world_;
+    const int per = (n + world_ - 1) / world_ + 1;  // (+ 1: "one of my searches could not be completed optimistically")
     std::vector<int32_t> slice((size_t)per * world_, 0);
     for (int t = rank_; t < n; t += world_) slice[(size_t)rank_ * per + t / world_] = mine[t];
+    slice[(size_t)rank_ * per + per - 1] = solo_flag_ ? 1 : 0;
+    solo_flag_ = false;
     int32_t* dev = count_xchg_.reserve((size_t)per * world_);
     BMX_HIP(hipMemcpyAsync(dev, slice.data(), slice.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
     BMX_HIP(hipStreamSynchronize(stream_));
     exchange(dev, (int64_t)per * (int64_t)sizeof(int32_t));
     BMX_HIP(hipMemcpyAsync(slice.data(), dev, slice.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
     wait();
+    for (int r = 0; r < world_; ++r)
+        if (slice[(size_t)r * per + per - 1] != 0) throw OptimisticRetry();  // every rank sees the same slices: all restart here
     std::vector<int32_t> out((size_t)n);
     for (int t = 0; t < n; ++t) out[t] = slice[(size_t)(t % world_) * per + t / world_];
     return out;
@@ -892,15 +930,18 @@ std::vector<int32_t> Engine::solo_counts(int n, const std::function<int(int)>& c
         if (t % wd != rk) continue;
         rank_ = 0;
         world_ = 1;  // an unsharded search on this rank alone
+        solo_ = wd > 1;
         try {
             mine[t] = count(t);
         } catch (...) {
             rank_ = rk;
             world_ = wd;
+            solo_ = false;
             throw;
         }
         rank_ = rk;
         world_ = wd;
+        solo_ = false;
     }
     return gather_counts(mine);
 }
@@ -1114,15 +1155,18 @@ void Engine::run_once(const bmx_params_t& p, const int32_t* tree, int tree_len) 
                     const int rk = rank_, wd = world_;
                     rank_ = 0;
                     world_ = 1;  // an unsharded search on this rank alone
+                    solo_ = wd > 1;
                     try {
                         mine[c] = (int32_t)find_mnn(*lcopy, *r, p.k, p.prop_k).P;
                     } catch (...) {
                         rank_ = rk;
                         world_ = wd;
+                        solo_ = false;
                         throw;
                     }
                     rank_ = rk;
                     world_ = wd;
+                    solo_ = false;
                 }
                 const std::vector<int32_t> all = gather_counts(mine);
                 for (int c = 0; c < K; ++c) ns[K][c] = all[c];

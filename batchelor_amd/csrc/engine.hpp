@@ -145,6 +145,9 @@ class Engine {
     std::vector<int32_t> solo_counts(int n, const std::function<int(int)>& count, bool dry = false);
     std::vector<int32_t> gather_counts(const std::vector<int32_t>& mine);
     DevBuf<int32_t> count_xchg_;
+    DevBuf<int32_t> xflags_;   // [world][4] the ranks' optimistic-search flags, gathered with every search's lists
+    bool solo_ = false;        // this rank is running a whole search of its own (auto-merge counts): read_state does not restart
+    bool solo_flag_ = false;   // ... but remembers that it should have; gather_counts tells every rank
     const int32_t* read_state();  // one wait: the run's device words in pinned memory; throws OptimisticRetry
     void merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p, std::unique_ptr<Node>& merged);
     // statistics (column means + total variance) of the segments whose slot is stale

@@ -203,7 +203,8 @@ int32_t bmx_engine_snapshot(bmx_engine_t* e, double* left_rm, double* right_rm, 
  * the merges' streaming sections (everything that is not a kNN search), out[7] = queries that took the exact FP64
  * path, out[8] = queries the first tier handed to the second, out[9] = runs of this engine that were repeated with
  * host-checked searches (a run first leaves the counts of its uncertified queries on the device; when a search cannot be
- * completed that way -- hundreds of uncertified queries, lists overflowing with ties -- it starts over). */
+ * completed that way -- hundreds of uncertified queries, lists overflowing with ties -- it starts over; the ranks of a
+ * sharded run agree on that through a flag that travels with every search's lists, and start over together). */
 int32_t bmx_engine_profile_detail(bmx_engine_t* e, double* out10);
 /* Name of the full-pass candidate kernel the engine launched last, as rocprofv3 prints it (template arguments
  * included): lets a benchmark check that a stored counter measurement belongs to the kernel it has just timed. */

@@ -21,16 +21,22 @@ def main():
     from tests.conftest import synth_batches
 
     B = synth_batches(13, [3001, 2500, 1777], 50) if not auto else synth_batches(14, [900, 1400, 700, 1100, 800], 20)
+    if mode.startswith("retry"):
+        from tests.test_gpu_dist import retry_batches
+        B = retry_batches()
+        auto = mode == "retry_auto"
     eng = bx.MnnEngine(0)
     ex = TorchExchange(0)
     eng.set_shard(rank, world, ex)
     eng.upload(B)
+    eng.set_profiling(True)
     eng.run(var_adj=var_adj, sigma=1.0, auto_merge=auto)
     out = eng.download()
+    retries = eng.profile_detail()["optimistic_retries"]
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), corrected=out.corrected,
              pl0=out.merge_info.pairs[0][0], pr0=out.merge_info.pairs[0][1],
              pl1=out.merge_info.pairs[1][0], pr1=out.merge_info.pairs[1][1],
-             lost_var=out.merge_info.lost_var, calls=ex.calls,
+             lost_var=out.merge_info.lost_var, calls=ex.calls, retries=retries,
              left=np.asarray([sum(1 << (b - 1) for b in s_) for s_ in out.merge_info.left]),
              right=np.asarray([sum(1 << (b - 1) for b in s_) for s_ in out.merge_info.right]))
     eng.close()

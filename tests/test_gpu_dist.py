@@ -38,8 +38,52 @@ def test_n_rank_engine_equals_single_rank(tmp_path, world, var_adj):
             assert np.array_equal(got[f"pr{m}"], ref.merge_info.pairs[m][1])
         assert np.array_equal(got["lost_var"], ref.merge_info.lost_var)
         # per merge: index + distance gathers of the first search, index + k-th distance of the second, index + distance of
-        # the tricube search (+ the scalings with var_adj)
-        assert int(got["calls"]) == 2 * (2 + 2 + 2 + (1 if var_adj else 0))
+        # the tricube search, with each of them the ranks' "could not be completed on the device" flags (+ the scalings
+        # with var_adj)
+        assert int(got["calls"]) == 2 * (3 + 3 + 3 + (1 if var_adj else 0))
+        assert int(got["retries"]) == 0
+
+
+def retry_batches():
+    """Three batches whose FIRST half is 30 clusters of 100 near-duplicates (thousands of references inside the fp16 pass's
+    error margin of a query's k-th neighbour: the search cannot be completed on the device) and whose second half is a
+    diffuse cloud far away (certified at once): with two ranks the flag goes up on rank 0's query rows only."""
+    rng = np.random.default_rng(4242)
+    centres = rng.standard_normal((30, 50)) * 2.0
+    out = []
+    for b in range(3):
+        clus = np.repeat(centres, 100, axis=0) + 1e-4 * rng.standard_normal((3000, 50)) + 0.3 * b
+        diffuse = rng.standard_normal((3000, 50)) + 0.3 * b
+        diffuse[:, 0] += 60.0
+        out.append(np.vstack([clus, diffuse]))
+    return out
+
+
+@pytest.mark.parametrize("mode", ["retry", "retry_auto"])
+def test_ranks_restart_an_optimistic_run_together(tmp_path, mode):
+    """Several ranks run optimistically too: a search one rank cannot complete on the device raises a flag that travels with
+    the search's lists (or, for the searches auto-merge deals out whole, with their counts), every rank sees it at the same
+    wait and all of them repeat the run with host-checked searches.  A rank restarting alone would hang the others in a
+    collective: the workers have a timeout.  Same result as one rank, bit for bit; the restart did happen, on both."""
+    import batchelor_amd as bx
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_gpu_shard_worker.py"), str(r), "2", str(port),
+                               str(tmp_path), mode], env=env) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    B = retry_batches()
+    ref = bx.reducedMNN(*B, auto_merge=mode == "retry_auto")
+    for r in range(2):
+        got = np.load(tmp_path / f"rank{r}.npz")
+        assert int(got["retries"]) >= 1
+        assert np.array_equal(got["corrected"], ref.corrected)
+        for m in range(2):
+            assert np.array_equal(got[f"pl{m}"], ref.merge_info.pairs[m][0])
+            assert np.array_equal(got[f"pr{m}"], ref.merge_info.pairs[m][1])
 
 
 @pytest.mark.parametrize("world", [2, 3])
