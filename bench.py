@@ -527,6 +527,11 @@ def main():
             try:
                 line["cpu_baseline"], line["cpu_baseline_variants"] = cpu_baselines(batches, stats, d, k)
                 line["host_cores"] = os.cpu_count()
+                try:  # (the CPU baseline is reported with the host's core count and CPU model)
+                    with open("/proc/cpuinfo") as f:
+                        line["host_cpu_model"] = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), None)
+                except OSError:
+                    line["host_cpu_model"] = None
             except Exception as exc:  # the baseline must never take the GPU number down with it
                 line["cpu_baseline"] = {"value": None, "unit": "cells/s", "cores": os.cpu_count(), "kind": "port",
                                         "sample": f"failed: {exc}"}
