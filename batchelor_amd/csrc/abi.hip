@@ -147,6 +147,7 @@ int32_t bmx_set_device(int32_t device) {
 void bmx_trim_caches(void) {
     // device blocks parked by engines that are gone (up to 16 GB are kept for the next engine on the device)
     bmx::DevBlockCache::release_global();
+    bmx::StreamPool::release_all();  // (and the streams parked by engines that are gone)
 }
 
 int64_t bmx_last_knn_exact_fallbacks(void) { return g_last_fallbacks; }
@@ -763,7 +764,7 @@ int32_t bmx_fast_mnn(int32_t nbatches, int32_t d, const double* const* data, con
             const auto t3 = std::chrono::steady_clock::now();
             auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
             fprintf(stderr, "[bmx] one-shot: create+upload %.2f ms, run %.2f ms, download %.2f ms; %ld hipMallocs so far\n", ms(t0, t1),
-                    ms(t1, t2), ms(t2, t3), bmx::dev_malloc_calls());
+                    ms(t1, t2), ms(t2, t3), bmx::dev_malloc_calls().load());
         }
         if (out_engine) *out_engine = h.release();
     });

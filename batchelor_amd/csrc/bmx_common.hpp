@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <map>
@@ -198,6 +199,21 @@ struct StreamPool {
         BMX_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
         return s;
     }
+    // bmx_trim_caches: the parked streams of every device go back to the runtime (each destroyed on its own device)
+    static void release_all() {
+        std::map<int, std::vector<hipStream_t>> all;
+        {
+            std::lock_guard<std::mutex> lk(mu());
+            all.swap(parked());
+        }
+        int cur = 0;
+        const bool have = hipGetDevice(&cur) == hipSuccess;
+        for (auto& kv : all) {
+            if (hipSetDevice(kv.first) != hipSuccess) continue;
+            for (hipStream_t s : kv.second) (void)hipStreamDestroy(s);
+        }
+        if (have) (void)hipSetDevice(cur);
+    }
     // `s` belongs to the current device and has been synchronised without an error
     static void give(hipStream_t s) {
         if (!s) return;
@@ -229,8 +245,8 @@ inline void ensure_dynamic_lds(const void* func, size_t bytes) {
 }
 
 // (how many hipMallocs the process has made for DevBufs: printed with the one-shot call's timings under BMX_DEBUG=t)
-inline long& dev_malloc_calls() {
-    static long n = 0;
+inline std::atomic<long>& dev_malloc_calls() {
+    static std::atomic<long> n{0};
     return n;
 }
 

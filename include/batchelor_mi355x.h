@@ -39,7 +39,8 @@ void bmx_free(void* p);
 int32_t bmx_set_device(int32_t device);
 /* Engines park their device blocks in a process-wide pool when they go (at most 16 GB / 256 blocks: a host that calls
  * fastMNN() again and again then pays its hipMallocs once); an allocation that fails inside the library empties the pool
- * by itself, other allocators of the process (torch, RCCL, the host's own hipMalloc) call this when they need the memory. */
+ * by itself, other allocators of the process (torch, RCCL, the host's own hipMalloc) call this when they need the memory.
+ * The (at most 8 per device) streams parked by engines that are gone are destroyed too. */
 void bmx_trim_caches(void);
 
 /* ------------------------------------------------------------------------------------------------------------------
