@@ -12,7 +12,7 @@ captures the two matrices every merge hands to findMutualNN, and reports per mer
   * how many of them a threshold-only count with the fp16 margin (d^2 < m^2 - 2 eps) settles,
   * how many a count over a SAMPLE of the right cells settles (early exit),
   * the share of candidate pairs 1 / 2 / 4 thresholds per left cell decide.
-   python tests/replay_mutual_count.py [cells per batch] [batches]
+   python scripts/replay_mutual_count.py [cells per batch] [batches]
 """
 import os
 import sys
