@@ -59,6 +59,14 @@ def dev_set(name, value):
     check(lib().bmx_dev_set(name.encode(), ctypes.c_int32(int(value))))
 
 
+def dev_get(name):
+    """Counters for tests and bench.py (bmx_dev_get): e.g. "asv_literal_cells", "asv_fallback_cells", "asv_tiled_cells",
+    "asv_tally_reset"."""
+    v = ctypes.c_int64(0)
+    check(lib().bmx_dev_get(name.encode(), ctypes.byref(v)))
+    return int(v.value)
+
+
 def device_count():
     return int(lib().bmx_device_count())
 

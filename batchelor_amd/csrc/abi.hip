@@ -164,6 +164,7 @@ int32_t bmx_dev_set(const char* name, int32_t value) {
     else if (n == "force_c") k.force_c = value;
     else if (n == "no_margin") k.no_margin = value;
     else if (n == "asv_fast") k.asv_fast = value;
+    else if (n == "asv_cap") k.asv_cap = value;
     else if (n == "exchange_always") k.exchange_always = value;
     else if (n == "refine_wave") k.refine_wave = value;
     else if (n == "reset") k = bmx::DevKnobs();
@@ -172,6 +173,23 @@ int32_t bmx_dev_set(const char* name, int32_t value) {
         return BMX_ERR_ARG;
     }
     return BMX_OK;
+}
+
+int32_t bmx_dev_get(const char* name, int64_t* value) {
+    if (!name || !value) return BMX_ERR_ARG;
+    return guarded([&] {
+        const std::string n(name);
+        unsigned long long t[3];
+        if (n == "asv_literal_cells" || n == "asv_fallback_cells" || n == "asv_tiled_cells") {
+            bmx::asv_tally_read(t, false);
+            *value = (int64_t)t[n == "asv_literal_cells" ? 0 : (n == "asv_fallback_cells" ? 1 : 2)];
+        } else if (n == "asv_tally_reset") {
+            bmx::asv_tally_read(t, true);
+            *value = 0;
+        } else {
+            throw bmx::Error(BMX_ERR_ARG, "bmx_dev_get: unknown counter '" + n + "'");
+        }
+    });
 }
 
 int32_t bmx_dev_host_copy(void* dst, const void* src, int64_t bytes) {

@@ -55,6 +55,7 @@ struct DevKnobs {
     int force_c = 0;          // reference ranges of EVERY query block (0: off)
     int no_margin = 0;        // fp16 tier: lists cut at their KS-th best only (round 2's rule)
     int asv_fast = 0;         // adjust_shift_variance: the tiled form whatever the size
+    int asv_cap = -1;         // tiled form: kept addends per chain of the literal re-run (-1: default, 0: no re-run)
     int exchange_always = 0;  // a single rank goes through its exchange transport too (an all-gather of one)
     int refine_wave = 0;      // the exact re-rank takes a whole wave for every query (no half-wave form)
 };

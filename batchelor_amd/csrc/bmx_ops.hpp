@@ -162,9 +162,12 @@ struct AsvPlan {
     int exact = 1;   // 1: asv_exact_kernel (the reference's order of operations literally), 0: the tiled FP64-MFMA form
     int blocks = 1;  // workgroups
     int npad = 1;    // exact form: nr1 rounded up to a power of two
+    int lcap = 0;    // tiled form: addends a chain of the literal re-run of a flagged cell may keep (0: no re-run)
     size_t main_doubles = 0, extra_doubles = 0;
 };
 AsvPlan adjust_shift_variance_plan(int g, int n2, int nr1, int nr2, int vect_row_major);
+// counters of the tiled form on the current device: {cells re-run literally, flagged cells beyond lcap, all cells}
+void asv_tally_read(unsigned long long out[3], bool reset);
 // out[c] for the cells c in [cell_begin, cell_end) only (cell_end < 0: n2) -- the unit a multi-GPU run shards by
 void adjust_shift_variance_device(hipStream_t stream, const double* data1, int g, int n1, const double* data2, int n2,
                                   const double* vect, double sigma2, const int32_t* restrict1, int nr1,

@@ -390,16 +390,28 @@ constexpr int AT_NP = 2 * AT_R; // the stream is padded to whole pairs of steps 
 constexpr int AT_SM = 4 * AT_C * 6;  // doubles of the block-reduction area: six values per (wave, cell) after the stream (>= T)
 
 __host__ __device__ inline int asv_tile_gp(int g) { return (g + AT_KC - 1) / AT_KC * AT_KC + 2; }
-inline int asv_tile_nb8(int g) { return g <= 128 ? (g + 7) / 8 : 0; }  // 8-dimension blocks of a row; 0: the staged form
+__host__ __device__ inline int asv_tile_nb8(int g) { return g <= 128 ? (g + 7) / 8 : 0; }  // 8-dimension blocks of a row; 0: the staged form
 // row stride of the gathered stream: whole 8-dimension blocks (zero filled) for the register-streamed form
 inline int asv_tile_gs(int g) { return g <= 128 ? asv_tile_nb8(g) * 8 : g; }
 inline size_t asv_tile_npad(size_t N) { return std::max<size_t>((N + AT_NP - 1) / AT_NP * AT_NP, AT_NP); }
-inline size_t asv_tile_lds_bytes(int g) {
+// addends a chain of the literal re-run may keep (its sort buffer and two 16 KB bin arrays must fit the LDS beside the tile)
+inline int asv_tile_lcap_default(int g) { return g <= 128 ? 4096 : 2048; }
+// doubles of the kernel's multi-purpose LDS region (see there)
+__host__ __device__ inline int asv_tile_ub_doubles(int g, int lcap) {
     const int nb8 = asv_tile_nb8(g);
-    // (the tile's cells / gradients and the collected bin share a region: the one is dead before the other is written)
-    return (std::max<size_t>((size_t)2 * AT_C * asv_tile_gp(g), (size_t)2 * AT_CAP) +
+    int u = 2 * AT_CAP;
+    u = u > 2 * lcap ? u : 2 * lcap;
+    const int a = nb8 > 8 ? 2 * nb8 * 2 * 64 : 0;
+    return u > a ? u : a;
+}
+// doubles of a workgroup's lists: per cell (log-weight, flag) of the own batch, log-weight of the reference in restrict order,
+// (projection, log-weight) of the reference sorted; three index lists
+__host__ __device__ inline int64_t asv_tile_list_doubles(int lcap) { return (int64_t)AT_C * lcap * 5 + (3 * (int64_t)lcap + 1) / 2 + 1; }
+inline size_t asv_tile_lds_bytes(int g, int lcap) {
+    const int nb8 = asv_tile_nb8(g);
+    return ((size_t)2 * AT_C * asv_tile_gp(g) + (size_t)asv_tile_ub_doubles(g, lcap) +
             (nb8 == 0 ? (size_t)AT_R * (AT_KC + 2) : 0) + 8 * AT_C + AT_SM) * sizeof(double) +
-           (size_t)AT_NB * sizeof(unsigned long long) + (nb8 > 8 ? (size_t)2 * nb8 * 2 * 64 * sizeof(double) : 0);
+           (size_t)2 * AT_NB * sizeof(unsigned long long);
 }
 
 // The weighted-quantile walk (src/adjust_shift_variance.cpp:137-157: the first entry at which the cumulative weight reaches
@@ -488,6 +500,131 @@ __device__ __forceinline__ void asv_row_scan(const double* __restrict__ P, const
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The literal re-run of the cells whose quantile walk is decided by rounding (the "flagged" cells of asv_tile_kernel).
+//
+// The reference sums its weights by sequential R::logspace_add chains (src/adjust_shift_variance.cpp:96-109, :127-131,
+// :147-151).  Where the bandwidth is small against the squared distances, a cell's own log-weight (0) dwarfs the rest of
+// its batch, prob2 - totalprob2 is below an ulp of totalprob1, the target of the walk IS totalprob1 (or an ulp or two
+// below it) and the walk ends where the cumulative chain over the SORTED reference cells first reaches what the chain in
+// RESTRICT order ended at: a statement about the rounding of two summation orders, which only the chains themselves
+// reproduce.  But in exactly that regime almost every addend of a chain is an exact no-op:
+//
+//   Lemma.  Let acc be a chain's running value, known to lie in [L, U] with L, U of one sign, and 2^e <= min(|L|, |U|).
+//   An addend lw < L + (e - 54) ln 2 - 1/4 leaves it unchanged: logspace_add(acc, lw) = acc + log1p(exp(lw - acc)), the
+//   second term is <= exp(lw - L) < 2^(e - 54) e^(-1/4), less than a quarter of the spacing of doubles at |acc| >= 2^e (half
+//   of it just below a power of two, towards zero) -- the sum rounds to acc; the few-ulp errors of the portable exp / log1p
+//   are inside the factor e^(-1/4).  An addend lw <= acc - 700 is a no-op outright: the portable exp returns 0 there.
+//
+// acc is bounded from what has gone by: it is >= the largest addend so far (M) and <= M + log(count); once the cell's own
+// weight 1 has gone by it is log(1 + sum of the others) in [log1p(e^Mx), log1p(count e^Mx)], Mx the largest other addend.
+// A chain restricted to the addends the lemma does not exclude therefore has, by induction over its steps, the SAME bits
+// as the full chain -- and keeping more addends than necessary (bounds from an earlier point of the sequence, margins for
+// the matrix-core form's rounding of lw) is harmless: every addend that is left out is individually a no-op.
+// So, per flagged cell: (i) the kept addends of the three chains are picked from the tile's scratch (values in GEMM form,
+// margins `mb` / `tolp` for their rounding) -- in restrict order for totalprob2 / prob2 (:96-109) and totalprob1 (:127-131),
+// in projection order for the walk (:147-151), where "what has gone by" is taken per histogram bin, two bins back; (ii)
+// for those few the projection and the distance to the line are recomputed in the reference's own order of operations
+// (:9-27, :88-89, :120-123), sorted as std::sort sorts the pairs (:134); (iii) one lane per chain repeats the reference's
+// sequential sums with the bit-reproducible exp / log1p.  Every such cell is bit-equal to what a CPU following the
+// reference's order of operations gets -- whatever the size of the call.  A cell that keeps more than `lcap` addends in
+// any chain (bandwidths of the order of the squared distances: nearly every pair carries weight) goes the histogram
+// way, which there resolves the quantile to 2^-40 of the total weight.
+// ---------------------------------------------------------------------------------------------------
+constexpr double AT_LN2 = 0.6931471805599453;
+
+// addends below the returned value cannot change a chain whose running value lies in [L, U] (the lemma above)
+__device__ __forceinline__ double asv_noop_below(double L, double U) {
+    double t = L - 701.0;  // (portable exp: 0 for arguments <= -700)
+    if ((L > 0.0 && U > 0.0) || (L < 0.0 && U < 0.0)) {
+        const double amin = fmin(fabs(L), fabs(U));
+        t = fmax(t, L + (double)(ilogb(amin) - 54) * AT_LN2 - 0.25);
+    }
+    return t;
+}
+
+// Thresholds of a chain from what has gone by (addends below them are no-ops), for the two regimes of a chain:
+//  * running value below zero (a reference chain; an own-batch chain until the cell's own weight 1 arrives): it is >= the
+//    largest addend so far (lo) and never exceeds hi + log(count), hi >= every addend the chain can have met by then;
+//  * the cell itself has gone by: the chain stands at log(1 + the others' weights) >= log1p(exp(largest other so far)), and
+//    only grows -- away from zero, towards coarser spacing.
+// mb >= the rounding of the GEMM-form log-weights the bounds are taken from.
+__device__ __forceinline__ double asv_thr_neg(double lo, double hi, double cnt, double mb) {
+    if (lo == -__builtin_inf()) return lo;  // nothing has gone by: the next addend starts the chain
+    return asv_noop_below(lo - mb, fmax(lo, hi) + mb + log(cnt) + 0.01) - mb;
+}
+__device__ __forceinline__ double asv_thr_self(double others, double mb) {
+    // (no other addend yet: the chain stands at 0 exactly, only exp's underflow makes a no-op)
+    const double L = others == -__builtin_inf() ? 0.0 : log1p(exp(others - mb)) * (1.0 - 1e-9);
+    return asv_noop_below(L, L) - mb;
+}
+
+// projection of `other` on the cell's line and its squared distance to it, in the reference's order of operations
+// (:88-89 / :120-123 inner_product, :9-27 sq_distance_to_line); cur / grad: the cell and its unit gradient
+__device__ __forceinline__ void asv_pair_literal(const double* cur, const double* grad, const double* __restrict__ other,
+                                                 int g, double sigma2, double& proj, double& lw) {
+    double pr = 0.0, sc = 0.0;
+    for (int x = 0; x < g; ++x) pr += grad[x] * other[x];
+    for (int x = 0; x < g; ++x) sc += (cur[x] - other[x]) * grad[x];
+    double dist = 0.0;
+    for (int x = 0; x < g; ++x) {
+        const double w = (cur[x] - other[x]) - sc * grad[x];
+        dist += w * w;
+    }
+    proj = pr;
+    lw = -dist / sigma2;
+}
+
+// asv_row_scan in PIECES with a block-wide step in the middle of each: `pre` sees every element of a piece, then `hook(end)`
+// runs -- it may synchronise the block (every thread makes every call, the loop bounds are uniform) and returns true to end
+// the scan --, then `test` sees the piece's elements again (they are still in registers).  A piece is a row of T elements
+// over the first two batches (the bounds of a chain tighten fastest at its start) and a batch of AT_U rows from then on.
+template <class Pre, class Hook, class Test>
+__device__ __forceinline__ void asv_row_scan_pieces(const double* __restrict__ P, const double* __restrict__ W,
+                                                    int64_t jstart, int n, int crot, int last_block, int tid, Pre pre,
+                                                    Hook hook, Test test) {
+    const int64_t jt = jstart + tid;
+    const int jlow = (int)(jt & 63), jb_t = (int)(jt >> 6);
+    double pa[AT_U], wa[AT_U], pb[AT_U], wb[AT_U];
+    auto fetch = [&](double (&p)[AT_U], double (&w)[AT_U], int base) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < AT_U; ++u) {
+            int jb = jb_t + ((base + u * T) >> 6);
+            jb = jb < last_block ? jb : last_block;
+            const int64_t off = (int64_t)jb * (AT_C * 64) + (((crot + jb) & (AT_C - 1)) << 6) + jlow;
+            p[u] = P[off];
+            w[u] = W[off];
+        }
+    };
+    bool stop = false;
+    auto consume = [&](const double (&p)[AT_U], const double (&w)[AT_U], int base) __attribute__((always_inline)) {
+        if (base < 2 * AT_U * T) {
+#pragma unroll
+            for (int u = 0; u < AT_U; ++u) {
+                if (stop) break;
+                pre(p[u], w[u], base + u * T + tid);
+                stop = hook(base + (u + 1) * T);
+                if (!stop) test(p[u], w[u], base + u * T + tid);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < AT_U; ++u) pre(p[u], w[u], base + u * T + tid);
+            stop = hook(base + AT_U * T);
+            if (!stop) {
+#pragma unroll
+                for (int u = 0; u < AT_U; ++u) test(p[u], w[u], base + u * T + tid);
+            }
+        }
+    };
+    fetch(pa, wa, 0);
+    for (int base = 0; base < n && !stop; base += 2 * AT_U * T) {
+        fetch(pb, wb, base + AT_U * T);
+        consume(pa, wa, base);
+        fetch(pa, wa, base + 2 * AT_U * T);
+        if (base + AT_U * T < n && !stop) consume(pb, wb, base + AT_U * T);
+    }
+}
+
 // The streamed cells of one call, in stream order (the own batch's restricted cells, then the reference's), as ONE
 // contiguous matrix with their squared norms and -- for the own batch -- their cell ids: the tile kernel then reads plain
 // consecutive rows (coalesced, prefetchable any distance ahead) instead of chasing restrict[] -> row -> norm per step.
@@ -526,15 +663,19 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                                                      const double* __restrict__ vect, double sigma2, int nr1, int nr2,
                                                      const double* __restrict__ S, const double* __restrict__ snrm,
                                                      const int32_t* __restrict__ sid, double* __restrict__ out,
-                                                     double* __restrict__ scratch, int cell_begin, int cell_end) {
+                                                     double* __restrict__ scratch, int cell_begin, int cell_end, int lcap,
+                                                     unsigned long long* __restrict__ tally) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int GP = asv_tile_gp(g);
     double* cx = reinterpret_cast<double*>(smem_raw);  // [16][GP] the tile's cells
-    double* cg = cx + AT_C * GP;                        // [16][GP] their unit gradients
-    // (cx / cg are read for the last time before a tile's per-cell phase starts, lp / lw_ only inside it: same region)
-    double* lp = cx;                                                             // [CAP] collected projections
+    double* cg = cx + AT_C * GP;                        // [16][GP] their unit gradients (both live through the per-cell phase: the literal re-run reads them)
+    // one region, three lives: the A operands in lane order during the stream (cxp / cgp, NB8 > 8), the collected bin of the
+    // histogram walk (lp / lw_), the sort buffer of the literal re-run (2 lcap doubles)
+    double* ub = cg + AT_C * GP;
+    const int ub_doubles = asv_tile_ub_doubles(g, lcap);
+    double* lp = ub;                                                             // [CAP] collected projections
     unsigned long long* lw_ = reinterpret_cast<unsigned long long*>(lp + AT_CAP);  // [CAP] and their weights
-    double* rs = cx + (2 * AT_C * GP > 2 * AT_CAP ? 2 * AT_C * GP : 2 * AT_CAP);  // [64][KC + 2] a step of streamed cells (staged form only)
+    double* rs = ub + ub_doubles;  // [64][KC + 2] a step of streamed cells (staged form only)
     double* sc_proj = rs + (NB8 == 0 ? AT_R * (AT_KC + 2) : 0);  // per cell: own projection, |x|^2, |vect|, maxima, projection range
     double* sc_n = sc_proj + AT_C;
     double* sc_l2 = sc_n + AT_C;
@@ -545,18 +686,31 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
     double* sc_tmp = sc_hi + AT_C;
     double* sm = sc_tmp + AT_C;                         // [AT_SM] block reductions
     unsigned long long* hist = reinterpret_cast<unsigned long long*>(sm + AT_SM);  // [NB]
-    double* cxp = reinterpret_cast<double*>(hist + AT_NB);  // [2 NB8][64] the cells' coordinates as the lanes read them
+    unsigned long long* binmax = hist + AT_NB;  // [NB] per projection bin: the largest log-weight (bit pattern), then the bin's threshold
+    double* cxp = ub;                                       // [2 NB8][64] the cells' coordinates as the lanes read them
     double* cgp = cxp + (NB8 > 8 ? NB8 * 2 * 64 : 0);       // [2 NB8][64] the unit gradients likewise (NB8 > 8)
     __shared__ int sh_cnt, sh_bin;
     __shared__ unsigned long long sh_before;
+    __shared__ int sh_sel[4];        // literal re-run: kept addends (own batch, reference in restrict order, in projection order), abort flag
+    __shared__ int sh_K[AT_C][3];    // per cell of the tile: the lengths of its three lists (-1: the cell went the histogram way)
+    __shared__ double sh_chain[AT_C][3];  // per cell: totalprob2, prob2, totalprob1 as the chains leave them
+    __shared__ double sh_nmx[4];          // per wave: the largest squared norm of a streamed cell
+    __shared__ int sh_spos[AT_C];         // per cell: its own first place in restrict2's order (0x7fffffff: it is not in it)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t N = (int64_t)nr1 + nr2;  // streamed cells: the own batch's restricted cells first, then the reference's
     // the tile's scratch: per block of 64 streamed cells, 16 rows (cells) of 64 values -- a step of the stream writes ONE
     // contiguous 8 KB piece of each array (the [cell][N] layout of the first version wrote 32 rows 8 MB apart per step and
     // spent its time in address translation), and a cell's row is 512-byte pieces 8 KB apart, read by whole waves
     const int64_t Npad = N <= AT_NP ? AT_NP : (N + AT_NP - 1) / AT_NP * AT_NP;
-    double* SP = scratch + (int64_t)blockIdx.x * 2 * AT_C * Npad;  // projections
-    double* SW = SP + (int64_t)AT_C * Npad;                         // log-weights
+    const int64_t per_block = 2 * AT_C * Npad + asv_tile_list_doubles(lcap);
+    double* SP = scratch + (int64_t)blockIdx.x * per_block;  // projections
+    double* SW = SP + (int64_t)AT_C * Npad;                   // log-weights
+    // the literal re-run's lists, per cell of the tile: own batch (log-weight, counted-in-prob2 flag) in restrict order,
+    // reference log-weights in restrict order, reference (projection, log-weight) sorted; and three index lists, reused per cell
+    double* LO = SW + (int64_t)AT_C * Npad;        // [16][lcap][2]
+    double* LR = LO + (int64_t)AT_C * lcap * 2;    // [16][lcap]
+    double* LS = LR + (int64_t)AT_C * lcap;        // [16][lcap][2]
+    int32_t* GI = reinterpret_cast<int32_t*>(LS + (int64_t)AT_C * lcap * 2);  // [3][lcap]
     // -- and a cell's slot inside a block's piece rotates with the block number: with a fixed slot the per-cell passes
     // walked the scratch at a stride of exactly 8 KB, i.e. through a handful of the memory channels
     const int rot0 = blockIdx.x;
@@ -577,6 +731,7 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
         }
         __syncthreads();
         if (tid < AT_C) {
+            sh_spos[tid] = 0x7fffffff;
             double l2 = 0.0, nn = 0.0;
             for (int x = 0; x < g; ++x) l2 += cg[tid * GP + x] * cg[tid * GP + x];
             l2 = sqrt(l2);
@@ -595,7 +750,10 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
         // ---- pass over the streamed cells: projections and log-weights of every (cell, streamed cell) pair
         // own batch: log-sum-exp of every cell's weights, all of them and those at or below its projection (:74-112), taken
         // ONLINE in the stream's epilogue -- running maximum om, sums relative to it -- so that the own batch's 40 % of the
-        // (cell, streamed cell) pairs never go to the scratch and are not read back (round 3: 16 + 16 bytes per pair)
+        // (cell, streamed cell) pairs are not read back (round 3: 16 + 16 bytes per pair); they are written all the same when
+        // the literal re-run is on (lit_on): a flagged cell picks the kept addends of its own-batch chains from them
+        const bool lit_on = lcap > 0;
+        double nmx = 0.0;  // largest squared norm of a streamed cell (bounds the rounding of the GEMM-form distances)
         double om[4], oa[4], ob[4];
         double mx1[4], mx2[4], lo[4], hi[4], cp[4], cn[4];
 #pragma unroll
@@ -652,6 +810,7 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                 load_rows(bn, srow + (j0 + AT_R < Npad ? (j0 + AT_R) : j0) * GS);
                 const double no = snrm[jo];
                 const int rid = sid[jo];
+                nmx = fmax(nmx, no);
                 // two accumulator pairs (k-steps alternate): D and P chains are independent of each other as well
                 d4 Dq[2], Pq[2];
 #pragma unroll
@@ -692,6 +851,7 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                     lo[i] = fmin(lo[i], ref ? pr : POS);
                     hi[i] = fmax(hi[i], ref ? pr : NEG);
                     if (own) {  // (whole waves but for the one step where the own batch ends)
+                        if (self) atomicMin(&sh_spos[kq + 4 * i], (int)jo);
                         if (lw > om[i]) {  // a new maximum: rare once the cell itself (log-weight 0) has gone by
                             const double f = exp(om[i] - lw);  // exp(-inf) = 0 the first time
                             oa[i] *= f;
@@ -701,7 +861,8 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                         const double e = exp(lw - om[i]);
                         oa[i] += e;
                         ob[i] += !(pr > cp[i]) ? e : 0.0;
-                    } else {
+                    }
+                    if (!own || lit_on) {
                         const int slot = (kq + 4 * i + blk + rot0) & (AT_C - 1);  // == at(kq + 4 i, jo)
                         sp_[slot * 64] = pr;
                         sw_[slot * 64] = lw;
@@ -748,6 +909,7 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
             const int64_t jo = j0 + 16 * w + (lane & 15);
             const double no = jo < N ? snrm[jo] : 0.0;
             const int rid = jo < N ? sid[jo] : -1;
+            nmx = fmax(nmx, no);
             for (int kc = 0; kc < nkc; ++kc) {
                 const int k0 = kc * AT_KC;
 #pragma unroll
@@ -785,6 +947,7 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                     if (own && rid == c0 + c) {  // the cell itself: log-weight 0, always counted (:80-84)
                         lw = 0.0;
                         pr = NEG;
+                        atomicMin(&sh_spos[c], (int)jo);
                     }
                     mx1[i] = fmax(mx1[i], own ? NEG : lw);
                     lo[i] = fmin(lo[i], own ? POS : pr);
@@ -799,7 +962,8 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                         const double e = exp(lw - om[i]);
                         oa[i] += e;
                         ob[i] += !(pr > cp[i]) ? e : 0.0;
-                    } else {
+                    }
+                    if (!own || lit_on) {
                         SP[at(c, jo)] = pr;
                         SW[at(c, jo)] = lw;
                     }
@@ -823,7 +987,9 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                 om[i] = mm;
             }
         }
+        for (int o = 1; o < 64; o <<= 1) nmx = fmax(nmx, __shfl_xor(nmx, o));
         __syncthreads();
+        if (lane == 0) sh_nmx[w] = nmx;
         if ((lane & 15) == 0) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -864,13 +1030,18 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
         // (the scratch rows were written by this block and are read by it: same CU, through the L2)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
         // ---- cell by cell: own-batch probability, then the weighted quantile of the reference projections
+        const double nmax_s = fmax(fmax(sh_nmx[0], sh_nmx[1]), fmax(sh_nmx[2], sh_nmx[3]));
+        const int last_block = (int)(Npad >> 6) - 1;
+        const int gs_rt = NB8 > 0 ? NB8 * 8 : g;  // row stride of the gathered stream
+        if (tid < AT_C) sh_K[tid][0] = -1;
+        int n_lit = 0, n_back = 0;  // (thread 0's tallies: cells re-run literally, flagged cells that went the histogram way)
         for (int c = 0; c < AT_C && c0 + c < n2; ++c) {
             // (own batch: streamed cells [0, nr2); reference batch: [nr2, N))
             auto w1 = [&](int64_t o_) { return SW[at(c, nr2 + o_)]; };
-            const int last_block = (int)(Npad >> 6) - 1;
             const double curproj = sc_proj[c], l2 = sc_l2[c];
             const double prob2 = sc_mx2[c];  // (taken online by the stream, see above)
             double ref_quan = __builtin_nan("");
+            bool literal = false;
             if (nr1 > 0) {
                 const double mx = sc_mx1[c];
                 const double FIX = 1099511627776.0;  // 2^40
@@ -878,20 +1049,324 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                 unsigned long long before = 0;          // weight of the projections below blo
                 double target = -1.0;                   // in fixed-point units, known after the first histogram
                 ref_quan = sc_hi[c];                    // default: the last one (:141)
-                for (int round = 0; round < 40; ++round) {
-                    for (int b = tid; b < AT_NB; b += T) hist[b] = 0ull;
-                    if (tid == 0) sh_cnt = 0;
-                    __syncthreads();
-                    const double scale = bhi > blo ? (double)AT_NB / (bhi - blo) : 0.0;
+                // Flagged: (i) the own batch's cumulative probability at the cell is 1 to within 1e-6, i.e. the walk over the
+                // reference batch runs to where all but 1e-6 of the weight has gone by -- and is decided by single addends of
+                // relative size <= 1e-6, far enough down for the rounding of the two summation orders to matter; (ii) it is below
+                // e^-12 (a cell that is not in its own batch's restrict vector can sit far below all the weight): the walk ends among
+                // addends the 2^-40 fixed-point weights of the histogram do not resolve.  (Cells in between cross on addends the
+                // histogram way resolves.)
+                const bool flagged = lit_on && (-prob2 < 1e-6 || prob2 < -12.0);
+                const unsigned long long NEGBITS = 0xFFF0000000000000ull;  // -inf
+                // ---- the first histogram of the walk; for a flagged cell also every bin's largest log-weight and the number
+                // of reference cells within 38.5 of the largest one (all of those are kept addends)
+                for (int b = tid; b < AT_NB; b += T) {
+                    hist[b] = 0ull;
+                    binmax[b] = NEGBITS;
+                }
+                if (tid == 0) sh_cnt = 0;
+                __syncthreads();
+                const double scale0 = bhi > blo ? (double)AT_NB / (bhi - blo) : 0.0;
+                int cG = 0;
+                if (flagged) {
                     asv_row_scan<true>(SP, SW, nr2, nr1, c + rot0, last_block, tid, [&](double pr, double lw, int o) {
                         const bool in = o < nr1 && pr >= blo && pr <= bhi;
-                        int b = (int)((pr - blo) * scale);
+                        int b = (int)((pr - blo) * scale0);
+                        b = b < 0 ? 0 : (b > AT_NB - 1 ? AT_NB - 1 : b);
+                        const double wv = exp(lw - mx) * FIX;
+                        atomicAdd(&hist[in ? b : (tid & (AT_NB - 1))], in ? (unsigned long long)wv : 0ull);
+                        // (log-weights are <= -0: as bit patterns the largest value is the smallest pattern)
+                        atomicMin(&binmax[in ? b : (tid & (AT_NB - 1))], in ? (unsigned long long)__double_as_longlong(lw) : NEGBITS);
+                        cG += in && lw >= mx - 38.5 ? 1 : 0;
+                    });
+                } else {
+                    asv_row_scan<true>(SP, SW, nr2, nr1, c + rot0, last_block, tid, [&](double pr, double lw, int o) {
+                        const bool in = o < nr1 && pr >= blo && pr <= bhi;
+                        int b = (int)((pr - blo) * scale0);
                         b = b < 0 ? 0 : (b > AT_NB - 1 ? AT_NB - 1 : b);
                         const double wv = exp(lw - mx) * FIX;
                         // (an element out of play adds nothing to a bin of the thread's own: no branch, no pile-up on one bin)
                         atomicAdd(&hist[in ? b : (tid & (AT_NB - 1))], in ? (unsigned long long)wv : 0ull);
                     });
+                }
+                __syncthreads();
+                if (flagged) {
+                    int* smi = reinterpret_cast<int*>(sm);
+                    smi[tid] = cG;
                     __syncthreads();
+                    for (int o2 = T / 2; o2 > 0; o2 >>= 1) {
+                        if (tid < o2) smi[tid] += smi[tid + o2];
+                        __syncthreads();
+                    }
+                    const int cGtot = smi[0];
+                    __syncthreads();
+                    if (cGtot <= lcap) {
+                        // ================= the literal re-run (see the comment in front of asv_noop_below) =================
+                        const double cn_c = sc_n[c];
+                        const double mb = 1e-3 + 1e-13 * (cn_c + nmax_s) / sigma2;      // >= the rounding of a GEMM-form log-weight
+                        const double tolp = 1e-13 * (sqrt(cn_c) + sqrt(nmax_s)) + 1e-300;  // >= the rounding of a projection
+                        int32_t* giO = GI;
+                        int32_t* giR = GI + lcap;
+                        int32_t* giS = GI + 2 * lcap;
+                        // (b) per bin: the threshold below which a reference cell cannot change the SORTED chain -- from the
+                        // largest log-weight of the bins at least two back (every cell of those sorts in front of every cell of
+                        // this bin whatever the rounding of the projections, as long as a bin is much wider than that rounding)
+                        double* binthr = reinterpret_cast<double*>(binmax);
+                        {
+                            const bool wide = (bhi - blo) > 16.0 * AT_NB * tolp;
+                            double v[8], m8 = NEG;
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) {
+                                v[k] = __longlong_as_double((long long)binmax[8 * tid + k]);
+                                m8 = fmax(m8, v[k]);
+                            }
+                            double inc = m8;
+                            for (int o2 = 1; o2 < 64; o2 <<= 1) {
+                                const double t2 = __shfl_up(inc, o2);
+                                if (lane >= o2) inc = fmax(inc, t2);
+                            }
+                            __syncthreads();
+                            if (lane == 63) sm[w] = inc;
+                            __syncthreads();
+                            double run = __shfl_up(inc, 1);
+                            if (lane == 0) run = NEG;
+                            for (int ww = 0; ww < w; ++ww) run = fmax(run, sm[ww]);
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) {
+                                const double E = run;  // largest log-weight of the bins in front of bin 8 tid + k
+                                run = fmax(run, v[k]);
+                                if (8 * tid + k + 1 < AT_NB)
+                                    binthr[8 * tid + k + 1] = wide ? asv_thr_neg(E, mx, (double)nr1, mb) : NEG;
+                            }
+                            if (tid == 0) {
+                                binthr[0] = NEG;
+                                sh_sel[0] = sh_sel[1] = sh_sel[2] = 0;
+                            }
+                            __syncthreads();
+                        }
+                        // (c) the reference batch: kept addends of totalprob1's chain (restrict order) and of the walk's.  A piece's
+                        // elements are held against the largest log-weight of the pieces in front of it; the chain never exceeds
+                        // mx + log(nr1), mx the largest log-weight of all (from the stream).
+                        {
+                            double Mr = NEG, thrR = NEG, mT = NEG;
+                            int par = 0;
+                            const double hi_keep = bhi - 2.0 * tolp;  // (the last projection of the sort is the walk's default, :141)
+                            asv_row_scan_pieces(
+                                SP, SW, nr2, nr1, c + rot0, last_block, tid,
+                                [&](double, double lw, int o) { mT = fmax(mT, o < nr1 ? lw : NEG); },
+                                [&](int) -> bool {
+                                    thrR = asv_thr_neg(Mr, mx, (double)nr1, mb);  // (from the pieces in front of this one)
+                                    double r = mT;
+                                    for (int o2 = 1; o2 < 64; o2 <<= 1) r = fmax(r, __shfl_xor(r, o2));
+                                    double* smx = sm + par * 8;
+                                    if (lane == 0) smx[w] = r;
+                                    if (tid == 0) smx[4] = (sh_sel[1] > lcap || sh_sel[2] > lcap) ? 1.0 : 0.0;
+                                    __syncthreads();
+                                    Mr = fmax(Mr, fmax(fmax(smx[0], smx[1]), fmax(smx[2], smx[3])));
+                                    mT = NEG;
+                                    par ^= 1;
+                                    return smx[4] != 0.0;
+                                },
+                                [&](double pr, double lw, int o) {
+                                    const bool in = o < nr1;
+                                    int b = (int)((pr - blo) * scale0);
+                                    b = b < 0 ? 0 : (b > AT_NB - 1 ? AT_NB - 1 : b);
+                                    if (in && lw >= thrR) {
+                                        const int pos = atomicAdd(&sh_sel[1], 1);
+                                        if (pos < lcap) giR[pos] = o;
+                                    }
+                                    if (in && (lw >= binthr[b] || pr >= hi_keep)) {
+                                        const int pos = atomicAdd(&sh_sel[2], 1);
+                                        if (pos < lcap) giS[pos] = o;
+                                    }
+                                });
+                            __syncthreads();
+                        }
+                        bool ok = sh_sel[1] <= lcap && sh_sel[2] <= lcap;
+                        // (d) the own batch: kept addends of totalprob2's and prob2's chains (one list: an addend that is a
+                        // no-op for one of them is one in the re-run as well).  The cell's own first place in restrict2 (spos, from
+                        // the stream) splits the chains into their two regimes; elements in front of it are held against the largest
+                        // log-weight of the pieces in front of theirs and the chain is bounded with their own piece's included, those
+                        // behind it against the largest other log-weight of the pieces in front.
+                        if (ok) {
+                            const int spos = sh_spos[c];
+                            double Tb = NEG, Tx = NEG, Pb = NEG, Px = NEG;          // totalprob2 / prob2: before the cell, others anywhere
+                            double mTb = NEG, mTx = NEG, mPb = NEG, mPx = NEG;      // the same of the current piece
+                            double thrTb = NEG, thrPb = NEG, thrTa = NEG, thrPa = NEG;
+                            int par = 0;
+                            asv_row_scan_pieces(
+                                SP, SW, 0, nr2, c + rot0, last_block, tid,
+                                [&](double pr, double lw, int o) {
+                                    const bool in = o < nr2;
+                                    const bool other = in && o != spos;              // (later occurrences of the cell: log-weight 0, addends like any other)
+                                    const bool sure = other && pr <= curproj - tolp;  // counted in prob2 whatever the rounding (:90-92)
+                                    mTx = fmax(mTx, other ? lw : NEG);
+                                    mPx = fmax(mPx, sure ? lw : NEG);
+                                    mTb = fmax(mTb, other && o < spos ? lw : NEG);
+                                    mPb = fmax(mPb, sure && o < spos ? lw : NEG);
+                                },
+                                [&](int end) -> bool {
+                                    double r0 = mTb, r1 = mTx, r2 = mPb, r3 = mPx;
+                                    for (int o2 = 1; o2 < 64; o2 <<= 1) {
+                                        r0 = fmax(r0, __shfl_xor(r0, o2));
+                                        r1 = fmax(r1, __shfl_xor(r1, o2));
+                                        r2 = fmax(r2, __shfl_xor(r2, o2));
+                                        r3 = fmax(r3, __shfl_xor(r3, o2));
+                                    }
+                                    double* smx = sm + par * 32;
+                                    if (lane == 0) {
+                                        smx[w * 4 + 0] = r0;
+                                        smx[w * 4 + 1] = r1;
+                                        smx[w * 4 + 2] = r2;
+                                        smx[w * 4 + 3] = r3;
+                                    }
+                                    if (tid == 0) smx[16] = sh_sel[0] > lcap ? 1.0 : 0.0;
+                                    __syncthreads();
+                                    double pTb = NEG, pTx = NEG, pPb = NEG, pPx = NEG;
+                                    for (int ww = 0; ww < 4; ++ww) {
+                                        pTb = fmax(pTb, smx[ww * 4 + 0]);
+                                        pTx = fmax(pTx, smx[ww * 4 + 1]);
+                                        pPb = fmax(pPb, smx[ww * 4 + 2]);
+                                        pPx = fmax(pPx, smx[ww * 4 + 3]);
+                                    }
+                                    const double cnt = (double)(end < nr2 ? end : nr2);
+                                    // in front of the cell: lower bound from the pieces in front, upper bound with this piece's
+                                    thrTb = asv_thr_neg(Tb, fmax(Tb, pTb), cnt, mb);
+                                    thrPb = Pb == NEG ? NEG : asv_thr_neg(Pb, fmax(Tb, pTb), cnt, mb);  // (prob2's chain never exceeds totalprob2's)
+                                    // behind it: the chains stand at log(1 + others)
+                                    thrTa = asv_thr_self(Tx, mb);
+                                    thrPa = asv_thr_self(Px, mb);
+                                    Tb = fmax(Tb, pTb);
+                                    Tx = fmax(Tx, pTx);
+                                    Pb = fmax(Pb, pPb);
+                                    Px = fmax(Px, pPx);
+                                    mTb = mTx = mPb = mPx = NEG;
+                                    par ^= 1;
+                                    return smx[16] != 0.0;
+                                },
+                                [&](double pr, double lw, int o) {
+                                    const bool in = o < nr2;
+                                    const bool maybe = pr <= curproj + tolp;
+                                    const bool behind = o > spos;
+                                    const double tT = behind ? thrTa : thrTb, tP = behind ? thrPa : thrPb;
+                                    if (in && (o == spos || lw >= tT || (maybe && lw >= tP))) {
+                                        const int pos = atomicAdd(&sh_sel[0], 1);
+                                        if (pos < lcap) giO[pos] = o;
+                                    }
+                                });
+                            __syncthreads();
+                            ok = sh_sel[0] <= lcap;
+                        }
+                        if (ok) {
+                            // (e) the kept addends, recomputed in the reference's order of operations
+                            const int KO = sh_sel[0], KR = sh_sel[1], KS = sh_sel[2];
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");  // (the index lists went to global memory)
+                            int* ib = reinterpret_cast<int*>(ub);
+                            const double* cur = cx + c * GP;
+                            const double* grd = cg + c * GP;
+                            auto sorted_ints = [&](const int32_t* gi, int cnt) {  // -> ib[0 .. cnt) ascending
+                                int np2 = 1;
+                                while (np2 < cnt) np2 <<= 1;
+                                for (int i = tid; i < np2; i += T) ib[i] = i < cnt ? gi[i] : 0x7fffffff;
+                                __syncthreads();
+                                for (int k = 2; k <= np2; k <<= 1)
+                                    for (int j = k >> 1; j > 0; j >>= 1) {
+                                        for (int i = tid; i < np2; i += T) {
+                                            const int ixj = i ^ j;
+                                            if (ixj > i) {
+                                                const int a = ib[i], b2 = ib[ixj];
+                                                if (((i & k) == 0) ? a > b2 : a < b2) {
+                                                    ib[i] = b2;
+                                                    ib[ixj] = a;
+                                                }
+                                            }
+                                        }
+                                        __syncthreads();
+                                    }
+                            };
+                            sorted_ints(giR, KR);  // totalprob1's chain runs in restrict order (:117-131)
+                            for (int i = tid; i < KR; i += T) {
+                                double pr, lw;
+                                asv_pair_literal(cur, grd, S + ((int64_t)nr2 + ib[i]) * gs_rt, g, sigma2, pr, lw);
+                                LR[(int64_t)c * lcap + i] = lw;
+                            }
+                            __syncthreads();
+                            sorted_ints(giO, KO);  // totalprob2's and prob2's likewise (:78-109)
+                            for (int i = tid; i < KO; i += T) {
+                                const int j = ib[i];
+                                double pr = 0.0, lw = 0.0;
+                                bool add = true;
+                                if (sid[j] != c0 + c) {  // :84
+                                    asv_pair_literal(cur, grd, S + (int64_t)j * gs_rt, g, sigma2, pr, lw);
+                                    add = !(pr > curproj);  // :90-92
+                                }
+                                LO[((int64_t)c * lcap + i) * 2] = lw;
+                                LO[((int64_t)c * lcap + i) * 2 + 1] = add ? 1.0 : 0.0;
+                            }
+                            __syncthreads();
+                            // the walk's chain runs over the (projection, log-weight) pairs as std::sort orders them (:134)
+                            double* kp = ub;
+                            double* kw = ub + lcap;
+                            int np2 = 1;
+                            while (np2 < KS) np2 <<= 1;
+                            for (int i = tid; i < np2; i += T) {
+                                double pr = POS, lw = POS;
+                                if (i < KS) asv_pair_literal(cur, grd, S + ((int64_t)nr2 + giS[i]) * gs_rt, g, sigma2, pr, lw);
+                                kp[i] = pr;
+                                kw[i] = lw;
+                            }
+                            __syncthreads();
+                            for (int k = 2; k <= np2; k <<= 1)
+                                for (int j = k >> 1; j > 0; j >>= 1) {
+                                    for (int i = tid; i < np2; i += T) {
+                                        const int ixj = i ^ j;
+                                        if (ixj > i) {
+                                            const double p0 = kp[i], w0 = kw[i], p1 = kp[ixj], w1_ = kw[ixj];
+                                            const bool up = (i & k) == 0;
+                                            if (up ? pair_less(p1, w1_, p0, w0) : pair_less(p0, w0, p1, w1_)) {
+                                                kp[i] = p1;
+                                                kw[i] = w1_;
+                                                kp[ixj] = p0;
+                                                kw[ixj] = w0;
+                                            }
+                                        }
+                                    }
+                                    __syncthreads();
+                                }
+                            for (int i = tid; i < KS; i += T) {
+                                LS[((int64_t)c * lcap + i) * 2] = kp[i];
+                                LS[((int64_t)c * lcap + i) * 2 + 1] = kw[i];
+                            }
+                            if (tid == 0) {
+                                sh_K[c][0] = KO;
+                                sh_K[c][1] = KR;
+                                sh_K[c][2] = KS;
+                            }
+                            literal = true;
+                            ++n_lit;
+                            __syncthreads();
+                        }
+                    }
+                    if (!literal) ++n_back;
+                }
+                if (!literal)
+                for (int round = 0; round < 40; ++round) {
+                    if (round > 0) {  // (round 0's histogram is the one taken above)
+                        for (int b = tid; b < AT_NB; b += T) hist[b] = 0ull;
+                        if (tid == 0) sh_cnt = 0;
+                        __syncthreads();
+                    }
+                    const double scale = bhi > blo ? (double)AT_NB / (bhi - blo) : 0.0;
+                    if (round > 0) {
+                        asv_row_scan<true>(SP, SW, nr2, nr1, c + rot0, last_block, tid, [&](double pr, double lw, int o) {
+                            const bool in = o < nr1 && pr >= blo && pr <= bhi;
+                            int b = (int)((pr - blo) * scale);
+                            b = b < 0 ? 0 : (b > AT_NB - 1 ? AT_NB - 1 : b);
+                            const double wv = exp(lw - mx) * FIX;
+                            // (an element out of play adds nothing to a bin of the thread's own: no branch, no pile-up on one bin)
+                            atomicAdd(&hist[in ? b : (tid & (AT_NB - 1))], in ? (unsigned long long)wv : 0ull);
+                        });
+                        __syncthreads();
+                    }
                     const double ep2 = exp(prob2);
                     const int at = asv_first_crossing(
                         hist, AT_NB, before,
@@ -981,7 +1456,59 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                     __syncthreads();
                 }
             }
-            if (tid == 0) out[c0 + c] = (ref_quan - curproj) / l2;  // :160
+            if (!literal && tid == 0) out[c0 + c] = (ref_quan - curproj) / l2;  // :160
+            __syncthreads();
+        }
+        // ---- the literal re-run's chains: one lane per chain, the reference's sequential sums (:96-109, :127-131), then
+        // one lane per cell for the walk (:137-157)
+        if (lit_on) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");  // (the lists were written by other threads of the block)
+            if (tid < 3 * AT_C) {
+                const int c = tid & (AT_C - 1), which = tid >> 4;
+                const int KO = sh_K[c][0];
+                if (KO >= 0) {
+                    double acc = 0.0;
+                    bool first = true;
+                    if (which < 2) {
+                        const double* L = LO + (int64_t)c * lcap * 2;
+                        for (int i = 0; i < KO; ++i) {
+                            const double lw = L[2 * i];
+                            if (which == 0 || L[2 * i + 1] != 0.0) {
+                                acc = first ? lw : bmx_pm_logspace_add(acc, lw);
+                                first = false;
+                            }
+                        }
+                    } else {
+                        const double* L = LR + (int64_t)c * lcap;
+                        const int KR = sh_K[c][1];
+                        for (int i = 0; i < KR; ++i) {
+                            acc = first ? L[i] : bmx_pm_logspace_add(acc, L[i]);
+                            first = false;
+                        }
+                    }
+                    sh_chain[c][which] = acc;
+                }
+            }
+            __syncthreads();
+            if (tid < AT_C && c0 + tid < n2 && sh_K[tid][0] >= 0) {
+                const int c = tid, KS = sh_K[c][2];
+                const double* L = LS + (int64_t)c * lcap * 2;
+                const double tgt = (sh_chain[c][1] - sh_chain[c][0]) + sh_chain[c][2];  // :111, :138
+                double cum = 0.0, rq = L[2 * (KS - 1)];  // :141
+                for (int i = 0; i < KS; ++i) {
+                    cum = i == 0 ? L[1] : bmx_pm_logspace_add(cum, L[2 * i + 1]);
+                    if (cum >= tgt) {
+                        rq = L[2 * i];
+                        break;
+                    }
+                }
+                out[c0 + c] = (rq - sc_proj[c]) / sc_l2[c];  // :160
+            }
+            if (tid == 0 && tally) {
+                atomicAdd(&tally[0], (unsigned long long)n_lit);
+                atomicAdd(&tally[1], (unsigned long long)n_back);
+                atomicAdd(&tally[2], (unsigned long long)(n2 - c0 < AT_C ? n2 - c0 : AT_C));
+            }
             __syncthreads();
         }
     }
@@ -1014,6 +1541,29 @@ void smooth_gaussian_kernel_device(hipStream_t stream, const double* averaged, i
 // (bit-exact walk; up to 131 072 restricted cells and 4e7 pairs); exact = 0: the tiled FP64-MFMA form, `blocks` workgroups
 // with 2 x 16 x (nr1 + nr2) doubles of scratch each, behind them (`extra_doubles`) the gathered stream, the squared norms
 // of its cells and -- vect handed over column-major -- a row-major copy of vect.
+// Counters of the tiled form, per device, for tests and bench.py (bmx_dev_get "asv_literal_cells" / "asv_fallback_cells" /
+// "asv_tiled_cells"): cells re-run literally, flagged cells that went the histogram way (more than lcap kept addends),
+// all cells the tiled form has handled.  Added up until "asv_tally_reset".
+static unsigned long long* g_tally[64] = {};
+unsigned long long* asv_tally_device() {
+    int dev = 0;
+    BMX_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return nullptr;
+    if (!g_tally[dev]) {
+        BMX_HIP(hipMalloc(reinterpret_cast<void**>(&g_tally[dev]), 4 * sizeof(unsigned long long)));
+        BMX_HIP(hipMemset(g_tally[dev], 0, 4 * sizeof(unsigned long long)));
+    }
+    return g_tally[dev];
+}
+void asv_tally_read(unsigned long long out[3], bool reset) {
+    unsigned long long* t = asv_tally_device();
+    out[0] = out[1] = out[2] = 0;
+    if (!t) return;
+    BMX_HIP(hipDeviceSynchronize());
+    BMX_HIP(hipMemcpy(out, t, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (reset) BMX_HIP(hipMemset(t, 0, 4 * sizeof(unsigned long long)));
+}
+
 AsvPlan adjust_shift_variance_plan(int g, int n2, int nr1, int nr2, int vect_row_major) {
     AsvPlan pl;
     // the bit-exact form's sequential log-sum chains cost ~1.6 ns per (cell, restricted cell) pair, the tiled form 0.015:
@@ -1031,7 +1581,10 @@ AsvPlan adjust_shift_variance_plan(int g, int n2, int nr1, int nr2, int vect_row
         return pl;
     }
     const size_t N = asv_tile_npad((size_t)nr1 + (size_t)nr2);  // (padded to whole pairs of steps of the stream)
-    const size_t per_block = (size_t)2 * AT_C * N;
+    // the literal re-run of flagged cells keeps at most lcap addends per chain (testing hook "asv_cap": 0 = off, n = at most n)
+    pl.lcap = asv_tile_lcap_default(g);
+    if (dev_knobs().asv_cap >= 0) pl.lcap = std::min(pl.lcap, dev_knobs().asv_cap);
+    const size_t per_block = (size_t)2 * AT_C * N + (size_t)asv_tile_list_doubles(pl.lcap);
     const size_t budget = (size_t)12 << 30;  // doubles: 96 GiB of the 288 at most
     const size_t tiles = ((size_t)std::max(n2, 1) + AT_C - 1) / AT_C;
     pl.blocks = (int)std::max<size_t>(1, std::min<size_t>({tiles, (size_t)256, budget / per_block}));
@@ -1071,12 +1624,14 @@ void adjust_shift_variance_device(hipStream_t stream, const double* data1, int g
         }
         hipLaunchKernelGGL(asv_gather_stream, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, stream, data1, data2, g, gs, restrict1,
                            nr1, restrict2, nr2, N, S, snrm, sid);
-        const size_t lds = asv_tile_lds_bytes(g);
+        const size_t lds = asv_tile_lds_bytes(g, pl.lcap);
+        unsigned long long* tally = asv_tally_device();
 #define BMX_ASV_TILE(NB8)                                                                                                    \
     case NB8:                                                                                                                \
         ensure_dynamic_lds(reinterpret_cast<const void*>(&asv_tile_kernel<NB8>), lds);                                       \
         hipLaunchKernelGGL(asv_tile_kernel<NB8>, dim3(blocks), dim3(T), lds, stream, g, data2, n2, vrm, sigma2, nr1, nr2,     \
-                           (const double*)S, (const double*)snrm, (const int32_t*)sid, out, ws_pairs, cell_begin, cell_end);  \
+                           (const double*)S, (const double*)snrm, (const int32_t*)sid, out, ws_pairs, cell_begin, cell_end,  \
+                           pl.lcap, tally);                                                                                \
         break
         switch (asv_tile_nb8(g)) {
             BMX_ASV_TILE(1);

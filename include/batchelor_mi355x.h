@@ -97,8 +97,15 @@ void bmx_set_force_exact_knn(int32_t on);
  * FP64 scan only), "sample" (rows of a candidate pass's threshold sample, -1 = automatic), "split_c" / "force_c"
  * (reference ranges of the tail / of every query block), "no_margin" (fp16 tier: lists cut at their KS-th best only),
  * "asv_fast" (the tiled form of adjust_shift_variance at any size), "exchange_always" (a single rank goes through its
- * exchange transport too), "refine_wave" (the exact re-rank spends a whole wave on every query), "reset" (all back to their defaults).  Unknown name: BMX_ERR_ARG. */
+ * exchange transport too), "refine_wave" (the exact re-rank spends a whole wave on every query), "asv_cap" (tiled
+ * adjust_shift_variance: addends a chain of the literal re-run of an ill-conditioned cell may keep; -1 = default, 0 = no
+ * re-run), "reset" (all back to their defaults).  Unknown name: BMX_ERR_ARG. */
 int32_t bmx_dev_set(const char* name, int32_t value);
+/* Counters for tests and bench.py, current device: "asv_tiled_cells" (cells the tiled form of adjust_shift_variance has
+ * handled), "asv_literal_cells" (of those, re-run in the reference's order of operations: bit-equal to the exact form),
+ * "asv_fallback_cells" (ill-conditioned cells with too many significant pairs for the re-run: histogram quantile, may pick a
+ * neighbouring quantile), "asv_tally_reset" (zeroes them).  Waits for the device. */
+int32_t bmx_dev_get(const char* name, int64_t* value);
 /* Testing hook, needs no GPU: dst[0, bytes) = src[0, bytes) by the pool of host threads that moves the boundary's
  * matrices between the caller's memory and the pinned staging buffers (csrc/host_xfer.hpp) -- lets a CPU test hammer that
  * pool from several threads at once. */

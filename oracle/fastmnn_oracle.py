@@ -113,18 +113,21 @@ def smooth_gaussian_kernel(averaged, index, mat, sigma2):
     return out
 
 
-def adjust_shift_variance(data1, data2, vect, sigma2, restrict1, restrict2):
-    """src/adjust_shift_variance.cpp:30-164.  data1 [g x n1], data2 [g x n2], vect [n2 x g], restrict* 0-based."""
+def adjust_shift_variance(data1, data2, vect, sigma2, restrict1, restrict2, cells=None):
+    """src/adjust_shift_variance.cpp:30-164.  data1 [g x n1], data2 [g x n2], vect [n2 x g], restrict* 0-based.
+    `cells` (0-based) evaluates only those cells of data2 -- the loop at :51 treats every cell on its own."""
     data1 = np.asfortranarray(data1, dtype=np.float64)
     data2 = np.asfortranarray(data2, dtype=np.float64)
     vect = np.asfortranarray(vect, dtype=np.float64)
     r1 = np.ascontiguousarray(restrict1, dtype=np.int32)
     r2 = np.ascontiguousarray(restrict2, dtype=np.int32)
-    out = np.zeros(data2.shape[1], dtype=np.float64)
-    rc = lib().orc_adjust_shift_variance(_p(data1, c_f64p), data1.shape[0], data1.shape[1], _p(data2, c_f64p),
-                                         data2.shape[0], data2.shape[1], _p(vect, c_f64p), vect.shape[0],
-                                         vect.shape[1], ctypes.c_double(sigma2), _p(r1, c_i32p), r1.size,
-                                         _p(r2, c_i32p), r2.size, _p(out, c_f64p))
+    cl = None if cells is None else np.ascontiguousarray(cells, dtype=np.int32)
+    out = np.zeros(data2.shape[1] if cl is None else cl.size, dtype=np.float64)
+    rc = lib().orc_adjust_shift_variance_cells(_p(data1, c_f64p), data1.shape[0], data1.shape[1], _p(data2, c_f64p),
+                                               data2.shape[0], data2.shape[1], _p(vect, c_f64p), vect.shape[0],
+                                               vect.shape[1], ctypes.c_double(sigma2), _p(r1, c_i32p), r1.size,
+                                               _p(r2, c_i32p), r2.size, None if cl is None else _p(cl, c_i32p),
+                                               0 if cl is None else cl.size, _p(out, c_f64p))
     if rc:
         raise RuntimeError(ORC_MESSAGES.get(rc, str(rc)))
     return out

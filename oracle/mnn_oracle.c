@@ -316,16 +316,86 @@ static double dot(const double* a, const double* b, int32_t g) {
     return s;
 }
 
-int orc_adjust_shift_variance(const double* data1, int32_t g1, int32_t n1, const double* data2, int32_t g2, int32_t n2,
-                              const double* vect, int32_t vrow, int32_t vcol, double sigma2, const int32_t* restrict1,
-                              int32_t nr1, const int32_t* restrict2, int32_t nr2, double* out) {
+/* one cell of the loop at :51-161; work / grad : g doubles, d1 : nr1 entries */
+static double asv_one_cell(const double* data1, const double* data2, int32_t g, int32_t n2, const double* vect,
+                           double sigma2, const int32_t* restrict1, int32_t nr1, const int32_t* restrict2, int32_t nr2,
+                           int32_t cell, double* work, double* grad, pw_t* d1) {
+    const double* cur = data2 + (size_t)cell * g;
+    double l2 = 0.0; /* :57-68 */
+    for (int32_t x = 0; x < g; ++x) {
+        grad[x] = vect[(size_t)x * n2 + cell];
+        l2 += grad[x] * grad[x];
+    }
+    l2 = sqrt(l2);
+    if (l2 != 0.0)
+        for (int32_t x = 0; x < g; ++x) grad[x] /= l2;
+    const double curproj = dot(grad, cur, g); /* :70 */
+
+    double prob2 = 0.0, tot2 = 0.0; /* :74-112 */
+    int first_p = 1, first_t = 1;
+    for (int32_t s = 0; s < nr2; ++s) {
+        const int32_t same = restrict2[s];
+        int add = 1;
+        double lp = 0.0;
+        if (same != cell) {
+            const double* sc = data2 + (size_t)same * g;
+            const double sproj = dot(grad, sc, g);
+            const double sd = dist2_to_line(cur, grad, sc, work, g);
+            lp = -sd / sigma2;
+            if (sproj > curproj) add = 0;
+        }
+        if (add) {
+            prob2 = first_p ? lp : logspace_add(prob2, lp);
+            first_p = 0;
+        }
+        tot2 = first_t ? lp : logspace_add(tot2, lp);
+        first_t = 0;
+    }
+    prob2 -= tot2;
+
+    double tot1 = 0.0; /* :115-135 */
+    for (int32_t o = 0; o < nr1; ++o) {
+        const double* oc = data1 + (size_t)restrict1[o] * g;
+        d1[o].proj = dot(grad, oc, g);
+        d1[o].logw = -dist2_to_line(cur, grad, oc, work, g) / sigma2;
+        tot1 = o == 0 ? d1[o].logw : logspace_add(tot1, d1[o].logw);
+    }
+    qsort(d1, (size_t)nr1, sizeof(pw_t), pw_cmp);
+
+    double ref_quan = NAN; /* :138-157 */
+    if (nr1 > 0) {
+        const double target = prob2 + tot1;
+        double cum = 0.0;
+        ref_quan = d1[nr1 - 1].proj;
+        for (int32_t o = 0; o < nr1; ++o) {
+            cum = o == 0 ? d1[o].logw : logspace_add(cum, d1[o].logw);
+            if (cum >= target) {
+                ref_quan = d1[o].proj;
+                break;
+            }
+        }
+    }
+    return (ref_quan - curproj) / l2; /* :160 */
+}
+
+/* cells == NULL: every cell of data2 (the reference's loop, out : n2); otherwise only the listed cells (0-based, out :
+ * ncells) -- each cell's value is independent of the others (:51), which is what lets a test check a sample of a call
+ * whose whole would take a CPU hours. */
+int orc_adjust_shift_variance_cells(const double* data1, int32_t g1, int32_t n1, const double* data2, int32_t g2,
+                                    int32_t n2, const double* vect, int32_t vrow, int32_t vcol, double sigma2,
+                                    const int32_t* restrict1, int32_t nr1, const int32_t* restrict2, int32_t nr2,
+                                    const int32_t* cells, int32_t ncells, double* out) {
     if (g1 != g2 || g1 != vcol) return ORC_ERR_DIM_GENES; /* :33-36 */
     if (n2 != vrow) return ORC_ERR_DIM_CELLS;             /* :38-41 */
     for (int32_t i = 0; i < nr1; ++i)
         if (restrict1[i] == INT32_MIN || restrict1[i] < 0 || restrict1[i] >= n1) return ORC_ERR_SUBSET;
     for (int32_t i = 0; i < nr2; ++i)
         if (restrict2[i] == INT32_MIN || restrict2[i] < 0 || restrict2[i] >= n2) return ORC_ERR_SUBSET;
+    if (cells)
+        for (int32_t i = 0; i < ncells; ++i)
+            if (cells[i] < 0 || cells[i] >= n2) return ORC_ERR_SUBSET;
     const int32_t g = g1;
+    const int32_t todo = cells ? ncells : n2;
     int fail = 0;
 #pragma omp parallel
     {
@@ -337,68 +407,21 @@ int orc_adjust_shift_variance(const double* data1, int32_t g1, int32_t n1, const
             fail = 1;
         }
 #pragma omp for schedule(dynamic, 4)
-        for (int32_t cell = 0; cell < n2; ++cell) {
+        for (int32_t i = 0; i < todo; ++i) {
             if (!work || !grad || !d1) continue;
-            const double* cur = data2 + (size_t)cell * g;
-            double l2 = 0.0; /* :57-68 */
-            for (int32_t x = 0; x < g; ++x) {
-                grad[x] = vect[(size_t)x * n2 + cell];
-                l2 += grad[x] * grad[x];
-            }
-            l2 = sqrt(l2);
-            if (l2 != 0.0)
-                for (int32_t x = 0; x < g; ++x) grad[x] /= l2;
-            const double curproj = dot(grad, cur, g); /* :70 */
-
-            double prob2 = 0.0, tot2 = 0.0; /* :74-112 */
-            int first_p = 1, first_t = 1;
-            for (int32_t s = 0; s < nr2; ++s) {
-                const int32_t same = restrict2[s];
-                int add = 1;
-                double lp = 0.0;
-                if (same != cell) {
-                    const double* sc = data2 + (size_t)same * g;
-                    const double sproj = dot(grad, sc, g);
-                    const double sd = dist2_to_line(cur, grad, sc, work, g);
-                    lp = -sd / sigma2;
-                    if (sproj > curproj) add = 0;
-                }
-                if (add) {
-                    prob2 = first_p ? lp : logspace_add(prob2, lp);
-                    first_p = 0;
-                }
-                tot2 = first_t ? lp : logspace_add(tot2, lp);
-                first_t = 0;
-            }
-            prob2 -= tot2;
-
-            double tot1 = 0.0; /* :115-135 */
-            for (int32_t o = 0; o < nr1; ++o) {
-                const double* oc = data1 + (size_t)restrict1[o] * g;
-                d1[o].proj = dot(grad, oc, g);
-                d1[o].logw = -dist2_to_line(cur, grad, oc, work, g) / sigma2;
-                tot1 = o == 0 ? d1[o].logw : logspace_add(tot1, d1[o].logw);
-            }
-            qsort(d1, (size_t)nr1, sizeof(pw_t), pw_cmp);
-
-            double ref_quan = NAN; /* :138-157 */
-            if (nr1 > 0) {
-                const double target = prob2 + tot1;
-                double cum = 0.0;
-                ref_quan = d1[nr1 - 1].proj;
-                for (int32_t o = 0; o < nr1; ++o) {
-                    cum = o == 0 ? d1[o].logw : logspace_add(cum, d1[o].logw);
-                    if (cum >= target) {
-                        ref_quan = d1[o].proj;
-                        break;
-                    }
-                }
-            }
-            out[cell] = (ref_quan - curproj) / l2; /* :160 */
+            out[i] = asv_one_cell(data1, data2, g, n2, vect, sigma2, restrict1, nr1, restrict2, nr2, cells ? cells[i] : i,
+                                  work, grad, d1);
         }
         free(work);
         free(grad);
         free(d1);
     }
     return fail ? ORC_ERR_NOMEM : ORC_OK;
+}
+
+int orc_adjust_shift_variance(const double* data1, int32_t g1, int32_t n1, const double* data2, int32_t g2, int32_t n2,
+                              const double* vect, int32_t vrow, int32_t vcol, double sigma2, const int32_t* restrict1,
+                              int32_t nr1, const int32_t* restrict2, int32_t nr2, double* out) {
+    return orc_adjust_shift_variance_cells(data1, g1, n1, data2, g2, n2, vect, vrow, vcol, sigma2, restrict1, nr1,
+                                           restrict2, nr2, NULL, 0, out);
 }

@@ -151,39 +151,116 @@ def test_portable_logspace_add_is_the_oracles(oracle, nat):
         assert np.array_equal(a, b, equal_nan=True)
 
 
-def test_adjust_shift_variance_scalable_form_agrees_off_the_ill_conditioned_cells(oracle, nat, dev):
-    """The testing hook "asv_fast" selects the form used beyond 4e7 (cell, restricted cell) pairs (16-cell tiles on the FP64
-    matrix cores + a sort-free histogram quantile): it may pick a different cell only where the walk decides on the last
-    bit.  On the reference's own test shapes (tests/testthat/test-mnn-correct.R:96-98) that is no cell at sigma 1 .. 0.03
-    (scripts/asv_parity_probe.py: 1.0000 each); where the bandwidth is small against the data's distances -- 100
-    dimensions, sigma <= 0.3: the weights sit on a handful of cells, every walk ends where a 53-bit sum stops changing --
-    the two forms part on up to 60 % of the cells, which is why the exact form is the one every
-    size a test can check is given."""
-    dev("asv_fast", 1)
+def _asv_shapes():
+    """The reference's own test shape (tests/testthat/test-mnn-correct.R:96-98: 25 dimensions, coordinates of scale 0.1)
+    and a 100-dimension shape with BASELINE config 5's spectrum."""
     rng = np.random.default_rng(100032)
     data1 = rng.standard_normal((25, 400)) * 0.1
     data2 = rng.standard_normal((25, 1000)) * 0.1
     corvect = rng.random((1000, 25))
-    for sigma, bar in ((1.0, 0.999), (0.1, 0.999)):
-        out = nat.adjust_shift_variance(data1, data2, corvect, sigma, np.arange(400), np.arange(1000))
-        ref = oracle.adjust_shift_variance(data1, data2, corvect, sigma, np.arange(400), np.arange(1000))
-        close = np.isclose(out, ref, rtol=1e-8, atol=1e-12)
-        assert close.mean() > bar, (sigma, close.mean())
-        again = nat.adjust_shift_variance(data1, data2, corvect, sigma, np.arange(400), np.arange(1000))
-        assert np.array_equal(out, again, equal_nan=True)          # integer histogram sums: runs are bit-identical
-    # the tiled form's edges: 100 dimensions (four staged steps of 32, the last ragged), cell and stream counts that are
-    # not multiples of the tile sizes, restrict vectors in arbitrary order that leave cells out, a zero gradient
+    d1 = rng.standard_normal((100, 1237)) / np.sqrt(1.0 + np.arange(100) / 5.0)[:, None]
+    d2 = rng.standard_normal((100, 1003)) / np.sqrt(1.0 + np.arange(100) / 5.0)[:, None] + 0.3
+    cv = rng.standard_normal((1003, 100)) * 0.2
+    return {"25d": (data1, data2, corvect), "100d": (d1, d2, cv)}
+
+
+@pytest.mark.parametrize("shape", ["25d", "100d"])
+@pytest.mark.parametrize("sigma", [10.0, 1.0, 0.5, 0.3, 0.1, 0.03, 0.01])
+def test_adjust_shift_variance_tiled_form_matches_oracle_at_every_bandwidth(oracle, nat, dev, shape, sigma):
+    """The testing hook "asv_fast" selects the form used beyond 4e7 (cell, restricted cell) pairs: 16-cell tiles on the FP64
+    matrix cores, a sort-free histogram quantile for the cells whose walk crosses on weights >= 1e-6 of the total, and for
+    the others -- where the walk (src/adjust_shift_variance.cpp:137-157) is decided by the rounding of the two summation
+    orders -- the literal re-run: the reference's own sequential chains over the addends that can change them.  Round 4
+    measured 0.41 / 0.63 / 0.94 of the cells of the 100-dimension shape equal to the oracle at sigma 0.3 / 0.1 / 0.03
+    (VERDICT r4 weak #1); every cell the re-run takes is bit-equal."""
+    from batchelor_amd import _lib
+    dev("asv_fast", 1)
+    a, b, v = _asv_shapes()[shape]
+    r1, r2 = np.arange(a.shape[1]), np.arange(b.shape[1])
+    _lib.dev_get("asv_tally_reset")
+    out = nat.adjust_shift_variance(a, b, v, sigma, r1, r2)
+    lit, back, tiled = (_lib.dev_get(n) for n in ("asv_literal_cells", "asv_fallback_cells", "asv_tiled_cells"))
+    ref = oracle.adjust_shift_variance(a, b, v, sigma, r1, r2)
+    assert tiled == b.shape[1]
+    close = np.isclose(out, ref, rtol=1e-8, atol=1e-12, equal_nan=True)
+    assert close.mean() >= 0.999, (shape, sigma, close.mean(), lit, back)
+    if lit == tiled:  # every cell went through the reference's own chains: bit for bit
+        assert np.array_equal(out, ref, equal_nan=True), (shape, sigma, int((out != ref).sum()))
+    assert back == 0, (shape, sigma, back)  # at these sizes no chain keeps more addends than the re-run holds
+    again = nat.adjust_shift_variance(a, b, v, sigma, r1, r2)
+    assert np.array_equal(out, again, equal_nan=True)
+
+
+@pytest.mark.parametrize("sigma", [1.0, 0.2, 0.05])
+def test_adjust_shift_variance_tiled_form_edges(oracle, nat, dev, sigma):
+    # the tiled form's edges: 100 dimensions, cell and stream counts that are not multiples of the tile sizes, restrict
+    # vectors in arbitrary order that leave cells out and name others twice (the cell's own second occurrence is an addend
+    # like any other), a zero gradient, a cell that is not in its own batch's restrict vector
+    dev("asv_fast", 1)
+    rng = np.random.default_rng(100033)
     d1 = rng.standard_normal((100, 1237)) / np.sqrt(1.0 + np.arange(100) / 5.0)[:, None]
     d2 = rng.standard_normal((100, 1003)) / np.sqrt(1.0 + np.arange(100) / 5.0)[:, None] + 0.3
     cv = rng.standard_normal((1003, 100)) * 0.2
     cv[17] = 0.0
-    r1 = rng.permutation(1237)[:901]
-    r2 = rng.permutation(1003)[:777]
-    out = nat.adjust_shift_variance(d1, d2, cv, 1.0, r1, r2)
-    ref = oracle.adjust_shift_variance(d1, d2, cv, 1.0, r1, r2)
+    r1 = np.concatenate([rng.permutation(1237)[:901], rng.integers(0, 1237, 40)])
+    r2 = np.concatenate([rng.permutation(1003)[:777], rng.integers(0, 1003, 60)])
+    out = nat.adjust_shift_variance(d1, d2, cv, sigma, r1, r2)
+    ref = oracle.adjust_shift_variance(d1, d2, cv, sigma, r1, r2)
     close = np.isclose(out, ref, rtol=1e-8, atol=1e-12, equal_nan=True)
-    assert close.mean() > 0.999, close.mean()
+    assert close.mean() >= 0.999, (sigma, close.mean())
     assert np.isnan(out[17]) and np.isnan(ref[17])                  # 0 / 0, as the reference (:160)
+
+
+def test_adjust_shift_variance_tiled_form_beyond_the_rerun(oracle, nat, dev):
+    """What the tiled form does to an ill-conditioned cell that keeps more addends than the re-run holds (bandwidths of the
+    order of the squared distances on a large call: sigma 0.3 .. 0.7 at BASELINE config 5's size): it goes the histogram
+    way.  Forced here with the testing hook "asv_cap" (64 addends per chain, and 0 = no re-run at all = round 4's kernel):
+    the result stays finite and reproducible, the cells the re-run still takes stay bit-equal, and the agreement is the
+    number DESIGN.md quotes -- pinned from below, not asserted to be parity."""
+    from batchelor_amd import _lib
+    dev("asv_fast", 1)
+    a, b, v = _asv_shapes()["100d"]
+    r1, r2 = np.arange(a.shape[1]), np.arange(b.shape[1])
+    ref = oracle.adjust_shift_variance(a, b, v, 0.3, r1, r2)
+    share = {}
+    for cap in (0, 64):
+        dev("asv_cap", cap)
+        _lib.dev_get("asv_tally_reset")
+        out = nat.adjust_shift_variance(a, b, v, 0.3, r1, r2)
+        lit, back = _lib.dev_get("asv_literal_cells"), _lib.dev_get("asv_fallback_cells")
+        assert np.all(np.isfinite(out))
+        assert np.array_equal(out, nat.adjust_shift_variance(a, b, v, 0.3, r1, r2))
+        share[cap] = float(np.isclose(out, ref, rtol=1e-8, atol=1e-12).mean())
+        assert (lit == 0) if cap == 0 else (lit + back > 0)
+    print("tiled form without / with a 64-addend re-run at sigma 0.3, share of cells equal to the oracle:", share)
+    assert share[0] > 0.25 and share[64] >= share[0] - 0.02
+
+
+def test_adjust_shift_variance_tiled_form_large_call_sampled_cells(oracle, nat, dev):
+    """A call of 1.4e10 (cell, restricted cell) pairs -- 350x what the exact form takes -- at mnnCorrect's default bandwidth
+    (sigma = 0.1, R/mnnCorrect.R:125-130) relative to config 5's spectrum: 400 sampled cells against the oracle (the loop
+    over cells at src/adjust_shift_variance.cpp:51 treats each on its own)."""
+    from batchelor_amd import _lib
+    rng = np.random.default_rng(100034)
+    d, n1, n2 = 100, 300000, 40000
+    spec = 1.0 / np.sqrt(1.0 + np.arange(d) / 5.0)
+    d1 = (rng.standard_normal((n1, d)) * spec).T
+    d2 = (rng.standard_normal((n2, d)) * spec + 0.3).T
+    cv = rng.standard_normal((n2, d)) * 0.2 - 0.3
+    r1, r2 = np.arange(n1), np.arange(n2)
+    assert nat.adjust_shift_variance_form(n2, n1, n2) == "tiled"
+    cells = np.sort(rng.choice(n2, 400, replace=False))
+    for sigma in (0.1, 1.0):
+        _lib.dev_get("asv_tally_reset")
+        out = nat.adjust_shift_variance(d1, d2, cv, sigma, r1, r2)
+        lit, back, tiled = (_lib.dev_get(n) for n in ("asv_literal_cells", "asv_fallback_cells", "asv_tiled_cells"))
+        ref = oracle.adjust_shift_variance(d1, d2, cv, sigma, r1, r2, cells=cells)
+        close = np.isclose(out[cells], ref, rtol=1e-8, atol=1e-12)
+        print(f"sigma {sigma}: {lit} of {tiled} cells re-run literally, {back} flagged cells beyond it; "
+              f"{close.mean():.4f} of 400 sampled cells equal to the oracle")
+        assert tiled == n2 and close.mean() >= 0.999, (sigma, close.mean(), lit, back)
+        if sigma == 0.1:
+            assert lit == tiled and np.array_equal(out[cells], ref)
 
 
 def test_adjust_shift_variance_form_is_reported(nat):
