@@ -715,6 +715,11 @@ int32_t bmx_engine_snapshot(bmx_engine_t* e, double* left_rm, double* right_rm, 
     return guarded([&] { e->impl->snapshot(left_rm, right_rm, n_left, n_right); });
 }
 
+int32_t bmx_engine_snapshot_var_adj(bmx_engine_t* e, double* left_rm, double* right_rm, double* corr_rm, double* scaling,
+                                    int32_t* restrict1, int32_t* restrict2, int64_t* sizes4) {
+    return guarded([&] { e->impl->snapshot_var_adj(left_rm, right_rm, corr_rm, scaling, restrict1, restrict2, sizes4); });
+}
+
 int32_t bmx_engine_profile_detail(bmx_engine_t* e, double* out10) {
     return guarded([&] { e->impl->profile_detail(out10); });
 }

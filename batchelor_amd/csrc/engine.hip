@@ -812,6 +812,23 @@ void Engine::merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p,
                                          nRs, scaling, ws, plan, /* vect_row_major */ 1, (int)cb, (int)ce);
             queued_work_s_ += 5e-8 * (double)(ce - cb) * ((double)nLs + (double)nRs);
             exchange(scaling, per_cells * (int64_t)sizeof(double));
+            if (mdx == snap_merge_) {  // diagnostics: what adjust_shift_variance was handed at this merge, and what it returned
+                snap_anl_ = left.n;
+                snap_anr_ = right.n;
+                snap_ar1_ = nLs;
+                snap_ar2_ = nRs;
+                auto keep = [&](DevBuf<double>& b, const double* src, size_t n) {
+                    BMX_HIP(hipMemcpyAsync(b.reserve(n), src, n * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+                };
+                keep(snap_al_, left.data.p, (size_t)left.n * d_);
+                keep(snap_ar_, right.data.p, (size_t)right.n * d_);
+                keep(snap_ac_, corr, (size_t)right.n * d_);
+                keep(snap_as_, scaling, (size_t)right.n);
+                BMX_HIP(hipMemcpyAsync(snap_ai1_.reserve((size_t)std::max(nLs, 1)), r1, (size_t)nLs * sizeof(int32_t),
+                                       hipMemcpyDeviceToDevice, stream_));
+                BMX_HIP(hipMemcpyAsync(snap_ai2_.reserve((size_t)std::max(nRs, 1)), r2, (size_t)nRs * sizeof(int32_t),
+                                       hipMemcpyDeviceToDevice, stream_));
+            }
             add_scaled_rows(stream_, right.data.p, right.n, d_, corr, scaling);
         }
         right.stat_slot.assign(right.origin.size(), -1);  // the corrected cells moved
@@ -1432,6 +1449,29 @@ void Engine::snapshot(double* left_rm, double* right_rm, int64_t* nl, int64_t* n
         BMX_HIP(hipMemcpyAsync(left_rm, snap_l_.p, (size_t)snap_nl_ * d_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
     if (right_rm)
         BMX_HIP(hipMemcpyAsync(right_rm, snap_r_.p, (size_t)snap_nr_ * d_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    BMX_HIP(hipStreamSynchronize(stream_));
+}
+
+void Engine::snapshot_var_adj(double* left_rm, double* right_rm, double* corr_rm, double* scaling, int32_t* r1,
+                              int32_t* r2, int64_t* sizes4) {
+    CacheScope cache_scope(&cache_);
+    BMX_HIP(hipSetDevice(device_));
+    if (snap_merge_ < 0 || !root_ || !snap_as_.p) throw Error(BMX_ERR_ARG, "no snapshot of a variance adjustment was taken");
+    if (sizes4) {
+        sizes4[0] = snap_anl_;
+        sizes4[1] = snap_anr_;
+        sizes4[2] = snap_ar1_;
+        sizes4[3] = snap_ar2_;
+    }
+    auto out = [&](void* dst, const void* src, size_t bytes) {
+        if (dst && bytes) BMX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream_));
+    };
+    out(left_rm, snap_al_.p, (size_t)snap_anl_ * d_ * sizeof(double));
+    out(right_rm, snap_ar_.p, (size_t)snap_anr_ * d_ * sizeof(double));
+    out(corr_rm, snap_ac_.p, (size_t)snap_anr_ * d_ * sizeof(double));
+    out(scaling, snap_as_.p, (size_t)snap_anr_ * sizeof(double));
+    out(r1, snap_ai1_.p, (size_t)snap_ar1_ * sizeof(int32_t));
+    out(r2, snap_ai2_.p, (size_t)snap_ar2_ * sizeof(int32_t));
     BMX_HIP(hipStreamSynchronize(stream_));
 }
 

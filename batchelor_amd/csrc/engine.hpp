@@ -92,6 +92,8 @@ class Engine {
     // orthogonalisation, R/fastMNN.R:473-477); -1 = off
     void set_snapshot(int merge) { snap_merge_ = merge; }
     void snapshot(double* left_rm, double* right_rm, int64_t* nl, int64_t* nr);
+    void snapshot_var_adj(double* left_rm, double* right_rm, double* corr_rm, double* scaling, int32_t* r1, int32_t* r2,
+                          int64_t* sizes4);
     void profile(double* topk_ms, int64_t* launches, int64_t* fallbacks);
     // out[0..9]: full-pass ms / launches of the fp16 kernel, of the split-bf16 kernel, sample-pass ms / launches,
     // streaming-section ms (everything of the merges that is not a kNN search), queries that took the exact path,
@@ -210,6 +212,9 @@ class Engine {
     int snap_merge_ = -1;
     DevBuf<double> snap_l_, snap_r_;
     int64_t snap_nl_ = 0, snap_nr_ = 0;
+    DevBuf<double> snap_al_, snap_ar_, snap_ac_, snap_as_;  // the snapshot merge's variance adjustment: inputs and scalings
+    DevBuf<int32_t> snap_ai1_, snap_ai2_;
+    int64_t snap_anl_ = 0, snap_anr_ = 0, snap_ar1_ = 0, snap_ar2_ = 0;
 
     int B_ = 0;
     int64_t N_ = 0;

@@ -395,12 +395,16 @@ __host__ __device__ inline int asv_tile_nb8(int g) { return g <= 128 ? (g + 7) /
 inline int asv_tile_gs(int g) { return g <= 128 ? asv_tile_nb8(g) * 8 : g; }
 inline size_t asv_tile_npad(size_t N) { return std::max<size_t>((N + AT_NP - 1) / AT_NP * AT_NP, AT_NP); }
 // addends a chain of the literal re-run may keep (its sort buffer and two 16 KB bin arrays must fit the LDS beside the tile)
-inline int asv_tile_lcap_default(int g) { return g <= 128 ? 4096 : 2048; }
+// (a power of two: the lists are padded to one for the sorting networks)
+inline int asv_tile_lcap_default(int) { return 32768; }
+// ... of which this many are sorted in the LDS (beside the tile); longer lists are sorted where they lie, in global memory
+__host__ __device__ inline int asv_tile_lsort(int g) { return g <= 128 ? 4096 : 2048; }
 // doubles of the kernel's multi-purpose LDS region (see there)
 __host__ __device__ inline int asv_tile_ub_doubles(int g, int lcap) {
     const int nb8 = asv_tile_nb8(g);
     int u = 2 * AT_CAP;
-    u = u > 2 * lcap ? u : 2 * lcap;
+    const int ls = lcap < asv_tile_lsort(g) ? lcap : asv_tile_lsort(g);
+    u = u > 2 * ls ? u : 2 * ls;
     const int a = nb8 > 8 ? 2 * nb8 * 2 * 64 : 0;
     return u > a ? u : a;
 }
@@ -1263,78 +1267,123 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                             int* ib = reinterpret_cast<int*>(ub);
                             const double* cur = cx + c * GP;
                             const double* grd = cg + c * GP;
-                            auto sorted_ints = [&](const int32_t* gi, int cnt) {  // -> ib[0 .. cnt) ascending
+                            const int lsort = lcap < asv_tile_lsort(g) ? lcap : asv_tile_lsort(g);
+                            // a pass of a sorting network over a list in global memory: what the other threads of the block
+                            // wrote in the pass before must be what this pass reads
+                            auto pass_done = [&]() {
+                                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+                                __syncthreads();
+                                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+                            };
+                            // an index list ascending: in the LDS (-> ib) up to 4 lsort entries, else where it lies
+                            auto sorted_ints = [&](int32_t* gi, int cnt) -> const int32_t* {
                                 int np2 = 1;
                                 while (np2 < cnt) np2 <<= 1;
-                                for (int i = tid; i < np2; i += T) ib[i] = i < cnt ? gi[i] : 0x7fffffff;
+                                const bool in_lds = np2 <= 4 * lsort;
+                                int32_t* a = in_lds ? ib : gi;
+                                for (int i = tid; i < np2; i += T) {
+                                    if (in_lds) a[i] = i < cnt ? gi[i] : 0x7fffffff;
+                                    else if (i >= cnt) a[i] = 0x7fffffff;
+                                }
+                                if (in_lds) __syncthreads(); else pass_done();
+                                for (int k = 2; k <= np2; k <<= 1)
+                                    for (int j = k >> 1; j > 0; j >>= 1) {
+                                        for (int i = tid; i < np2; i += T) {
+                                            const int ixj = i ^ j;
+                                            if (ixj > i) {
+                                                const int x0 = a[i], x1 = a[ixj];
+                                                if (((i & k) == 0) ? x0 > x1 : x0 < x1) {
+                                                    a[i] = x1;
+                                                    a[ixj] = x0;
+                                                }
+                                            }
+                                        }
+                                        if (in_lds) __syncthreads(); else pass_done();
+                                    }
+                                return a;
+                            };
+                            {
+                                const int32_t* ix = sorted_ints(giR, KR);  // totalprob1's chain runs in restrict order (:117-131)
+                                for (int i = tid; i < KR; i += T) {
+                                    double pr, lw;
+                                    asv_pair_literal(cur, grd, S + ((int64_t)nr2 + ix[i]) * gs_rt, g, sigma2, pr, lw);
+                                    LR[(int64_t)c * lcap + i] = lw;
+                                }
+                                __syncthreads();
+                            }
+                            {
+                                const int32_t* ix = sorted_ints(giO, KO);  // totalprob2's and prob2's likewise (:78-109)
+                                for (int i = tid; i < KO; i += T) {
+                                    const int j = ix[i];
+                                    double pr = 0.0, lw = 0.0;
+                                    bool add = true;
+                                    if (sid[j] != c0 + c) {  // :84
+                                        asv_pair_literal(cur, grd, S + (int64_t)j * gs_rt, g, sigma2, pr, lw);
+                                        add = !(pr > curproj);  // :90-92
+                                    }
+                                    LO[((int64_t)c * lcap + i) * 2] = lw;
+                                    LO[((int64_t)c * lcap + i) * 2 + 1] = add ? 1.0 : 0.0;
+                                }
+                                __syncthreads();
+                            }
+                            // the walk's chain runs over the (projection, log-weight) pairs as std::sort orders them (:134)
+                            int np2 = 1;
+                            while (np2 < KS) np2 <<= 1;
+                            if (np2 <= lsort) {
+                                double* kp = ub;
+                                double* kw = ub + lsort;
+                                for (int i = tid; i < np2; i += T) {
+                                    double pr = POS, lw = POS;
+                                    if (i < KS) asv_pair_literal(cur, grd, S + ((int64_t)nr2 + giS[i]) * gs_rt, g, sigma2, pr, lw);
+                                    kp[i] = pr;
+                                    kw[i] = lw;
+                                }
                                 __syncthreads();
                                 for (int k = 2; k <= np2; k <<= 1)
                                     for (int j = k >> 1; j > 0; j >>= 1) {
                                         for (int i = tid; i < np2; i += T) {
                                             const int ixj = i ^ j;
                                             if (ixj > i) {
-                                                const int a = ib[i], b2 = ib[ixj];
-                                                if (((i & k) == 0) ? a > b2 : a < b2) {
-                                                    ib[i] = b2;
-                                                    ib[ixj] = a;
+                                                const double p0 = kp[i], w0 = kw[i], p1 = kp[ixj], w1_ = kw[ixj];
+                                                const bool up = (i & k) == 0;
+                                                if (up ? pair_less(p1, w1_, p0, w0) : pair_less(p0, w0, p1, w1_)) {
+                                                    kp[i] = p1;
+                                                    kw[i] = w1_;
+                                                    kp[ixj] = p0;
+                                                    kw[ixj] = w0;
                                                 }
                                             }
                                         }
                                         __syncthreads();
                                     }
-                            };
-                            sorted_ints(giR, KR);  // totalprob1's chain runs in restrict order (:117-131)
-                            for (int i = tid; i < KR; i += T) {
-                                double pr, lw;
-                                asv_pair_literal(cur, grd, S + ((int64_t)nr2 + ib[i]) * gs_rt, g, sigma2, pr, lw);
-                                LR[(int64_t)c * lcap + i] = lw;
-                            }
-                            __syncthreads();
-                            sorted_ints(giO, KO);  // totalprob2's and prob2's likewise (:78-109)
-                            for (int i = tid; i < KO; i += T) {
-                                const int j = ib[i];
-                                double pr = 0.0, lw = 0.0;
-                                bool add = true;
-                                if (sid[j] != c0 + c) {  // :84
-                                    asv_pair_literal(cur, grd, S + (int64_t)j * gs_rt, g, sigma2, pr, lw);
-                                    add = !(pr > curproj);  // :90-92
+                                for (int i = tid; i < KS; i += T) {
+                                    LS[((int64_t)c * lcap + i) * 2] = kp[i];
+                                    LS[((int64_t)c * lcap + i) * 2 + 1] = kw[i];
                                 }
-                                LO[((int64_t)c * lcap + i) * 2] = lw;
-                                LO[((int64_t)c * lcap + i) * 2 + 1] = add ? 1.0 : 0.0;
-                            }
-                            __syncthreads();
-                            // the walk's chain runs over the (projection, log-weight) pairs as std::sort orders them (:134)
-                            double* kp = ub;
-                            double* kw = ub + lcap;
-                            int np2 = 1;
-                            while (np2 < KS) np2 <<= 1;
-                            for (int i = tid; i < np2; i += T) {
-                                double pr = POS, lw = POS;
-                                if (i < KS) asv_pair_literal(cur, grd, S + ((int64_t)nr2 + giS[i]) * gs_rt, g, sigma2, pr, lw);
-                                kp[i] = pr;
-                                kw[i] = lw;
-                            }
-                            __syncthreads();
-                            for (int k = 2; k <= np2; k <<= 1)
-                                for (int j = k >> 1; j > 0; j >>= 1) {
-                                    for (int i = tid; i < np2; i += T) {
-                                        const int ixj = i ^ j;
-                                        if (ixj > i) {
-                                            const double p0 = kp[i], w0 = kw[i], p1 = kp[ixj], w1_ = kw[ixj];
-                                            const bool up = (i & k) == 0;
-                                            if (up ? pair_less(p1, w1_, p0, w0) : pair_less(p0, w0, p1, w1_)) {
-                                                kp[i] = p1;
-                                                kw[i] = w1_;
-                                                kp[ixj] = p0;
-                                                kw[ixj] = w0;
+                            } else {  // a long list: sorted where it lies
+                                typedef double d2a __attribute__((ext_vector_type(2)));
+                                d2a* L2 = reinterpret_cast<d2a*>(LS + (int64_t)c * lcap * 2);
+                                for (int i = tid; i < np2; i += T) {
+                                    double pr = POS, lw = POS;
+                                    if (i < KS) asv_pair_literal(cur, grd, S + ((int64_t)nr2 + giS[i]) * gs_rt, g, sigma2, pr, lw);
+                                    L2[i] = d2a{pr, lw};
+                                }
+                                pass_done();
+                                for (int k = 2; k <= np2; k <<= 1)
+                                    for (int j = k >> 1; j > 0; j >>= 1) {
+                                        for (int i = tid; i < np2; i += T) {
+                                            const int ixj = i ^ j;
+                                            if (ixj > i) {
+                                                const d2a e0 = L2[i], e1 = L2[ixj];
+                                                const bool up = (i & k) == 0;
+                                                if (up ? pair_less(e1[0], e1[1], e0[0], e0[1]) : pair_less(e0[0], e0[1], e1[0], e1[1])) {
+                                                    L2[i] = e1;
+                                                    L2[ixj] = e0;
+                                                }
                                             }
                                         }
+                                        pass_done();
                                     }
-                                    __syncthreads();
-                                }
-                            for (int i = tid; i < KS; i += T) {
-                                LS[((int64_t)c * lcap + i) * 2] = kp[i];
-                                LS[((int64_t)c * lcap + i) * 2 + 1] = kw[i];
                             }
                             if (tid == 0) {
                                 sh_K[c][0] = KO;
@@ -1583,7 +1632,11 @@ AsvPlan adjust_shift_variance_plan(int g, int n2, int nr1, int nr2, int vect_row
     const size_t N = asv_tile_npad((size_t)nr1 + (size_t)nr2);  // (padded to whole pairs of steps of the stream)
     // the literal re-run of flagged cells keeps at most lcap addends per chain (testing hook "asv_cap": 0 = off, n = at most n)
     pl.lcap = asv_tile_lcap_default(g);
-    if (dev_knobs().asv_cap >= 0) pl.lcap = std::min(pl.lcap, dev_knobs().asv_cap);
+    if (dev_knobs().asv_cap >= 0) {  // (rounded down to a power of two: the lists are padded to one)
+        int c2 = 0;
+        for (int b = 1; b > 0 && b <= dev_knobs().asv_cap; b <<= 1) c2 = b;
+        pl.lcap = std::min(pl.lcap, c2);
+    }
     const size_t per_block = (size_t)2 * AT_C * N + (size_t)asv_tile_list_doubles(pl.lcap);
     const size_t budget = (size_t)12 << 30;  // doubles: 96 GiB of the 288 at most
     const size_t tiles = ((size_t)std::max(n2, 1) + AT_C - 1) / AT_C;

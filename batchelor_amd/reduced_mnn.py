@@ -163,6 +163,19 @@ class MnnEngine:
         _lib.check(_lib.lib().bmx_engine_snapshot(self._h, _lib.f64p(left), _lib.f64p(right), None, None))
         return left, right
 
+    def snapshot_var_adj(self):
+        """What the snapshot merge's adjust_shift_variance was handed and returned (var_adj runs): dict of left, right,
+        correction (row-major [n x d]), scaling [n_right] (before pmax(., 1)), restrict1, restrict2 (0-based)."""
+        sz = (ctypes.c_int64 * 4)()
+        f = _lib.lib().bmx_engine_snapshot_var_adj
+        _lib.check(f(self._h, None, None, None, None, None, None, sz))
+        nl, nr, n1, n2 = (int(x) for x in sz)
+        out = {"left": np.zeros((nl, self.d)), "right": np.zeros((nr, self.d)), "correction": np.zeros((nr, self.d)),
+               "scaling": np.zeros(nr), "restrict1": np.zeros(n1, dtype=np.int32), "restrict2": np.zeros(n2, dtype=np.int32)}
+        _lib.check(f(self._h, _lib.f64p(out["left"]), _lib.f64p(out["right"]), _lib.f64p(out["correction"]),
+                     _lib.f64p(out["scaling"]), _lib.i32p(out["restrict1"]), _lib.i32p(out["restrict2"]), None))
+        return out
+
     def profile_detail(self):
         a = np.zeros(10, dtype=np.float64)
         _lib.check(_lib.lib().bmx_engine_profile_detail(self._h, _lib.f64p(a)))

@@ -206,6 +206,13 @@ int32_t bmx_engine_profile(bmx_engine_t* e, double* topk_ms, int64_t* topk_launc
  * matrices to read the sizes first. */
 int32_t bmx_engine_set_snapshot(bmx_engine_t* e, int32_t merge);
 int32_t bmx_engine_snapshot(bmx_engine_t* e, double* left_rm, double* right_rm, int64_t* n_left, int64_t* n_right);
+/* With params.var_adj, the snapshot merge also keeps what its adjust_shift_variance call (R/mnnCorrect.R:462-481) was handed
+ * and what it returned: the centred left and right nodes and the right cells' correction vectors (ROW-major [n x d]), the
+ * scalings [n_right] before pmax(., 1), the two restrict vectors (0-based rows of the nodes).  sizes4 = {n_left, n_right,
+ * length(restrict1), length(restrict2)}; NULL pointers are skipped.  Lets a test hold one merge of a large tree against
+ * src/adjust_shift_variance.cpp on the same inputs, a sample of cells at a time. */
+int32_t bmx_engine_snapshot_var_adj(bmx_engine_t* e, double* left_rm, double* right_rm, double* corr_rm, double* scaling,
+                                    int32_t* restrict1, int32_t* restrict2, int64_t* sizes4);
 /* Per kernel class (profiling on, since the last run started): out[0], out[1] = milliseconds and launches of the fp16
  * full pass, out[2], out[3] of the split-bf16 full pass, out[4], out[5] of the sample passes, out[6] = milliseconds of
  * the merges' streaming sections (everything that is not a kNN search), out[7] = queries that took the exact FP64
