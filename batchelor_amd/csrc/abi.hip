@@ -720,6 +720,10 @@ int32_t bmx_engine_snapshot_var_adj(bmx_engine_t* e, double* left_rm, double* ri
     return guarded([&] { e->impl->snapshot_var_adj(left_rm, right_rm, corr_rm, scaling, restrict1, restrict2, sizes4); });
 }
 
+int32_t bmx_engine_profile_var_adj(bmx_engine_t* e, double* out3) {
+    return guarded([&] { e->impl->profile_var_adj(out3); });
+}
+
 int32_t bmx_engine_profile_detail(bmx_engine_t* e, double* out10) {
     return guarded([&] { e->impl->profile_detail(out10); });
 }
@@ -754,21 +758,11 @@ int32_t bmx_fast_mnn(int32_t nbatches, int32_t d, const double* const* data, con
         // pages that fault on first touch, and the download's host copy was bound by exactly that (10 ms at 32 GB/s).  The
         // host has nothing to do while the GPU runs: a few short-lived threads touch every page now (one byte each; the
         // library overwrites every element before it returns), the download then copies into resident pages.
+        // (The size of that matrix comes from the caller's nbatches / nrows / d: nothing is written before they have been
+        // checked the way upload() checks them -- a wrong count must be BMX_ERR_ARG, not a dozen threads writing through wild
+        // memory -- and the joiner exists before the first thread does, so a failed thread creation unwinds cleanly and the
+        // call goes on without the touching.)
         std::vector<std::thread> toucher;
-        if (corrected) {
-            int64_t N = 0;
-            for (int b = 0; b < nbatches; ++b) N += nrows[b];
-            const size_t bytes = (size_t)N * (size_t)d * sizeof(double);
-            if (bytes >= ((size_t)8 << 20)) {
-                constexpr int nt = 12;
-                volatile char* base = reinterpret_cast<volatile char*>(corrected);
-                for (int t = 0; t < nt; ++t)
-                    toucher.emplace_back([base, bytes, t] {
-                        const size_t lo = bytes / nt * t, hi = t + 1 == nt ? bytes : bytes / nt * (t + 1);
-                        for (size_t o = lo; o < hi; o += 4096) base[o] = 0;
-                    });
-            }
-        }
         struct Joiner {
             std::vector<std::thread>& v;
             ~Joiner() {
@@ -776,6 +770,28 @@ int32_t bmx_fast_mnn(int32_t nbatches, int32_t d, const double* const* data, con
                     if (t.joinable()) t.join();
             }
         } joiner{toucher};
+        bool sizes_ok = corrected && nbatches >= 2 && nbatches <= 65536 && d >= 1 && nrows && data;
+        int64_t N = 0;
+        for (int b = 0; sizes_ok && b < nbatches; ++b) {
+            sizes_ok = nrows[b] >= 0 && data[b] != nullptr;
+            N += nrows[b];
+        }
+        if (sizes_ok && N <= (int64_t)2147483647) {
+            const size_t bytes = (size_t)N * (size_t)d * sizeof(double);
+            if (bytes >= ((size_t)8 << 20)) {
+                constexpr int nt = 12;
+                volatile char* base = reinterpret_cast<volatile char*>(corrected);
+                try {
+                    toucher.reserve(nt);
+                    for (int t = 0; t < nt; ++t)
+                        toucher.emplace_back([base, bytes, t] {
+                            const size_t lo = bytes / nt * t, hi = t + 1 == nt ? bytes : bytes / nt * (t + 1);
+                            for (size_t o = lo; o < hi; o += 4096) base[o] = 0;
+                        });
+                } catch (const std::system_error&) {  // (no more threads to be had: the download faults the pages itself)
+                }
+            }
+        }
         h->impl->upload(nbatches, d, data, nrows, restrict_idx, n_restrict, /* lazy */ true);
         const auto t1 = std::chrono::steady_clock::now();
         h->impl->run(p, tree, tree_len);

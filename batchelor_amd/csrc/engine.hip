@@ -808,8 +808,17 @@ void Engine::merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p,
             const int64_t per_cells = bmx_shard_rows_per_rank(right.n, world_);
             double* ws = asv_ws_.reserve(plan.main_doubles + plan.extra_doubles);
             double* scaling = asv_scale_.reserve((size_t)per_cells * world_);
+            sec.reset();  // (the variance adjustment is timed on its own: event tag 4, bmx_engine_profile_var_adj)
+            std::pair<hipEvent_t, hipEvent_t> aev{nullptr, nullptr};
+            if (knn_ws_.profile) {
+                aev = knn_ws_.next_events(4);
+                (void)hipEventRecord(aev.first, stream_);
+            }
             adjust_shift_variance_device(stream_, left.data.p, d_, left.n, right.data.p, right.n, corr, p.sigma, r1, nLs, r2,
                                          nRs, scaling, ws, plan, /* vect_row_major */ 1, (int)cb, (int)ce);
+            if (aev.second) (void)hipEventRecord(aev.second, stream_);
+            asv_pairs_ += (double)(ce - cb) * ((double)nLs + (double)nRs);
+            sec = std::make_unique<Section>(this);
             queued_work_s_ += 5e-8 * (double)(ce - cb) * ((double)nLs + (double)nRs);
             exchange(scaling, per_cells * (int64_t)sizeof(double));
             if (mdx == snap_merge_) {  // diagnostics: what adjust_shift_variance was handed at this merge, and what it returned
@@ -975,6 +984,7 @@ void Engine::run_once(const bmx_params_t& p, const int32_t* tree, int tree_len) 
     n_extras_ = 0;
     xchg_calls_ = xchg_bytes_ = 0;
     knn_ws_.events_used = 0;
+    asv_pairs_ = 0.0;
     vecs_.reserve((size_t)(2 * B_ + 8) * d_);
     // statistics slots (column means [d] + total variance) and batch.size scalars: a merge takes at most one per
     // segment before and after its centring, plus one
@@ -1499,6 +1509,7 @@ void Engine::profile_detail(double* out10) {
             case 1: out10[0] += t; out10[1] += 1; break;
             case 2: out10[2] += t; out10[3] += 1; break;
             case 0: out10[4] += t; out10[5] += 1; break;
+            case 4: break;  // (adjust_shift_variance: profile_var_adj)
             default: out10[6] += t; break;
         }
     }
@@ -1507,11 +1518,23 @@ void Engine::profile_detail(double* out10) {
     out10[9] = (double)optimistic_retries_;
 }
 
+void Engine::profile_var_adj(double* out3) {
+    out3[0] = out3[1] = 0.0;
+    for (size_t i = 0; i < knn_ws_.events_used; ++i) {
+        if (knn_ws_.event_tag[i] != 4) continue;
+        float t = 0.f;
+        BMX_HIP(hipEventElapsedTime(&t, knn_ws_.events[i].first, knn_ws_.events[i].second));
+        out3[0] += t;
+        out3[1] += 1;
+    }
+    out3[2] = asv_pairs_;
+}
+
 void Engine::profile(double* topk_ms, int64_t* launches, int64_t* fallbacks) {
     double ms = 0.0;
     int64_t n = 0;
     for (size_t i = 0; i < knn_ws_.events_used; ++i) {
-        if (knn_ws_.event_tag[i] == 3) continue;  // a streaming section, not a candidate-pass launch
+        if (knn_ws_.event_tag[i] >= 3) continue;  // a streaming section / a variance adjustment, not a candidate-pass launch
         float t = 0.f;
         BMX_HIP(hipEventElapsedTime(&t, knn_ws_.events[i].first, knn_ws_.events[i].second));
         ms += t;

@@ -92,6 +92,7 @@ class Engine {
     // orthogonalisation, R/fastMNN.R:473-477); -1 = off
     void set_snapshot(int merge) { snap_merge_ = merge; }
     void snapshot(double* left_rm, double* right_rm, int64_t* nl, int64_t* nr);
+    void profile_var_adj(double* out3);  // {ms, launches, (cell, restricted cell) pairs} of the run's adjust_shift_variance calls
     void snapshot_var_adj(double* left_rm, double* right_rm, double* corr_rm, double* scaling, int32_t* r1, int32_t* r2,
                           int64_t* sizes4);
     void profile(double* topk_ms, int64_t* launches, int64_t* fallbacks);
@@ -215,6 +216,7 @@ class Engine {
     DevBuf<double> snap_al_, snap_ar_, snap_ac_, snap_as_;  // the snapshot merge's variance adjustment: inputs and scalings
     DevBuf<int32_t> snap_ai1_, snap_ai2_;
     int64_t snap_anl_ = 0, snap_anr_ = 0, snap_ar1_ = 0, snap_ar2_ = 0;
+    double asv_pairs_ = 0.0;  // (cell, restricted cell) pairs of this rank's adjust_shift_variance calls in the last run
 
     int B_ = 0;
     int64_t N_ = 0;

@@ -69,7 +69,15 @@ class HostPool {
     }
 
   private:
-    static void relax() { __builtin_ia32_pause(); }
+    static void relax() {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#elif defined(__aarch64__)
+        __asm__ __volatile__("isb" ::: "memory");
+#else
+        std::this_thread::yield();
+#endif
+    }
     HostPool() {
         unsigned hw = std::thread::hardware_concurrency();
         int n = hw >= 96 ? 24 : (hw >= 32 ? 12 : (hw >= 8 ? 6 : (hw >= 4 ? 3 : 0)));
@@ -227,20 +235,26 @@ struct PinnedBlocks {
 
 // A staging buffer's DMA is waited for with a deadline too (the watchdog contract of bmx_common.hpp: the host never waits
 // without one): a copy queued behind a kernel that never ends gives up with an error instead of blocking the process.
-inline void guarded_event_sync(hipEvent_t ev, double budget_s = 120.0) {
+// stale_ok: the event may have been recorded, last, on the stream of an engine that is gone (the UPLOAD ring's busy slots
+// only: that ring outlives the engines that use it).  Such an event cannot be queried any more -- the runtime answers with an
+// error of its stream-capture / invalid-handle family --, the engine drained its streams before it went, so there is
+// nothing left to wait for and the slot is free.  Everywhere else (the download ring and the pair lists record their events
+// in the call that waits for them) an error is a device fault and is reported: the bytes behind it must not be taken.
+inline void guarded_event_sync(hipEvent_t ev, double budget_s = 120.0, bool stale_ok = false) {
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
         const hipError_t e = hipEventQuery(ev);
         if (e == hipSuccess) return;
-        (void)hipGetLastError();
         if (e != hipErrorNotReady) {
-            // A ring's event outlives the engines that record it: one last recorded on the stream of an engine that is gone
-            // cannot be queried any more (the runtime answers with an error of its stream-capture family).  That engine
-            // drained its streams before it went, so there is nothing left to wait for; a blocking wait settles the rest.
-            (void)hipEventSynchronize(ev);
             (void)hipGetLastError();
-            return;
+            const bool stale = e == hipErrorStreamCaptureUnsupported || e == hipErrorStreamCaptureInvalidated ||
+                               e == hipErrorStreamCaptureIsolation || e == hipErrorStreamCaptureImplicit ||
+                               e == hipErrorCapturedEvent || e == hipErrorInvalidHandle || e == hipErrorContextIsDestroyed ||
+                               e == hipErrorInvalidResourceHandle;
+            if (stale_ok && stale) return;
+            BMX_HIP(e);
         }
+        (void)hipGetLastError();
         const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (el > budget_s) throw WatchdogTimeout("watchdog: a staged host transfer did not finish in time");
         if (el > 2e-3) std::this_thread::sleep_for(std::chrono::microseconds(50));
@@ -261,7 +275,7 @@ inline void upload_pageable(void* dev, const void* host, size_t bytes, hipStream
         const int c = r.cur;
         if (r.busy[c]) {
             try {
-                guarded_event_sync(r.ev[c]);
+                guarded_event_sync(r.ev[c], 120.0, /* stale_ok */ true);
             } catch (...) {
                 r.busy[0] = r.busy[1] = false;  // (the stream these were recorded on is stuck: the next user starts afresh)
                 throw;

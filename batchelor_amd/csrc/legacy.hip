@@ -69,6 +69,7 @@ __device__ __forceinline__ double block_sum(double v, double* sm) {
 // per "cell" over the MNN cells, the cells being the MNN cells themselves).
 // ---------------------------------------------------------------------------------------------------
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
 
 __global__ void fill_nan(double* __restrict__ p, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -393,7 +394,10 @@ __host__ __device__ inline int asv_tile_gp(int g) { return (g + AT_KC - 1) / AT_
 __host__ __device__ inline int asv_tile_nb8(int g) { return g <= 128 ? (g + 7) / 8 : 0; }  // 8-dimension blocks of a row; 0: the staged form
 // row stride of the gathered stream: whole 8-dimension blocks (zero filled) for the register-streamed form
 inline int asv_tile_gs(int g) { return g <= 128 ? asv_tile_nb8(g) * 8 : g; }
-inline size_t asv_tile_npad(size_t N) { return std::max<size_t>((N + AT_NP - 1) / AT_NP * AT_NP, AT_NP); }
+__host__ __device__ inline size_t asv_tile_npad(size_t N) {
+    const size_t p = (N + AT_NP - 1) / AT_NP * AT_NP;
+    return p > (size_t)AT_NP ? p : (size_t)AT_NP;
+}
 // addends a chain of the literal re-run may keep (its sort buffer and two 16 KB bin arrays must fit the LDS beside the tile)
 // (a power of two: the lists are padded to one for the sorting networks)
 inline int asv_tile_lcap_default(int) { return 32768; }
@@ -579,14 +583,66 @@ __device__ __forceinline__ void asv_pair_literal(const double* cur, const double
     lw = -dist / sigma2;
 }
 
+// Bitonic sort of a[0, np2) (np2 a power of two) in GLOBAL memory by the whole block, through an LDS window of B elements
+// (B a power of two): every stage whose partners lie inside an aligned window runs there (a window is loaded, taken through
+// all such steps, stored), only the steps that reach across windows (j >= B) go to global memory one by one.  A list of
+// 32 768 pairs: 4 window rounds + 6 global steps instead of 120 global passes.  less(x, y): x sorts in front of y.
+template <class E, class Less>
+__device__ __forceinline__ void asv_sort_global(E* a, int np2, E* win, int B, int tid, Less less) {
+    auto pass_done = [&]() {  // what the other threads of the block wrote must be what the next step reads
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+    };
+    if (B > np2) B = np2;
+    // the steps j = jtop, jtop / 2, ..., 1 of stage k inside every window (jtop < B)
+    auto windows = [&](int k_lo, int k_hi, bool all_steps) {
+        for (int w0 = 0; w0 < np2; w0 += B) {
+            for (int i = tid; i < B; i += T) win[i] = a[w0 + i];
+            __syncthreads();
+            for (int k = k_lo; k <= k_hi; k <<= 1)
+                for (int j = all_steps ? (k >> 1) : (B >> 1); j > 0; j >>= 1) {
+                    for (int p = tid; p < B / 2; p += T) {
+                        const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1)), q = i | j;
+                        const E x = win[i], y = win[q];
+                        const bool up = ((w0 + i) & k) == 0;
+                        if (up ? less(y, x) : less(x, y)) {
+                            win[i] = y;
+                            win[q] = x;
+                        }
+                    }
+                    __syncthreads();
+                }
+            for (int i = tid; i < B; i += T) a[w0 + i] = win[i];
+            __syncthreads();
+        }
+        pass_done();
+    };
+    pass_done();
+    windows(2, B, true);  // every stage k <= B: all its steps stay inside a window
+    for (int k = 2 * B; k <= np2; k <<= 1) {
+        for (int j = k >> 1; j >= B; j >>= 1) {
+#pragma unroll 4
+            for (int p = tid; p < np2 / 2; p += T) {
+                const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1)), q = i | j;
+                const E x = a[i], y = a[q];
+                const bool sw = ((i & k) == 0) ? less(y, x) : less(x, y);
+                a[i] = sw ? y : x;
+                a[q] = sw ? x : y;
+            }
+            pass_done();
+        }
+        windows(k, k, false);  // the rest of stage k: steps j < B
+    }
+}
+
 // asv_row_scan in PIECES with a block-wide step in the middle of each: `pre` sees every element of a piece, then `hook(end)`
 // runs -- it may synchronise the block (every thread makes every call, the loop bounds are uniform) and returns true to end
 // the scan --, then `test` sees the piece's elements again (they are still in registers).  A piece is a row of T elements
 // over the first two batches (the bounds of a chain tighten fastest at its start) and a batch of AT_U rows from then on.
-template <class Pre, class Hook, class Test>
-__device__ __forceinline__ void asv_row_scan_pieces(const double* __restrict__ P, const double* __restrict__ W,
-                                                    int64_t jstart, int n, int crot, int last_block, int tid, Pre pre,
-                                                    Hook hook, Test test) {
+template <class Load, class Pre, class Hook, class Test>
+__device__ __forceinline__ void asv_row_scan_pieces(Load load, int64_t jstart, int n, int crot, int last_block, int tid,
+                                                    Pre pre, Hook hook, Test test) {
     const int64_t jt = jstart + tid;
     const int jlow = (int)(jt & 63), jb_t = (int)(jt >> 6);
     double pa[AT_U], wa[AT_U], pb[AT_U], wb[AT_U];
@@ -596,8 +652,7 @@ __device__ __forceinline__ void asv_row_scan_pieces(const double* __restrict__ P
             int jb = jb_t + ((base + u * T) >> 6);
             jb = jb < last_block ? jb : last_block;
             const int64_t off = (int64_t)jb * (AT_C * 64) + (((crot + jb) & (AT_C - 1)) << 6) + jlow;
-            p[u] = P[off];
-            w[u] = W[off];
+            load(off, p[u], w[u]);
         }
     };
     bool stop = false;
@@ -656,6 +711,21 @@ __global__ __launch_bounds__(256) void asv_gather_stream(const double* __restric
     }
 }
 
+// snrm[n] = max of snrm[0, n): non-negative doubles order like their bit patterns (one workgroup's maximum per atomic)
+__global__ __launch_bounds__(256) void asv_max_norm(double* __restrict__ snrm, int64_t n) {
+    __shared__ double sm[256];
+    double m = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmax(m, snrm[i]);
+    sm[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        atomicMax(reinterpret_cast<unsigned long long*>(snrm + n), (unsigned long long)__double_as_longlong(sm[0]));
+}
+
 // NB8 > 0 (= ceil(g / 8), g <= 128): the streamed cells go from global memory straight into the B-operand registers.  A row
 // is taken in blocks of 8 dimensions, each two MFMA steps: step (q, t) multiplies dimensions 8 q + 2 (lane >> 4) + t, so the
 // two values a lane needs of a block are 16 contiguous bytes of its row and a row costs ceil(g / 8) * 8 dimensions of
@@ -698,23 +768,20 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
     __shared__ int sh_sel[4];        // literal re-run: kept addends (own batch, reference in restrict order, in projection order), abort flag
     __shared__ int sh_K[AT_C][3];    // per cell of the tile: the lengths of its three lists (-1: the cell went the histogram way)
     __shared__ double sh_chain[AT_C][3];  // per cell: totalprob2, prob2, totalprob1 as the chains leave them
-    __shared__ double sh_nmx[4];          // per wave: the largest squared norm of a streamed cell
-    __shared__ int sh_spos[AT_C];         // per cell: its own first place in restrict2's order (0x7fffffff: it is not in it)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t N = (int64_t)nr1 + nr2;  // streamed cells: the own batch's restricted cells first, then the reference's
     // the tile's scratch: per block of 64 streamed cells, 16 rows (cells) of 64 values -- a step of the stream writes ONE
     // contiguous 8 KB piece of each array (the [cell][N] layout of the first version wrote 32 rows 8 MB apart per step and
     // spent its time in address translation), and a cell's row is 512-byte pieces 8 KB apart, read by whole waves
     const int64_t Npad = N <= AT_NP ? AT_NP : (N + AT_NP - 1) / AT_NP * AT_NP;
-    const int64_t per_block = 2 * AT_C * Npad + asv_tile_list_doubles(lcap);
+    const int64_t Nown = lcap > 0 ? (int64_t)asv_tile_npad((size_t)nr2) : 0;  // (the own batch's part of the stream, padded likewise)
+    const int64_t per_block = 2 * AT_C * Npad + asv_tile_list_doubles(lcap) + AT_C * Nown / 2;
     double* SP = scratch + (int64_t)blockIdx.x * per_block;  // projections
     double* SW = SP + (int64_t)AT_C * Npad;                   // log-weights
-    // the literal re-run's lists, per cell of the tile: own batch (log-weight, counted-in-prob2 flag) in restrict order,
-    // reference log-weights in restrict order, reference (projection, log-weight) sorted; and three index lists, reused per cell
-    double* LO = SW + (int64_t)AT_C * Npad;        // [16][lcap][2]
-    double* LR = LO + (int64_t)AT_C * lcap * 2;    // [16][lcap]
-    double* LS = LR + (int64_t)AT_C * lcap;        // [16][lcap][2]
-    int32_t* GI = reinterpret_cast<int32_t*>(LS + (int64_t)AT_C * lcap * 2);  // [3][lcap]
+    // the own batch's pairs, for the literal re-run only (it picks the kept addends of a flagged cell's own-batch chains from
+    // them): ONE float per pair, the log-weight with its two lowest mantissa bits replaced by a code -- 0: above the cell's
+    // projection (not counted in prob2, :90-92), 1: within rounding of it, 2: at or below it, 3: the cell itself
+    float* SO = reinterpret_cast<float*>(SW + (int64_t)AT_C * Npad + asv_tile_list_doubles(lcap));
     // -- and a cell's slot inside a block's piece rotates with the block number: with a fixed slot the per-cell passes
     // walked the scratch at a stride of exactly 8 KB, i.e. through a handful of the memory channels
     const int rot0 = blockIdx.x;
@@ -735,7 +802,6 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
         }
         __syncthreads();
         if (tid < AT_C) {
-            sh_spos[tid] = 0x7fffffff;
             double l2 = 0.0, nn = 0.0;
             for (int x = 0; x < g; ++x) l2 += cg[tid * GP + x] * cg[tid * GP + x];
             l2 = sqrt(l2);
@@ -756,8 +822,11 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
         // ONLINE in the stream's epilogue -- running maximum om, sums relative to it -- so that the own batch's 40 % of the
         // (cell, streamed cell) pairs are not read back (round 3: 16 + 16 bytes per pair); they are written all the same when
         // the literal re-run is on (lit_on): a flagged cell picks the kept addends of its own-batch chains from them
+#ifdef BMX_ASV_AB_NOLIT
+        const bool lit_on = false;
+#else
         const bool lit_on = lcap > 0;
-        double nmx = 0.0;  // largest squared norm of a streamed cell (bounds the rounding of the GEMM-form distances)
+#endif
         double om[4], oa[4], ob[4];
         double mx1[4], mx2[4], lo[4], hi[4], cp[4], cn[4];
 #pragma unroll
@@ -769,6 +838,12 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
             hi[i] = NEG;
             cp[i] = sc_proj[(lane >> 4) + 4 * i];
             cn[i] = sc_n[(lane >> 4) + 4 * i];
+        }
+        double tol_tile = 0.0;  // >= the rounding of g . x for any cell of the tile and any streamed cell (|g| = 1)
+        if (lit_on) {
+            double cmx = 0.0;
+            for (int c = 0; c < AT_C; ++c) cmx = fmax(cmx, sc_n[c]);
+            tol_tile = 1e-13 * (1.0 + cmx + snrm[Npad]);
         }
         if constexpr (NB8 > 0) {
             typedef double d2a __attribute__((ext_vector_type(2)));
@@ -800,6 +875,8 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
             const double* srow = S + (int64_t)jl * GS + 2 * kq;
             double* spo = SP + jl;
             double* swo = SW + jl;
+            // own-batch codes: [block of 64 streamed cells][kq][64][4 cells kq + 4 i] floats
+            f4* so_ = reinterpret_cast<f4*>(SO) + kq * 64 + jl;
             auto load_rows = [&](double (&b)[NST], const double* src) __attribute__((always_inline)) {
 #pragma unroll
                 for (int q = 0; q < NB8; ++q) {
@@ -814,7 +891,6 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                 load_rows(bn, srow + (j0 + AT_R < Npad ? (j0 + AT_R) : j0) * GS);
                 const double no = snrm[jo];
                 const int rid = sid[jo];
-                nmx = fmax(nmx, no);
                 // two accumulator pairs (k-steps alternate): D and P chains are independent of each other as well
                 d4 Dq[2], Pq[2];
 #pragma unroll
@@ -837,6 +913,8 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                 }
                 const bool own = jo < nr2, ref = !own && jo < N;
                 const int blk = (int)(j0 >> 6);
+                f4 oc = f4{0.f, 0.f, 0.f, 0.f};
+                (void)tol_tile;
                 double* sp_ = spo + (int64_t)blk * (AT_C * 64);
                 double* sw_ = swo + (int64_t)blk * (AT_C * 64);
 #pragma unroll
@@ -855,7 +933,6 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                     lo[i] = fmin(lo[i], ref ? pr : POS);
                     hi[i] = fmax(hi[i], ref ? pr : NEG);
                     if (own) {  // (whole waves but for the one step where the own batch ends)
-                        if (self) atomicMin(&sh_spos[kq + 4 * i], (int)jo);
                         if (lw > om[i]) {  // a new maximum: rare once the cell itself (log-weight 0) has gone by
                             const double f = exp(om[i] - lw);  // exp(-inf) = 0 the first time
                             oa[i] *= f;
@@ -866,12 +943,18 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                         oa[i] += e;
                         ob[i] += !(pr > cp[i]) ? e : 0.0;
                     }
-                    if (!own || lit_on) {
+                    if (!own) {
                         const int slot = (kq + 4 * i + blk + rot0) & (AT_C - 1);  // == at(kq + 4 i, jo)
                         sp_[slot * 64] = pr;
                         sw_[slot * 64] = lw;
+                    } else if (lit_on) {
+                        // (s_ = the cell's projection minus this one's; tol_tile >= the rounding of the two, for every cell of the tile)
+                        const unsigned code = self ? 3u : (s_ >= tol_tile ? 2u : (s_ >= -tol_tile ? 1u : 0u));
+                        oc[i] = __uint_as_float((__float_as_uint((float)fmax(lw, -3.0e38)) & ~3u) | code);
                     }
                 }
+                // (this lane's four cells kq, kq + 4, kq + 8, kq + 12 of one streamed cell: one 16-byte store, 16 lanes a 256-byte run)
+                if (own && lit_on) so_[(int64_t)blk * (AT_C * 16)] = oc;
             };
             double ba[NST], bb[NST];
             load_rows(ba, srow);
@@ -913,7 +996,6 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
             const int64_t jo = j0 + 16 * w + (lane & 15);
             const double no = jo < N ? snrm[jo] : 0.0;
             const int rid = jo < N ? sid[jo] : -1;
-            nmx = fmax(nmx, no);
             for (int kc = 0; kc < nkc; ++kc) {
                 const int k0 = kc * AT_KC;
 #pragma unroll
@@ -951,7 +1033,6 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                     if (own && rid == c0 + c) {  // the cell itself: log-weight 0, always counted (:80-84)
                         lw = 0.0;
                         pr = NEG;
-                        atomicMin(&sh_spos[c], (int)jo);
                     }
                     mx1[i] = fmax(mx1[i], own ? NEG : lw);
                     lo[i] = fmin(lo[i], own ? POS : pr);
@@ -967,9 +1048,13 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                         oa[i] += e;
                         ob[i] += !(pr > cp[i]) ? e : 0.0;
                     }
-                    if (!own || lit_on) {
+                    if (!own) {
                         SP[at(c, jo)] = pr;
                         SW[at(c, jo)] = lw;
+                    } else if (lit_on) {
+                        const unsigned code = rid == c0 + c ? 3u : (s_ >= tol_tile ? 2u : (s_ >= -tol_tile ? 1u : 0u));
+                        SO[(((jo >> 6) * 4 + (c & 3)) * 64 + (jo & 63)) * 4 + (c >> 2)] =
+                            __uint_as_float((__float_as_uint((float)fmax(lw, -3.0e38)) & ~3u) | code);
                     }
                 }
             }
@@ -991,9 +1076,7 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                 om[i] = mm;
             }
         }
-        for (int o = 1; o < 64; o <<= 1) nmx = fmax(nmx, __shfl_xor(nmx, o));
         __syncthreads();
-        if (lane == 0) sh_nmx[w] = nmx;
         if ((lane & 15) == 0) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -1034,7 +1117,7 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
         // (the scratch rows were written by this block and are read by it: same CU, through the L2)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
         // ---- cell by cell: own-batch probability, then the weighted quantile of the reference projections
-        const double nmax_s = fmax(fmax(sh_nmx[0], sh_nmx[1]), fmax(sh_nmx[2], sh_nmx[3]));
+        const double nmax_s = snrm[Npad];  // the largest squared norm of a streamed cell (asv_max_norm; bounds the rounding of the GEMM-form distances)
         const int last_block = (int)(Npad >> 6) - 1;
         const int gs_rt = NB8 > 0 ? NB8 * 8 : g;  // row stride of the gathered stream
         if (tid < AT_C) sh_K[tid][0] = -1;
@@ -1108,6 +1191,12 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                         const double cn_c = sc_n[c];
                         const double mb = 1e-3 + 1e-13 * (cn_c + nmax_s) / sigma2;      // >= the rounding of a GEMM-form log-weight
                         const double tolp = 1e-13 * (sqrt(cn_c) + sqrt(nmax_s)) + 1e-300;  // >= the rounding of a projection
+                        // the lists, per cell of the tile: own batch (log-weight, counted-in-prob2 flag) in restrict order, reference
+                        // log-weights in restrict order, reference (projection, log-weight) sorted; three index lists, reused per cell
+                        double* LO = SW + (int64_t)AT_C * Npad;        // [16][lcap][2]
+                        double* LR = LO + (int64_t)AT_C * lcap * 2;    // [16][lcap]
+                        double* LS = LR + (int64_t)AT_C * lcap;        // [16][lcap][2]
+                        int32_t* GI = reinterpret_cast<int32_t*>(LS + (int64_t)AT_C * lcap * 2);  // [3][lcap]
                         int32_t* giO = GI;
                         int32_t* giR = GI + lcap;
                         int32_t* giS = GI + 2 * lcap;
@@ -1155,7 +1244,11 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                             int par = 0;
                             const double hi_keep = bhi - 2.0 * tolp;  // (the last projection of the sort is the walk's default, :141)
                             asv_row_scan_pieces(
-                                SP, SW, nr2, nr1, c + rot0, last_block, tid,
+                                [&](int64_t off, double& p_, double& w_) {
+                                    p_ = SP[off];
+                                    w_ = SW[off];
+                                },
+                                nr2, nr1, c + rot0, last_block, tid,
                                 [&](double, double lw, int o) { mT = fmax(mT, o < nr1 ? lw : NEG); },
                                 [&](int) -> bool {
                                     thrR = asv_thr_neg(Mr, mx, (double)nr1, mb);  // (from the pieces in front of this one)
@@ -1187,72 +1280,82 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                         }
                         bool ok = sh_sel[1] <= lcap && sh_sel[2] <= lcap;
                         // (d) the own batch: kept addends of totalprob2's and prob2's chains (one list: an addend that is a
-                        // no-op for one of them is one in the re-run as well).  The cell's own first place in restrict2 (spos, from
-                        // the stream) splits the chains into their two regimes; elements in front of it are held against the largest
-                        // log-weight of the pieces in front of theirs and the chain is bounded with their own piece's included, those
-                        // behind it against the largest other log-weight of the pieces in front.
+                        // no-op for one of them is one in the re-run as well).  The cell's own first place in restrict2 (spos: the
+                        // first code-3 element, found by the scan as it goes) splits the chains into their two regimes: elements in
+                        // front of it are held against the largest log-weight of the pieces in front of theirs, the chain bounded with
+                        // their own piece's included; those behind it against the largest OTHER log-weight of the pieces in front (the
+                        // cell's later occurrences, log-weight 0, are left out of that bound: lower bounds may always leave out).  The
+                        // pairs come as float codes (see SO): log-weights to 1e-6 relative (they are <= 0: x (1 + 1e-6) bounds one
+                        // from below, x (1 - 1e-6) from above), the side of the cell's projection as decided by the stream.
                         if (ok) {
-                            const int spos = sh_spos[c];
-                            double Tb = NEG, Tx = NEG, Pb = NEG, Px = NEG;          // totalprob2 / prob2: before the cell, others anywhere
-                            double mTb = NEG, mTx = NEG, mPb = NEG, mPx = NEG;      // the same of the current piece
+                            const double DN = 1.0 + 1e-6, UP = 1.0 - 1e-6;
+                            const int last_own = (int)(Nown >> 6) - 1;
+                            int spos = 0x7fffffff, mspos = 0x7fffffff;
+                            double Tx = NEG, Px = NEG;      // totalprob2 / prob2: the largest other log-weight of the pieces gone by
+                            double mTx = NEG, mPx = NEG;    // the same of the current piece
                             double thrTb = NEG, thrPb = NEG, thrTa = NEG, thrPa = NEG;
                             int par = 0;
                             asv_row_scan_pieces(
-                                SP, SW, 0, nr2, c + rot0, last_block, tid,
-                                [&](double pr, double lw, int o) {
+                                [&](int64_t off, double& p_, double& w_) {
+                                    // (the scanner's offset is (block * 16 + slot) * 64 + j: the block and j are what is needed)
+                                    const int64_t blk_ = off >> 10;
+                                    const unsigned u = __float_as_uint(SO[((blk_ * 4 + (c & 3)) * 64 + (off & 63)) * 4 + (c >> 2)]);
+                                    p_ = (double)(u & 3u);
+                                    w_ = (double)__uint_as_float(u & ~3u);
+                                },
+                                0, nr2, c + rot0, last_own, tid,
+                                [&](double code, double lw, int o) {
                                     const bool in = o < nr2;
-                                    const bool other = in && o != spos;              // (later occurrences of the cell: log-weight 0, addends like any other)
-                                    const bool sure = other && pr <= curproj - tolp;  // counted in prob2 whatever the rounding (:90-92)
+                                    const bool other = in && code != 3.0;
+                                    const bool sure = other && code >= 2.0;    // counted in prob2 whatever the rounding (:90-92)
                                     mTx = fmax(mTx, other ? lw : NEG);
                                     mPx = fmax(mPx, sure ? lw : NEG);
-                                    mTb = fmax(mTb, other && o < spos ? lw : NEG);
-                                    mPb = fmax(mPb, sure && o < spos ? lw : NEG);
+                                    mspos = in && code == 3.0 && o < mspos ? o : mspos;
                                 },
                                 [&](int end) -> bool {
-                                    double r0 = mTb, r1 = mTx, r2 = mPb, r3 = mPx;
+                                    double r1 = mTx, r3 = mPx;
+                                    int rs_ = mspos;
                                     for (int o2 = 1; o2 < 64; o2 <<= 1) {
-                                        r0 = fmax(r0, __shfl_xor(r0, o2));
                                         r1 = fmax(r1, __shfl_xor(r1, o2));
-                                        r2 = fmax(r2, __shfl_xor(r2, o2));
                                         r3 = fmax(r3, __shfl_xor(r3, o2));
+                                        const int t2 = __shfl_xor(rs_, o2);
+                                        rs_ = t2 < rs_ ? t2 : rs_;
                                     }
                                     double* smx = sm + par * 32;
                                     if (lane == 0) {
-                                        smx[w * 4 + 0] = r0;
-                                        smx[w * 4 + 1] = r1;
-                                        smx[w * 4 + 2] = r2;
-                                        smx[w * 4 + 3] = r3;
+                                        smx[w * 4 + 0] = r1;
+                                        smx[w * 4 + 1] = r3;
+                                        smx[w * 4 + 2] = (double)rs_;
                                     }
                                     if (tid == 0) smx[16] = sh_sel[0] > lcap ? 1.0 : 0.0;
                                     __syncthreads();
-                                    double pTb = NEG, pTx = NEG, pPb = NEG, pPx = NEG;
+                                    double pTx = NEG, pPx = NEG, ps = 2147483647.0;
                                     for (int ww = 0; ww < 4; ++ww) {
-                                        pTb = fmax(pTb, smx[ww * 4 + 0]);
-                                        pTx = fmax(pTx, smx[ww * 4 + 1]);
-                                        pPb = fmax(pPb, smx[ww * 4 + 2]);
-                                        pPx = fmax(pPx, smx[ww * 4 + 3]);
+                                        pTx = fmax(pTx, smx[ww * 4 + 0]);
+                                        pPx = fmax(pPx, smx[ww * 4 + 1]);
+                                        ps = fmin(ps, smx[ww * 4 + 2]);
                                     }
+                                    if (spos == 0x7fffffff) spos = (int)ps;
                                     const double cnt = (double)(end < nr2 ? end : nr2);
-                                    // in front of the cell: lower bound from the pieces in front, upper bound with this piece's
-                                    thrTb = asv_thr_neg(Tb, fmax(Tb, pTb), cnt, mb);
-                                    thrPb = Pb == NEG ? NEG : asv_thr_neg(Pb, fmax(Tb, pTb), cnt, mb);  // (prob2's chain never exceeds totalprob2's)
+                                    // in front of the cell: lower bound from the pieces in front, upper bound with this piece's (all of
+                                    // its others: an upper bound may always take in more)
+                                    const double hiT = fmax(Tx, pTx) * UP;
+                                    thrTb = asv_thr_neg(Tx * DN, hiT, cnt, mb);
+                                    thrPb = asv_thr_neg(Px * DN, hiT, cnt, mb);  // (prob2's chain never exceeds totalprob2's)
                                     // behind it: the chains stand at log(1 + others)
-                                    thrTa = asv_thr_self(Tx, mb);
-                                    thrPa = asv_thr_self(Px, mb);
-                                    Tb = fmax(Tb, pTb);
+                                    thrTa = asv_thr_self(Tx * DN, mb);
+                                    thrPa = asv_thr_self(Px * DN, mb);
                                     Tx = fmax(Tx, pTx);
-                                    Pb = fmax(Pb, pPb);
                                     Px = fmax(Px, pPx);
-                                    mTb = mTx = mPb = mPx = NEG;
+                                    mTx = mPx = NEG;
                                     par ^= 1;
                                     return smx[16] != 0.0;
                                 },
-                                [&](double pr, double lw, int o) {
-                                    const bool in = o < nr2;
-                                    const bool maybe = pr <= curproj + tolp;
+                                [&](double code, double lw, int o) {
                                     const bool behind = o > spos;
                                     const double tT = behind ? thrTa : thrTb, tP = behind ? thrPa : thrPb;
-                                    if (in && (o == spos || lw >= tT || (maybe && lw >= tP))) {
+                                    const double up = lw * UP;  // (the log-weight is at most this)
+                                    if (o < nr2 && (code == 3.0 || up >= tT || (code >= 1.0 && up >= tP))) {
                                         const int pos = atomicAdd(&sh_sel[0], 1);
                                         if (pos < lcap) giO[pos] = o;
                                     }
@@ -1268,39 +1371,32 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                             const double* cur = cx + c * GP;
                             const double* grd = cg + c * GP;
                             const int lsort = lcap < asv_tile_lsort(g) ? lcap : asv_tile_lsort(g);
-                            // a pass of a sorting network over a list in global memory: what the other threads of the block
-                            // wrote in the pass before must be what this pass reads
-                            auto pass_done = [&]() {
-                                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
-                                __syncthreads();
-                                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
-                            };
                             // an index list ascending: in the LDS (-> ib) up to 4 lsort entries, else where it lies
                             auto sorted_ints = [&](int32_t* gi, int cnt) -> const int32_t* {
                                 int np2 = 1;
                                 while (np2 < cnt) np2 <<= 1;
-                                const bool in_lds = np2 <= 4 * lsort;
-                                int32_t* a = in_lds ? ib : gi;
-                                for (int i = tid; i < np2; i += T) {
-                                    if (in_lds) a[i] = i < cnt ? gi[i] : 0x7fffffff;
-                                    else if (i >= cnt) a[i] = 0x7fffffff;
+                                if (np2 > 4 * lsort) {
+                                    for (int i = cnt + tid; i < np2; i += T) gi[i] = 0x7fffffff;
+                                    asv_sort_global(gi, np2, ib, 4 * lsort, tid, [](int x, int y) { return x < y; });
+                                    return gi;
                                 }
-                                if (in_lds) __syncthreads(); else pass_done();
+                                for (int i = tid; i < np2; i += T) ib[i] = i < cnt ? gi[i] : 0x7fffffff;
+                                __syncthreads();
                                 for (int k = 2; k <= np2; k <<= 1)
                                     for (int j = k >> 1; j > 0; j >>= 1) {
                                         for (int i = tid; i < np2; i += T) {
                                             const int ixj = i ^ j;
                                             if (ixj > i) {
-                                                const int x0 = a[i], x1 = a[ixj];
+                                                const int x0 = ib[i], x1 = ib[ixj];
                                                 if (((i & k) == 0) ? x0 > x1 : x0 < x1) {
-                                                    a[i] = x1;
-                                                    a[ixj] = x0;
+                                                    ib[i] = x1;
+                                                    ib[ixj] = x0;
                                                 }
                                             }
                                         }
-                                        if (in_lds) __syncthreads(); else pass_done();
+                                        __syncthreads();
                                     }
-                                return a;
+                                return ib;
                             };
                             {
                                 const int32_t* ix = sorted_ints(giR, KR);  // totalprob1's chain runs in restrict order (:117-131)
@@ -1360,7 +1456,7 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                                     LS[((int64_t)c * lcap + i) * 2] = kp[i];
                                     LS[((int64_t)c * lcap + i) * 2 + 1] = kw[i];
                                 }
-                            } else {  // a long list: sorted where it lies
+                            } else {  // a long list: sorted where it lies, through an LDS window
                                 typedef double d2a __attribute__((ext_vector_type(2)));
                                 d2a* L2 = reinterpret_cast<d2a*>(LS + (int64_t)c * lcap * 2);
                                 for (int i = tid; i < np2; i += T) {
@@ -1368,22 +1464,8 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                                     if (i < KS) asv_pair_literal(cur, grd, S + ((int64_t)nr2 + giS[i]) * gs_rt, g, sigma2, pr, lw);
                                     L2[i] = d2a{pr, lw};
                                 }
-                                pass_done();
-                                for (int k = 2; k <= np2; k <<= 1)
-                                    for (int j = k >> 1; j > 0; j >>= 1) {
-                                        for (int i = tid; i < np2; i += T) {
-                                            const int ixj = i ^ j;
-                                            if (ixj > i) {
-                                                const d2a e0 = L2[i], e1 = L2[ixj];
-                                                const bool up = (i & k) == 0;
-                                                if (up ? pair_less(e1[0], e1[1], e0[0], e0[1]) : pair_less(e0[0], e0[1], e1[0], e1[1])) {
-                                                    L2[i] = e1;
-                                                    L2[ixj] = e0;
-                                                }
-                                            }
-                                        }
-                                        pass_done();
-                                    }
+                                asv_sort_global(L2, np2, reinterpret_cast<d2a*>(ub), lsort, tid,
+                                                [](const d2a& x, const d2a& y) { return pair_less(x[0], x[1], y[0], y[1]); });
                             }
                             if (tid == 0) {
                                 sh_K[c][0] = KO;
@@ -1512,6 +1594,9 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
         // one lane per cell for the walk (:137-157)
         if (lit_on) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");  // (the lists were written by other threads of the block)
+            const double* LO = SW + (int64_t)AT_C * Npad;
+            const double* LR = LO + (int64_t)AT_C * lcap * 2;
+            const double* LS = LR + (int64_t)AT_C * lcap;
             if (tid < 3 * AT_C) {
                 const int c = tid & (AT_C - 1), which = tid >> 4;
                 const int KO = sh_K[c][0];
@@ -1637,13 +1722,14 @@ AsvPlan adjust_shift_variance_plan(int g, int n2, int nr1, int nr2, int vect_row
         for (int b = 1; b > 0 && b <= dev_knobs().asv_cap; b <<= 1) c2 = b;
         pl.lcap = std::min(pl.lcap, c2);
     }
-    const size_t per_block = (size_t)2 * AT_C * N + (size_t)asv_tile_list_doubles(pl.lcap);
+    const size_t per_block = (size_t)2 * AT_C * N + (size_t)asv_tile_list_doubles(pl.lcap) +
+                             (pl.lcap > 0 ? (size_t)AT_C * asv_tile_npad((size_t)nr2) / 2 : 0);  // (+ the own batch's float codes)
     const size_t budget = (size_t)12 << 30;  // doubles: 96 GiB of the 288 at most
     const size_t tiles = ((size_t)std::max(n2, 1) + AT_C - 1) / AT_C;
     pl.blocks = (int)std::max<size_t>(1, std::min<size_t>({tiles, (size_t)256, budget / per_block}));
     pl.main_doubles = per_block * (size_t)pl.blocks;
     // the nr1 + nr2 streamed cells: their rows, norms, ids; a row-major copy of vect if it came column-major
-    pl.extra_doubles = N * asv_tile_gs(g) + N + (N + 1) / 2 + 2 + (vect_row_major ? 0 : (size_t)n2 * g) + 16;
+    pl.extra_doubles = N * asv_tile_gs(g) + N + 1 + (N + 1) / 2 + 2 + (vect_row_major ? 0 : (size_t)n2 * g) + 16;
     return pl;
 }
 
@@ -1667,16 +1753,18 @@ void adjust_shift_variance_device(hipStream_t stream, const double* data1, int g
         const int64_t N = (int64_t)asv_tile_npad((size_t)nr1 + (size_t)nr2);
         const int gs = asv_tile_gs(g);
         double* S = extra;                      // [N][gs] the streamed cells, zero rows up to whole pairs of steps
-        double* snrm = S + N * gs;              // [N]
-        int32_t* sid = reinterpret_cast<int32_t*>(snrm + N);  // [N]
+        double* snrm = S + N * gs;              // [N] + their maximum
+        int32_t* sid = reinterpret_cast<int32_t*>(snrm + N + 1);  // [N]
         const double* vrm = vect;
         if (!vect_row_major) {
-            double* t = snrm + N + (N + 1) / 2 + 2;
+            double* t = snrm + N + 1 + (N + 1) / 2 + 2;
             transpose_cm_to_rm(stream, vect, n2, g, t);
             vrm = t;
         }
+        BMX_HIP(hipMemsetAsync(snrm + N, 0, sizeof(double), stream));
         hipLaunchKernelGGL(asv_gather_stream, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, stream, data1, data2, g, gs, restrict1,
                            nr1, restrict2, nr2, N, S, snrm, sid);
+        hipLaunchKernelGGL(asv_max_norm, dim3(256), dim3(256), 0, stream, snrm, N);
         const size_t lds = asv_tile_lds_bytes(g, pl.lcap);
         unsigned long long* tally = asv_tally_device();
 #define BMX_ASV_TILE(NB8)                                                                                                    \
@@ -1687,6 +1775,9 @@ void adjust_shift_variance_device(hipStream_t stream, const double* data1, int g
                            pl.lcap, tally);                                                                                \
         break
         switch (asv_tile_nb8(g)) {
+#ifdef BMX_ASV_AB_ONLY13
+            BMX_ASV_TILE(13);
+#else
             BMX_ASV_TILE(1);
             BMX_ASV_TILE(2);
             BMX_ASV_TILE(3);
@@ -1703,6 +1794,7 @@ void adjust_shift_variance_device(hipStream_t stream, const double* data1, int g
             BMX_ASV_TILE(14);
             BMX_ASV_TILE(15);
             BMX_ASV_TILE(16);
+#endif
             default:
                 BMX_ASV_TILE(0);
         }

@@ -186,6 +186,11 @@ class MnnEngine:
                 "exact_fallbacks": int(a[7]), "tier2_queries": int(a[8]), "optimistic_retries": int(a[9]),
                 "kernel": buf.value.decode()}
 
+    def profile_var_adj(self):
+        a = np.zeros(3, dtype=np.float64)
+        _lib.check(_lib.lib().bmx_engine_profile_var_adj(self._h, _lib.f64p(a)))
+        return {"asv_ms": a[0], "asv_launches": int(a[1]), "asv_pairs": a[2]}
+
     def merge_stats(self):
         out = []
         for m in range(self.nbatches - 1):

@@ -343,8 +343,10 @@ def main():
     ap.add_argument("--pca-tol", type=float, default=1e-9, help="config4: relative Ritz residual the PCA iterates to")
     ap.add_argument("--gen-threads", type=int, default=16, help="config4: host threads generating the input blocks")
     ap.add_argument("--var-adj", action="store_true", help="config5: mnnCorrect-style variance adjustment in the merges")
+    ap.add_argument("--sigma", type=float, default=1.0, help="--var-adj: the bandwidth handed to adjust_shift_variance "
+                    "(1.0 relative to the synthetic spectrum; 0.1 is mnnCorrect's default, R/mnnCorrect.R:125-130)")
     ap.add_argument("--dev", action="append", default=[], metavar="KNOB=VALUE",
-                    help="developer A/B runs: a testing hook of the library (bmx_dev_set), e.g. --dev f16_cons=8")
+                    help="developer A/B runs: a testing hook of the library (bmx_dev_set), e.g. --dev asv_cap=0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-to-host", action="store_true")
     args = ap.parse_args()
@@ -405,16 +407,26 @@ def main():
     if tree is not None:
         from batchelor_amd.merge_tree import resolve_merge_order
         tree = resolve_merge_order(len(sizes), tree)
-    run_kw = {"var_adj": True, "sigma": 1.0} if args.var_adj else {}
+    run_kw = {"var_adj": True, "sigma": args.sigma} if args.var_adj else {}
     for _ in range(args.warmup):
         eng.run(k=k, merge_tree=tree, **run_kw)
     eng.set_profiling(True)
+    if args.var_adj:
+        from batchelor_amd import _lib as _bl
+        if not hasattr(_bl.lib(), "bmx_engine_profile_var_adj"):  # (BMX_LIB = a build of an earlier round, A/B runs)
+            args.var_adj_old_lib = True
+        else:
+            _bl.dev_get("asv_tally_reset")
     barrier()
     t0 = time.perf_counter()
     acc = None
+    asv = {"asv_ms": 0.0, "asv_launches": 0, "asv_pairs": 0.0}
     for _ in range(args.steps):
         eng.run(k=k, merge_tree=tree, **run_kw)  # returns after the engine's stream has drained
         p = eng.profile_detail()
+        if args.var_adj and not getattr(args, "var_adj_old_lib", False):
+            for key, v in eng.profile_var_adj().items():
+                asv[key] += v
         if acc is None:
             acc = dict(p)
         else:
@@ -519,6 +531,31 @@ def main():
                          "streaming_ms_per_step": 1e3 * stream_s,
                          "exchange_calls_per_step": xst["calls"], "exchange_bytes_per_step": xst["bytes"]},
         }
+        if args.var_adj and asv["asv_ms"] > 0:
+            # configs[4] "with adjust_shift_variance on": the step is that kernel.  Algorithmic work per (cell, restricted cell)
+            # pair: the two inner products x_c . x_o and g_c . x_o (src/adjust_shift_variance.cpp:9-27, :88-89 in GEMM form) =
+            # 4 d flops.  Peak: the FP64 matrix rate of the MI355X data sheet, 78.6 TFLOP/s -- the in-container guide
+            # (MI355X_MICROARCH.md) lists no FP64 MFMA figure, so this one is NOT from it.
+            from batchelor_amd import _lib as _bl
+            a_tf = 4.0 * d * asv["asv_pairs"] / (asv["asv_ms"] * 1e-3) / 1e12
+            line["metric"] = "cells/sec corrected (reducedMNN engine + adjust_shift_variance, 100 PCs)"
+            line["dtype"] = "f64 (FP64 MFMA) for adjust_shift_variance; " + kern["dtype"] + " for the searches"
+            line["config"]["var_adj_sigma"] = args.sigma
+            line["roofline_searches"] = line["roofline"]
+            line["roofline"] = {
+                "bound": "mfma", "kernel": "asv_tile_kernel<13> (adjust_shift_variance, tiled FP64-MFMA form)",
+                "achieved": a_tf, "peak": 78.6, "unit": "TFLOP/s", "frac": a_tf / 78.6,
+                "peak_note": "FP64 matrix peak from AMD's MI355X data sheet; not in the in-container guide",
+                "traffic": None, "traffic_note": "profiles/r05_asv_tile_pmc.json (own rocprofv3 --pmc passes)",
+                "launches_per_step": asv["asv_launches"] / max(1, args.steps),
+                "avg_launch_ms": asv["asv_ms"] / max(1, asv["asv_launches"]),
+                "pairs_per_step": asv["asv_pairs"] / max(1, args.steps),
+                "algorithmic_flops_per_step": 4.0 * d * asv["asv_pairs"] / max(1, args.steps),
+                "share_of_step": asv["asv_ms"] / (1e3 * elapsed),
+                "cells_tiled": _bl.dev_get("asv_tiled_cells") // max(1, args.steps + 0),
+                "cells_rerun_in_reference_order": _bl.dev_get("asv_literal_cells") // max(1, args.steps),
+                "cells_flagged_beyond_the_rerun": _bl.dev_get("asv_fallback_cells") // max(1, args.steps),
+            }
         if h2h is not None:
             line["value_host_to_host"] = n_cells / h2h
             line["host_to_host_ms"] = 1e3 * h2h

@@ -221,6 +221,9 @@ int32_t bmx_engine_snapshot_var_adj(bmx_engine_t* e, double* left_rm, double* ri
  * completed that way -- hundreds of uncertified queries, lists overflowing with ties -- it starts over; the ranks of a
  * sharded run agree on that through a flag that travels with every search's lists, and start over together). */
 int32_t bmx_engine_profile_detail(bmx_engine_t* e, double* out10);
+/* The last profiled run's adjust_shift_variance calls (params.var_adj): out[0] = milliseconds (HIP events on the engine's
+ * stream around each call), out[1] = calls, out[2] = (cell, restricted cell) pairs this rank evaluated. */
+int32_t bmx_engine_profile_var_adj(bmx_engine_t* e, double* out3);
 /* Name of the full-pass candidate kernel the engine launched last, as rocprofv3 prints it (template arguments
  * included): lets a benchmark check that a stored counter measurement belongs to the kernel it has just timed. */
 int32_t bmx_engine_knn_kernel(bmx_engine_t* e, char* buf, int32_t n);
