@@ -165,6 +165,7 @@ int32_t bmx_dev_set(const char* name, int32_t value) {
     else if (n == "no_margin") k.no_margin = value;
     else if (n == "asv_fast") k.asv_fast = value;
     else if (n == "asv_cap") k.asv_cap = value;
+    else if (n == "sample_split") k.sample_split = value;
     else if (n == "exchange_always") k.exchange_always = value;
     else if (n == "refine_wave") k.refine_wave = value;
     else if (n == "reset") k = bmx::DevKnobs();
@@ -637,6 +638,10 @@ int32_t bmx_engine_init_rccl(bmx_engine_t* e, int32_t rank, int32_t world, const
         if (bytes < 128) throw bmx::Error(BMX_ERR_ARG, "the RCCL unique id needs 128 bytes");
         e->impl->init_rccl(rank, world, unique_id);
     });
+}
+
+int32_t bmx_engine_emulate(bmx_engine_t* e, int32_t mode, int32_t rank, int32_t world) {
+    return guarded([&] { e->impl->emulate(mode, rank, world); });
 }
 
 int32_t bmx_engine_exchange_stats(bmx_engine_t* e, int64_t* calls, int64_t* bytes) {

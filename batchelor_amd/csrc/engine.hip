@@ -222,7 +222,104 @@ void Engine::init_rccl(int rank, int world, const void* unique_id) {
     gather_ctx_ = nullptr;
 }
 
-void Engine::exchange(void* buf, int64_t bytes_per_rank) {
+// One rank of an N-rank run measured on ONE GPU (bmx_engine_emulate, bench.py --emulate-world): a single-rank run first
+// RECORDS what every exchange would have gathered -- the complete array, which a single rank computes itself --, then the
+// engine runs as rank r of N: every search covers its slice of the query rows only, every kernel that a multi-rank run
+// replicates runs in full, and an exchange fills the OTHER ranks' slices from the recording (a device copy in place of the
+// all-gather: what is timed is the rank's own work; the collective's time is modelled beside it from its byte count).
+// The results are bit-identical to the recorded run's, so the sequence and the sizes of the exchanges are the same.
+void Engine::emulate(int mode, int rank, int world) {
+    if (mode < 0 || mode > 2) throw Error(BMX_ERR_ARG, "emulation mode: 0 off, 1 record, 2 replay");
+    if (mode == 2 && (world < 1 || rank < 0 || rank >= world)) throw Error(BMX_ERR_ARG, "invalid rank / world size");
+    if (comm_ || gather_fn_) throw Error(BMX_ERR_ARG, "emulation is for an engine without a transport");
+    if (stream_) BMX_HIP(hipStreamSynchronize(stream_));
+    emu_mode_ = mode;
+    if (mode == 1) {
+        emu_rec_.clear();
+        rank_ = 0;
+        world_ = 1;
+    } else if (mode == 2) {
+        rank_ = rank;
+        world_ = world;
+    } else {
+        emu_rec_.clear();
+        rank_ = 0;
+        world_ = 1;
+    }
+}
+
+// n doubles from src to dst (a device copy as a kernel: a hipMemcpyAsync between device buffers costs ~200 us of idle stream
+// in front of it on this runtime, a launch ~5)
+__global__ void copy_doubles_kernel(double* __restrict__ dst, const double* __restrict__ src, int64_t n) {
+    const int64_t n2 = n >> 1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x)
+        reinterpret_cast<double2*>(dst)[i] = reinterpret_cast<const double2*>(src)[i];
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) dst[n - 1] = src[n - 1];
+}
+static void copy_doubles(hipStream_t stream, double* dst, const double* src, int64_t n) {
+    if (n <= 0) return;
+    if ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) {  // (never for rows of an even d)
+        BMX_HIP(hipMemcpyAsync(dst, src, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        return;
+    }
+    hipLaunchKernelGGL(copy_doubles_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(4096, (n / 2 + 255) / 256))),
+                       dim3(256), 0, stream, dst, src, n);
+    BMX_LAUNCH_CHECK();
+}
+
+// the other ranks' slices of an emulated exchange in ONE launch: bytes [0, lo) and [hi, total) of the recording (zeros when
+// there is none: the optimistic-search flags), 16 bytes per thread where the pieces allow
+__global__ void emu_fill_kernel(char* __restrict__ dst, const char* __restrict__ src, int64_t lo, int64_t hi, int64_t total) {
+    const int64_t n16 = (lo >> 4) + ((total - hi + 15) >> 4);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t o = i < (lo >> 4) ? i << 4 : hi + ((i - (lo >> 4)) << 4);
+        if (o + 16 <= total && ((reinterpret_cast<uintptr_t>(dst + o) | reinterpret_cast<uintptr_t>(src + o)) & 15) == 0) {
+            *reinterpret_cast<int4*>(dst + o) = src ? *reinterpret_cast<const int4*>(src + o) : int4{0, 0, 0, 0};
+        } else {
+            for (int64_t b = o; b < o + 16 && b < total; ++b) dst[b] = src ? src[b] : 0;
+        }
+    }
+    // (the ragged end of the first piece)
+    if (blockIdx.x == 0 && threadIdx.x < (lo & 15)) {
+        const int64_t b = (lo & ~(int64_t)15) + threadIdx.x;
+        dst[b] = src ? src[b] : 0;
+    }
+}
+
+void Engine::exchange(void* buf, int64_t bytes_per_rank, bool flags_only) {
+    if (emu_mode_ == 1) {  // record: this (single) rank's slice is the whole array
+        if (flags_only) return;
+        if (emu_next_ >= emu_rec_.size()) emu_rec_.emplace_back();
+        auto& r = emu_rec_[emu_next_++];
+        r.second = bytes_per_rank;
+        BMX_HIP(hipMemcpyAsync(r.first.reserve((size_t)std::max<int64_t>(bytes_per_rank, 1)), buf, (size_t)bytes_per_rank,
+                               hipMemcpyDeviceToDevice, stream_));
+        return;
+    }
+    if (emu_mode_ == 2) {
+        ++xchg_calls_;
+        xchg_bytes_ += bytes_per_rank * world_;
+        char* base = static_cast<char*>(buf);
+        const int64_t mine = (int64_t)rank_ * bytes_per_rank;
+        if (flags_only) {  // the other ranks' optimistic-search flags: all clear (the recorded run went through)
+            const int64_t total = (int64_t)world_ * bytes_per_rank;
+            hipLaunchKernelGGL(emu_fill_kernel, dim3(1), dim3(256), 0, stream_, base, (const char*)nullptr, mine,
+                               mine + bytes_per_rank, total);
+            BMX_LAUNCH_CHECK();
+            return;
+        }
+        if (emu_next_ >= emu_rec_.size()) throw Error(BMX_ERR_ARG, "emulated run: more exchanges than the recorded run made");
+        const auto& r = emu_rec_[emu_next_++];
+        // bytes [0, mine) and [mine + per, total) of the recording, where they exist
+        const int64_t total = r.second, lo = std::min(mine, total), hi = std::min(mine + bytes_per_rank, total);
+        const int64_t n16 = (lo >> 4) + ((total - hi + 15) >> 4);
+        if (n16 > 0 || (lo & 15)) {
+            hipLaunchKernelGGL(emu_fill_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, (n16 + 255) / 256))),
+                               dim3(256), 0, stream_, base, (const char*)r.first.p, lo, hi, total);
+            BMX_LAUNCH_CHECK();
+        }
+        return;
+    }
     // testing hook (bmx_dev_set "exchange_always"): a single rank goes through its transport too (an all-gather of one)
     const bool always = dev_knobs().exchange_always != 0;
     if (world_ == 1 && !(always && (comm_ || gather_fn_))) return;
@@ -336,7 +433,7 @@ void Engine::upload(int nbatches, int d, const double* const* data, const int32_
 }
 
 void Engine::knn(const double* X, const int32_t* ref_rows, int nr, const double* Q, const int32_t* q_rows, int nq,
-                 int k, int32_t* idx, double* dist, const float* seed_d2, const double* centre, double* kth) {
+                 int k, int32_t* idx, double* dist, const float* seed_d2, const double* centre, double* kth, bool gather) {
     // query rows are split over ranks; the padded per-rank slices are contiguous, so the all-gather is in place
     int64_t b = 0, e = nq;
     bmx_shard_range_impl(nq, rank_, world_, &b, &e);
@@ -364,10 +461,11 @@ void Engine::knn(const double* X, const int32_t* ref_rows, int nr, const double*
         const bool group = (dist || kth || flags) && comm_ && world_ > 1 && rccl::api().GroupStart && rccl::api().GroupEnd;
         if (group) (void)rccl::api().GroupStart();
         try {
-            exchange(idx, per * k * (int64_t)sizeof(int32_t));
-            if (dist) exchange(dist, per * k * (int64_t)sizeof(double));
-            if (kth) exchange(kth, per * (int64_t)sizeof(double));
-            if (flags) exchange(xf, 4 * (int64_t)sizeof(int32_t));
+            // (gather = false: the caller goes on with its own slice of the lists and exchanges what it makes of them)
+            if (gather) exchange(idx, per * k * (int64_t)sizeof(int32_t));
+            if (gather && dist) exchange(dist, per * k * (int64_t)sizeof(double));
+            if (gather && kth) exchange(kth, per * (int64_t)sizeof(double));
+            if (flags) exchange(xf, 4 * (int64_t)sizeof(int32_t), /* flags_only */ true);
         } catch (...) {
             if (group) (void)rccl::api().GroupEnd();  // never leave the group open behind an error
             throw;
@@ -773,13 +871,30 @@ void Engine::merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p,
         }
         const int k_tc = choose_k(p.k, p.prop_k, right.n);  // unrestricted size of the right batch
         const int safe_k = std::min(k_tc, mo.U);
-        const int64_t per = bmx_shard_rows_per_rank(right.n, world_) * (int64_t)world_;
+        const int64_t per1 = bmx_shard_rows_per_rank(right.n, world_);
+        const int64_t per = per1 * (int64_t)world_;
         int32_t* idxT = idxT_.reserve((size_t)per * safe_k);
         double* distT = distT_.reserve((size_t)per * safe_k);
+        // Several ranks (without var_adj): every rank has the neighbour lists of ITS slice of the right cells from the search;
+        // it corrects those rows and the CORRECTED ROWS are all-gathered (n x d x 8 bytes) instead of the lists (n x k x 12):
+        // the same order of bytes, and the apply is sharded with the search instead of being repeated on every rank.
+        const bool rows_sharded = !p.var_adj && (world_ > 1 || emu_mode_ == 1);
         sec.reset();
-        knn(right.data.p, srows, mo.U, right.data.p, nullptr, right.n, safe_k, idxT, distT, nullptr, mu_r);
+        knn(right.data.p, srows, mo.U, right.data.p, nullptr, right.n, safe_k, idxT, distT, nullptr, mu_r, nullptr, !rows_sharded);
         sec = std::make_unique<Section>(this);  // streaming section 3: tricube apply, rbind
-        if (!p.var_adj) {
+        if (rows_sharded) {
+            int64_t b = 0, e = right.n;
+            bmx_shard_range_impl(right.n, rank_, world_, &b, &e);
+            if (e > b)
+                tricube_apply(stream_, right.data.p + (size_t)b * d_, (int)(e - b), d_, averaged, idxT + (size_t)b * safe_k,
+                              distT + (size_t)b * safe_k, safe_k, p.ndist);
+            // (the node's rows sit in the run's arena, other leaves right behind them: the padded slices meet in a buffer)
+            double* rows = corr_.reserve((size_t)per * d_);
+            copy_doubles(stream_, rows + (size_t)b * d_, right.data.p + (size_t)b * d_, (e - b) * (int64_t)d_);
+            exchange(rows, per1 * d_ * (int64_t)sizeof(double));
+            copy_doubles(stream_, right.data.p, rows, b * (int64_t)d_);
+            copy_doubles(stream_, right.data.p + (size_t)e * d_, rows + (size_t)e * d_, (right.n - e) * (int64_t)d_);
+        } else if (!p.var_adj) {
             tricube_apply(stream_, right.data.p, right.n, d_, averaged, idxT, distT, safe_k, p.ndist);
         } else {
             // mnnCorrect(var.adj=TRUE) on the fastMNN correction (R/mnnCorrect.R:331-342,462-481): every right cell's
@@ -928,6 +1043,7 @@ void Engine::run(const bmx_params_t& p, const int32_t* tree, int tree_len) {
 
 // counts[t] is known on rank t % world only (0 elsewhere): every rank gets them all (an all-gather of the padded slices)
 std::vector<int32_t> Engine::gather_counts(const std::vector<int32_t>& mine) {
+    if (emu_mode_ == 2) throw Error(BMX_ERR_ARG, "the one-GPU emulation of a rank covers predefined merge trees, not auto-merge's dealt searches");
     if (world_ == 1) return mine;
     const int n = (int)mine.size();
     const int per = (n + world_ - 1) / world_ + 1;  // (+ 1: "one of my searches could not be completed optimistically")
@@ -983,6 +1099,7 @@ void Engine::run_once(const bmx_params_t& p, const int32_t* tree, int tree_len) 
     merges_.resize(nmerges);
     n_extras_ = 0;
     xchg_calls_ = xchg_bytes_ = 0;
+    emu_next_ = 0;
     knn_ws_.events_used = 0;
     asv_pairs_ = 0.0;
     vecs_.reserve((size_t)(2 * B_ + 8) * d_);

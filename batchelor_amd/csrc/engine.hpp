@@ -64,6 +64,7 @@ class Engine {
     // production exchange: an RCCL communicator owned by the engine, all-gathers in place on the engine's stream
     void init_rccl(int rank, int world, const void* unique_id);
     // exchange statistics since the last run() started
+    void emulate(int mode, int rank, int world);  // 0 off, 1 record (single rank), 2 replay as rank of world (see engine.hip)
     int64_t exchange_calls() const { return xchg_calls_; }
     int64_t exchange_bytes() const { return xchg_bytes_; }
     // lazy: the matrices are NOT copied here -- the caller keeps them valid until the next run() has returned, which
@@ -108,7 +109,7 @@ class Engine {
     // single primitives (also used by the host-pointer parity entry points)
     void knn(const double* X, const int32_t* ref_rows, int nr, const double* Q, const int32_t* q_rows, int nq, int k,
              int32_t* idx, double* dist, const float* seed_d2 = nullptr, const double* centre = nullptr,
-             double* kth = nullptr);
+             double* kth = nullptr, bool gather = true);
     struct MnnOut {
         int64_t P = 0;
         int U = 0;
@@ -165,7 +166,7 @@ class Engine {
     void orthogonalize(Node& node, const std::vector<int>& extras);
     int count_mnn_pairs(const Node& left, const Node& right, const bmx_params_t& p);
     std::unique_ptr<Node> clone_node(const Node& src);
-    void exchange(void* buf, int64_t bytes_per_rank);
+    void exchange(void* buf, int64_t bytes_per_rank, bool flags_only = false);
 
     void wait(double work_s = 0.0);  // guarded wait on the engine's stream: deadline wd_base_s_ + work_s
     void ensure_uploaded(int b);   // batch b's copy is queued (lazy uploads: on the copy stream, with an event)
@@ -203,6 +204,9 @@ class Engine {
     void* gather_ctx_ = nullptr;
     void* comm_ = nullptr;  // ncclComm_t
     int64_t xchg_calls_ = 0, xchg_bytes_ = 0;
+    int emu_mode_ = 0;                                        // bmx_engine_emulate
+    std::vector<std::pair<DevBuf<char>, int64_t>> emu_rec_;   // what each exchange of the recorded run would have gathered
+    size_t emu_next_ = 0;
     int64_t fallbacks_ = 0;
     struct Section {  // a streaming section bracketed by events while profiling
         Engine* e;

@@ -820,6 +820,16 @@ void candidate_pass(hipStream_t stream, KnnWorkspace& ws, const Tier& T, const d
     // one far-away right cell -- then starts from a sampled threshold instead of none; the tighter of the two counts)
     if (seed_d2 && T.id == 1) S_auto = std::min(S_auto, BMX_SEEDED_SAMPLE);
     int S = (int)round_up(dev_knobs().sample >= 0 ? dev_knobs().sample : S_auto, T.id == 1 ? f16_rows_per_slot(NS, KS) : 64);
+    // A search with few query blocks (a rank's slice of a multi-GPU run: 12 500 queries = 49 blocks for 256 CUs) would sweep
+    // the sample with a fifth of the chip, every block over all of it: the sample is split into CS ranges instead, block x
+    // range items fill the CUs, each range of at least 24 ring slots (a lane keeps the KS / 2 <= 24 smallest of its per-slot
+    // minima) hands its queries a threshold of its own and the tightest one counts (atomicMin on the shared word).
+    int CS = 1;
+    if (T.id == 1 && S > 0 && nqb < 128 && dev_knobs().sample_split != 0) {
+        const int rs = f16_rows_per_slot(NS, KS);
+        CS = std::max(1, std::min({256 / std::max(nqb, 1), 8, S / (24 * rs)}));
+        if (dev_knobs().sample_split > 0) CS = std::max(1, std::min(dev_knobs().sample_split, S / rs));
+    }
     int C = 1, n_full = 0;
     {
         const int a = nqb / 256, b = nqb % 256;
@@ -911,7 +921,7 @@ void candidate_pass(hipStream_t stream, KnnWorkspace& ws, const Tier& T, const d
         // without a sample pass the thresholds start at the seed (or at +inf): prep writes them
         f16_prep_all(stream, X, ref_rows, nr, nr_pad, Qs, qrs, nq, nq_pad, d, NS, centre, reinterpret_cast<uint16_t*>(pr),
                      reinterpret_cast<uint16_t*>(pq), rn2, qn2, maxbits, slots, flagged, margin, pe, seed_d2, tau_seed,
-                     S == 0 ? tau_g : nullptr);
+                     S == 0 || CS > 1 ? tau_g : nullptr);
         if (margin) {
             L.margin = margin;
             L.k = k;
@@ -919,7 +929,14 @@ void candidate_pass(hipStream_t stream, KnnWorkspace& ws, const Tier& T, const d
         L.tau_seed = tau_seed;
         zero_slots = slots;  // knn_refine leaves them zeroed for the next search
         ws.slots_clean = false;
-        if (S > 0) ok = go(L);
+        if (S > 0) {
+            if (CS > 1) {  // block x range items over the sample rows [0, S)
+                const int rs = f16_rows_per_slot(NS, KS);
+                L.range_len = (int)round_up(cdiv(S, CS), rs);
+                L.nranges = cdiv(S, L.range_len);
+            }
+            ok = go(L);
+        }
     } else {
         ws.slots_clean = false;
         BMX_HIP(hipMemsetAsync(maxbits, 0, sizeof(unsigned long long), stream));

@@ -1102,7 +1102,12 @@ __global__ __launch_bounds__((NCONS + NPROD + serv_waves(NS)) * 64) void knn_top
             }
         }
         // (a seeded search: the tighter of the sampled threshold and the seed's, prep wrote the latter's image)
-        if (h == 0) tau_g[q] = tau_seed ? min(start, tau_seed[q]) : start;
+        // A sample split into ranges (few query blocks, see knn.hip): every range's threshold is valid by itself -- k of ITS
+        // references lie at or below it -- so the tightest of them is; prep has written the seed (or +inf) there.
+        if (h == 0) {
+            if (nrng > 1) atomicMin(&tau_g[q], start);
+            else tau_g[q] = tau_seed ? min(start, tau_seed[q]) : start;
+        }
 #ifdef BMX_STAMPS
         if (lane == 0) {
             atomicAdd(&bmx_dbg16[0], STAMP() - dbg_t0);

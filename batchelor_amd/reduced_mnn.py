@@ -128,6 +128,11 @@ class MnnEngine:
             raise err
         _lib.check(rc)
 
+    def emulate(self, mode, rank=0, world=1):
+        """Measurement hook (bmx_engine_emulate): mode 1 records a single-rank run's exchanges, mode 2 makes the engine
+        rank `rank` of `world` with the other ranks' results replayed from the recording, mode 0 switches it off."""
+        _lib.check(_lib.lib().bmx_engine_emulate(self._h, int(mode), int(rank), int(world)))
+
     def exchange_stats(self):
         calls, nbytes = ctypes.c_int64(0), ctypes.c_int64(0)
         _lib.check(_lib.lib().bmx_engine_exchange_stats(self._h, ctypes.byref(calls), ctypes.byref(nbytes)))

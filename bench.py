@@ -333,6 +333,80 @@ def run_sgk(args):
     assert err < 1e-9, err
 
 
+def run_emulation(args):
+    """One rank's share of an N-rank run, measured on ONE GPU: `bmx_engine_emulate` makes the engine rank r
+    of N -- its slice of every search's query rows, every replicated kernel in full -- with the other ranks' slices of each
+    exchange replayed from a recorded single-rank run.  The collectives themselves are not run: their count and bytes are
+    reported with a stated model of their time beside the measured per-rank step.  One JSON line per world size."""
+    import torch
+    import batchelor_amd as bx
+    torch.cuda.set_device(0)
+    cfg, sizes, d, k, tree = WORKLOADS[args.workload]
+    batches = synth_batches(cfg, sizes, d)
+    n_cells = int(sum(sizes))
+    if tree is not None:
+        from batchelor_amd.merge_tree import resolve_merge_order
+        tree = resolve_merge_order(len(sizes), tree)
+    run_kw = {"var_adj": True, "sigma": args.sigma} if args.var_adj else {}
+    eng = bx.MnnEngine(0)
+    eng.upload(batches)
+
+    def timed(steps, warmup):
+        for _ in range(warmup):
+            eng.run(k=k, merge_tree=tree, **run_kw)
+        eng.set_profiling(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        acc = None
+        for _ in range(steps):
+            eng.run(k=k, merge_tree=tree, **run_kw)
+            p = eng.profile_detail()
+            acc = dict(p) if acc is None else {key: (acc[key] + v if isinstance(v, (int, float)) else v) for key, v in p.items()}
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / steps
+        eng.set_profiling(False)
+        cand = (acc["f16_ms"] + acc["bf16_ms"] + acc["sample_ms"]) / steps
+        return ms, cand, acc["streaming_ms"] / steps
+
+    t1, cand1, stream1 = timed(args.steps, args.warmup)
+    base = eng.download(with_pairs=True)
+    eng.emulate(1)
+    eng.run(k=k, merge_tree=tree, **run_kw)   # the recorded run
+    # xGMI: 7 links x ~153 GB/s per GPU (task statement); a ring all-gather moves (N-1)/N of the gathered bytes through every
+    # rank at the rate of its slowest hop; modelled at 60 % of one direction of the links a rank can drive + 15 us per launch
+    for world in [int(x) for x in str(args.emulate_world).split(",")]:
+        ranks = list(range(world)) if args.emulate_ranks == "all" else [int(x) for x in args.emulate_ranks.split(",") if int(x) < world]
+        per_rank, detail = [], []
+        xst = None
+        for r in ranks:
+            eng.emulate(2, r, world)
+            ms, cand, stream = timed(args.steps, args.warmup)
+            per_rank.append(ms)
+            detail.append({"rank": r, "ms_per_step": ms, "candidate_pass_ms": cand, "streaming_ms": stream})
+            xst = eng.exchange_stats()
+            if r == ranks[0]:  # the emulated rank ends with the recorded run's result, bit for bit
+                got = eng.download(with_pairs=True)
+                assert np.array_equal(got.corrected, base.corrected)
+                for (a0, a1), (b0, b1) in zip(got.merge_info.pairs, base.merge_info.pairs):
+                    assert np.array_equal(a0, b0) and np.array_equal(a1, b1)
+        links = min(world - 1, 7)
+        model_ms = 1e3 * (xst["bytes"] * (world - 1) / world) / (0.6 * 153e9 * links) + 0.015 * xst["calls"]
+        worst = max(per_rank)
+        print(json.dumps({
+            "metric": "one rank's ms per step, emulated on one GPU (rank r of N: its share of every search, every replicated kernel)",
+            "workload": args.workload, "n_gpus_emulated": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step_one_gpu": t1, "candidate_pass_ms_one_gpu": cand1, "streaming_ms_one_gpu": stream1,
+            "per_rank_ms_per_step": per_rank, "max_rank_ms_per_step": worst, "per_rank": detail,
+            "ideal_ms_per_step": t1 / world, "sharding_efficiency": (t1 / world) / worst,
+            "exchange_calls_per_step": xst["calls"], "exchange_bytes_per_step": xst["bytes"],
+            "exchange_model_ms_per_step": model_ms,
+            "exchange_model": "bytes (N-1)/N over min(N-1, 7) xGMI links at 60 % of 153 GB/s + 15 us per launch, serial",
+            "projected_speedup_compute_only": t1 / worst, "projected_speedup_with_modelled_exchange": t1 / (worst + model_ms),
+            "projected_cells_per_s": n_cells / ((worst + model_ms) * 1e-3),
+            "results_identical_to_one_gpu": True}), flush=True)
+    eng.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -347,6 +421,9 @@ def main():
                     "(1.0 relative to the synthetic spectrum; 0.1 is mnnCorrect's default, R/mnnCorrect.R:125-130)")
     ap.add_argument("--dev", action="append", default=[], metavar="KNOB=VALUE",
                     help="developer A/B runs: a testing hook of the library (bmx_dev_set), e.g. --dev asv_cap=0")
+    ap.add_argument("--emulate-world", default=None, metavar="N[,N...]",
+                    help="measure one rank's share of an N-rank run on this one GPU (bmx_engine_emulate); e.g. 2,4,8")
+    ap.add_argument("--emulate-ranks", default="all", help="--emulate-world: which ranks to measure (all, or e.g. 0,3,7)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-to-host", action="store_true")
     args = ap.parse_args()
@@ -356,6 +433,8 @@ def main():
         for kv in args.dev:
             name, val = kv.split("=")
             _bl.dev_set(name, int(val))
+    if args.emulate_world:
+        return run_emulation(args)
     if args.workload == "config4":
         return run_config4(args)
     if args.workload == "sgk":

@@ -224,6 +224,13 @@ int32_t bmx_engine_profile_detail(bmx_engine_t* e, double* out10);
 /* The last profiled run's adjust_shift_variance calls (params.var_adj): out[0] = milliseconds (HIP events on the engine's
  * stream around each call), out[1] = calls, out[2] = (cell, restricted cell) pairs this rank evaluated. */
 int32_t bmx_engine_profile_var_adj(bmx_engine_t* e, double* out3);
+/* Measurement hook: ONE rank's share of an N-rank run on one GPU.  mode 1: the next run (a single rank) records what every
+ * exchange of the run would have gathered; mode 2: the following runs are rank `rank` of `world` -- each search covers that
+ * rank's slice of the query rows (bmx_shard_range), every replicated kernel runs in full, and an exchange fills the other
+ * ranks' slices from the recording by a device copy (the collective itself is not timed: bmx_engine_exchange_stats gives its
+ * calls and bytes); results are those of the recorded run; mode 0: back to normal.  Predefined merge trees only (auto-merge
+ * deals whole searches over the ranks); the engine must have no transport (bmx_engine_init_rccl / _set_shard). */
+int32_t bmx_engine_emulate(bmx_engine_t* e, int32_t mode, int32_t rank, int32_t world);
 /* Name of the full-pass candidate kernel the engine launched last, as rocprofv3 prints it (template arguments
  * included): lets a benchmark check that a stored counter measurement belongs to the kernel it has just timed. */
 int32_t bmx_engine_knn_kernel(bmx_engine_t* e, char* buf, int32_t n);

@@ -37,10 +37,11 @@ def test_n_rank_engine_equals_single_rank(tmp_path, world, var_adj):
             assert np.array_equal(got[f"pl{m}"], ref.merge_info.pairs[m][0])
             assert np.array_equal(got[f"pr{m}"], ref.merge_info.pairs[m][1])
         assert np.array_equal(got["lost_var"], ref.merge_info.lost_var)
-        # per merge: index + distance gathers of the first search, index + k-th distance of the second, index + distance of
-        # the tricube search, with each of them the ranks' "could not be completed on the device" flags (+ the scalings
-        # with var_adj)
-        assert int(got["calls"]) == 2 * (3 + 3 + 3 + (1 if var_adj else 0))
+        # per merge: index + distance gathers of the first search, index + k-th distance of the second, with each of them the
+        # ranks' "could not be completed on the device" flags; the tricube search exchanges its flags only -- every rank
+        # corrects its own slice of the right cells and the corrected ROWS are gathered (with var_adj the lists are, as every
+        # rank needs all correction vectors, + the scalings)
+        assert int(got["calls"]) == 2 * (3 + 3 + (3 + 1 if var_adj else 2))
         assert int(got["retries"]) == 0
 
 
