@@ -335,6 +335,7 @@ struct KnnWorkspace {
     // per candidate tier: [count + 1] compact list of the queries it could not certify (+ counter in word 0), their
     // k-th candidate distances, and the scratch of the sub-search the next tier runs on them
     DevBuf<int32_t> flagged_t[2], sub_rows[2], sub_idx[2];
+    DevBuf<int32_t> lk_rows, lk_idx;  // k > 36: the partitions' row lists, their neighbour lists [P][nq][36]
     DevBuf<double> flag_bound_t[2], sub_dist[2];
     DevBuf<double> drow;           // exact-path distance rows
     DevBuf<double> xd;             // short exact lists

@@ -1192,6 +1192,216 @@ void search_tiers(hipStream_t stream, KnnWorkspace& ws, const Tier* tiers, int n
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// k beyond what the candidate tiers' lists hold (k > 36: `prop.k` of R/MNN_tree.R:140-146, or simply k = 50).
+// The reference is dealt into P strided partitions (row j of the list goes to partition j mod P: independent of how the
+// caller ordered its cells), every partition is searched for its 36 (or 20) nearest with the whole certified cascade above, and
+// the P x 36 candidates of a query are merged exactly: squared distances recomputed in the reference's order of operations
+// (sum over the dimensions of (q - x)^2, no contraction), sorted by (distance, position) -- the oracle's order --, the first
+// k are the answer PROVIDED no partition's list ends inside them: a partition whose 36th neighbour ranks behind the k-th
+// merged candidate cannot hold anything nearer that it did not list.  With P = ceil(k / 16) a partition holds 16 of the k
+// on average; a query for which one holds more than 35 fails the test and goes to the exact scan.
+// Cost: the matrix work of ONE search at k = 36 (P searches over 1 / P of the reference each) + P preparations.
+// ---------------------------------------------------------------------------------------------------
+constexpr int LK_MAXE = 2048;  // candidates merged per query
+
+// rows[off_p + j] = the (p + j P)-th row of the caller's reference list, partition-major
+__global__ void lk_partition_rows(const int32_t* __restrict__ ref_rows, int nr, int P, int32_t* __restrict__ rows) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nr) return;
+    const int p = g % P, j = g / P;
+    // partitions 0 .. (nr % P) - 1 hold one row more: offset of partition p = p * (nr / P) + min(p, nr % P)
+    const int base = nr / P, rem = nr % P;
+    rows[(int64_t)p * base + (p < rem ? p : rem) + j] = ref_rows ? ref_rows[g] : g;
+}
+
+// kp: neighbours asked of every partition (sub_idx [P][nq][kp])
+__global__ __launch_bounds__(256) void lk_merge(const double* __restrict__ X, const int32_t* __restrict__ rows, int nr, int P,
+                                                int kp, const double* __restrict__ Q, const int32_t* __restrict__ qrs, int nq,
+                                                int d, int k, const int32_t* __restrict__ sub_idx, int32_t* __restrict__ idx_out,
+                                                double* __restrict__ dist_out, int32_t* __restrict__ flagged,
+                                                int32_t* __restrict__ opt) {
+    __shared__ double kd[LK_MAXE];
+    __shared__ int32_t ki[LK_MAXE];
+    __shared__ int sh_fail;
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int E = P * kp;
+    int np2 = 256;
+    while (np2 < E) np2 <<= 1;
+    const double* qv = Q + (int64_t)(qrs ? qrs[q] : q) * d;
+    const int base = nr / P, rem = nr % P;
+    for (int e = tid; e < np2; e += 256) {
+        double d2 = __builtin_inf();
+        int g = 0x7fffffff;
+        if (e < E) {
+            const int p = e / kp, j = e - p * kp;
+            const int l = sub_idx[((int64_t)p * nq + q) * kp + j];  // position inside partition p
+            if (l >= 0) {
+                const double* x = X + (int64_t)rows[(int64_t)p * base + (p < rem ? p : rem) + l] * d;
+                double s = 0.0;
+                for (int c = 0; c < d; ++c) {
+                    const double t = qv[c] - x[c];
+                    s += t * t;
+                }
+                d2 = s;
+                g = l * P + p;  // its position in the caller's reference list
+            }
+        }
+        kd[e] = d2;
+        ki[e] = g;
+    }
+    if (tid == 0) sh_fail = 0;
+    __syncthreads();
+    for (int kk = 2; kk <= np2; kk <<= 1)
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < np2; i += 256) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const double a = kd[i], b = kd[ixj];
+                    const int ia = ki[i], ib = ki[ixj];
+                    const bool gt = a > b || (a == b && ia > ib);
+                    if (((i & kk) == 0) ? gt : !gt) {
+                        kd[i] = b;
+                        kd[ixj] = a;
+                        ki[i] = ib;
+                        ki[ixj] = ia;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    for (int r = tid; r < k; r += 256) {
+        idx_out[(int64_t)q * k + r] = ki[r];
+        if (dist_out) dist_out[(int64_t)q * k + r] = sqrt(kd[r]);
+    }
+    // no partition's list may end inside the first k: its last entry is the kp-th of its partition -- found among the sorted
+    // candidates by its position (unique) -- and must rank at k or later
+    for (int r = tid; r < k; r += 256) {
+        const int g = ki[r], p = g % P, l = g / P;
+        if (sub_idx[((int64_t)p * nq + q) * kp + kp - 1] == l) sh_fail = 1;
+    }
+    __syncthreads();
+    if (tid == 0 && sh_fail) {
+        if (opt) atomicOr(opt, 1);  // optimistic run: the engine repeats it with host-checked searches
+        else flagged[1 + atomicAdd(&flagged[0], 1)] = q;
+    }
+}
+
+// The same merge for up to 512 candidates a query (k <= 224 with lists of 36), one WAVE per query and no sort: the partitions'
+// lists arrive sorted by (squared distance, position) -- the order the merged list wants --, so a candidate's place in the
+// merged list is the number of candidates in front of it: its place in its own list plus, for every other partition, a binary
+// search.  (A 256-thread bitonic sort per query took 3 ms a search at config 2, a third of the whole.)
+__global__ __launch_bounds__(256) void lk_merge_wave(const double* __restrict__ X, const int32_t* __restrict__ rows, int nr, int P,
+                                                     int kp, const double* __restrict__ Q, const int32_t* __restrict__ qrs,
+                                                     int nq, int d, int k, const int32_t* __restrict__ sub_idx,
+                                                     int32_t* __restrict__ idx_out, double* __restrict__ dist_out,
+                                                     int32_t* __restrict__ flagged, int32_t* __restrict__ opt) {
+    __shared__ double kd_[4][512];
+    __shared__ int32_t ki_[4][512];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + w;
+    if (q >= nq) return;  // (whole waves: nothing below synchronises the block)
+    double* kd = kd_[w];
+    int32_t* ki = ki_[w];
+    const int E = P * kp;
+    const double* qv = Q + (int64_t)(qrs ? qrs[q] : q) * d;
+    const int base = nr / P, rem = nr % P;
+    for (int e = lane; e < E; e += 64) {
+        const int p = e / kp, j = e - p * kp;
+        const int l = sub_idx[((int64_t)p * nq + q) * kp + j];
+        const double* x = X + (int64_t)rows[(int64_t)p * base + (p < rem ? p : rem) + (l >= 0 ? l : 0)] * d;
+        // (eight coordinates asked for at a time -- a random row: the round trips are what this costs --, summed in order)
+        double s = 0.0;
+        int c = 0;
+        for (; c + 8 <= d; c += 8) {
+            double xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xv[u] = x[c + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const double t = qv[c + u] - xv[u];
+                s += t * t;
+            }
+        }
+        for (; c < d; ++c) {
+            const double t = qv[c] - x[c];
+            s += t * t;
+        }
+        kd[e] = l >= 0 ? s : __builtin_inf();
+        ki[e] = l >= 0 ? l * P + p : 0x7fffffff;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    bool fail = false;
+    for (int e = lane; e < E; e += 64) {
+        const int p = e / kp, j = e - p * kp;
+        const double de = kd[e];
+        const int ge = ki[e];
+        int rank = j;
+        for (int p2 = 0; p2 < P; ++p2) {
+            if (p2 == p) continue;
+            int lo = 0, hi = kp;  // entries of list p2 in front of (de, ge)
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                const double dm = kd[p2 * kp + mid];
+                const int gm = ki[p2 * kp + mid];
+                if (dm < de || (dm == de && gm < ge)) lo = mid + 1;
+                else hi = mid;
+            }
+            rank += lo;
+        }
+        if (rank < k) {
+            idx_out[(int64_t)q * k + rank] = ge;
+            if (dist_out) dist_out[(int64_t)q * k + rank] = sqrt(de);
+            fail |= j == kp - 1;  // a partition's list ends inside the first k
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(fail) != 0 && lane == 0) {
+        if (opt) atomicOr(opt, 1);
+        else flagged[1 + atomicAdd(&flagged[0], 1)] = q;
+    }
+}
+
+// false: the shape does not suit the partitioned search (too few reference cells a partition, too many candidates)
+bool large_k_search(hipStream_t stream, KnnWorkspace& ws, const double* X, const int32_t* ref_rows, int nr, const double* Qs,
+                    const int32_t* qrs, int nq, int d, int k, int32_t* io, double* dout, const double* centre) {
+    // neighbours asked of a partition: 36 where a tier holds that many (rows of up to 61 columns), else 20 (up to 125); a
+    // partition holds 0.45 of that of a query's k on average, so that one holding all of it is rare
+    Tier tiers[2];
+    int kp = 36;
+    if (candidate_tiers(d, kp, std::max(nr / cdiv(k, 16), 1), tiers) == 0) kp = 20;
+    const int P = std::max(2, cdiv(k, kp == 36 ? 16 : 9));
+    if ((int64_t)P * kp > LK_MAXE || nr / P < 4 * kp) return false;
+    if (candidate_tiers(d, kp, nr / P, tiers) == 0) return false;
+    int32_t* rows = ws.lk_rows.reserve((size_t)nr);
+    int32_t* sub = ws.lk_idx.reserve((size_t)P * nq * kp);
+    hipLaunchKernelGGL(lk_partition_rows, dim3(cdiv(nr, 256)), dim3(256), 0, stream, ref_rows, nr, P, rows);
+    BMX_LAUNCH_CHECK();
+    const int base = nr / P, rem = nr % P;
+    for (int p = 0; p < P; ++p) {
+        const int n_p = base + (p < rem ? 1 : 0);
+        const int nt = candidate_tiers(d, kp, n_p, tiers);
+        search_tiers(stream, ws, tiers, nt, 0, X, rows + (int64_t)p * base + std::min(p, rem), n_p, Qs, qrs, nq, d, kp,
+                     sub + (int64_t)p * nq * kp, nullptr, nullptr, centre, nullptr);
+    }
+    int32_t* flagged = ws.flagged_t[0].reserve((size_t)nq + 1);
+    int32_t* opt = ws.optimistic ? ws.opt_state_ptr(stream) : nullptr;
+    if (!opt) BMX_HIP(hipMemsetAsync(flagged, 0, sizeof(int32_t), stream));
+    if (P * kp <= 512)
+        hipLaunchKernelGGL(lk_merge_wave, dim3(cdiv(nq, 4)), dim3(256), 0, stream, X, (const int32_t*)rows, nr, P, kp, Qs, qrs, nq,
+                           d, k, (const int32_t*)sub, io, dout, flagged, opt);
+    else
+        hipLaunchKernelGGL(lk_merge, dim3(nq), dim3(256), 0, stream, X, (const int32_t*)rows, nr, P, kp, Qs, qrs, nq, d, k,
+                           (const int32_t*)sub, io, dout, flagged, opt);
+    BMX_LAUNCH_CHECK();
+    if (!opt) {
+        const int count = read_count(stream, ws, flagged);
+        if (count > 0) exact_search(stream, ws, X, ref_rows, nr, Qs, qrs, d, k, io, dout, flagged, nullptr, count);
+    }
+    return true;
+}
+
 }  // namespace
 
 void knn_device(hipStream_t stream, KnnWorkspace& ws, const double* X, const int32_t* ref_rows, int nr,
@@ -1218,6 +1428,13 @@ void knn_device(hipStream_t stream, KnnWorkspace& ws, const double* X, const int
     if (kth_out && ntiers == 0) {  // no candidate tier takes the shape: every row read by the probe
         hipLaunchKernelGGL(fill_f64, dim3(cdiv(nq, 256)), dim3(256), 0, stream, kth_out + q_begin, nq, __builtin_inf());
         BMX_LAUNCH_CHECK();
+    }
+    // (k beyond the tiers' lists: P partitions of the reference at k = 36 each, merged exactly; a seeded search goes unseeded --
+    // the full k nearest serve its caller just as well)
+    if (ntiers == 0 && !ws.force_exact && k > 36 && dev_knobs().knn_tier != 3 &&
+        large_k_search(stream, ws, X, ref_rows, nr, Qs, qrs, nq, d, k, io, dout, centre)) {
+        ws.exact_total += ws.last_exact;
+        return;
     }
     search_tiers(stream, ws, tiers, ntiers, 0, X, ref_rows, nr, Qs, qrs, nq, d, k, io, dout,
                  seed_d2 ? seed_d2 + q_begin : nullptr, centre, kth_out ? kth_out + q_begin : nullptr);

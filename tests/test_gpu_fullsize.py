@@ -94,3 +94,28 @@ def test_full_size_engine_properties(data):
     assert after < 0.5 * before
     lost = np.asarray(a.merge_info.lost_var)
     assert lost.shape == (1, 2) and np.all(lost >= -1e-12) and np.all(lost < 0.5)
+
+
+@pytest.mark.parametrize("k", [50, 100])
+def test_full_size_knn_beyond_the_tiers_lists(oracle, data, k):
+    """k > 36 at BASELINE config 2's size (`prop.k` = 0.001 of 100 000 cells is k = 100, R/MNN_tree.R:140-146): the partitioned
+    search of knn.hip (large_k_search) on the matrix cores instead of the FP64 scan -- 600 sampled queries against the
+    oracle's brute force over the FULL reference, indices and distances bitwise."""
+    from batchelor_amd import neighbors as nb
+    L, R = data
+    idx, dist = nb.query_knn(R, L, k)
+    assert nb.last_knn_exact_fallbacks() <= 2000
+    rows = np.sort(np.random.default_rng(50 + k).choice(N, 600, replace=False))
+    oi, od = oracle.query_knn(R, L[rows], k)
+    assert np.array_equal(idx[rows], oi) and np.array_equal(dist[rows], od)
+    assert np.all(np.diff(dist, axis=1) >= 0)
+
+
+def test_full_size_prop_k_run(data):
+    # reducedMNN(prop.k = 0.0005) on 2 x 100 000 cells: k = max(20, round(50)) = 50 for every search of the merge
+    import batchelor_amd as bx
+    a = bx.reducedMNN(*data, k=K, prop_k=0.0005)
+    b = bx.reducedMNN(*data, k=50)
+    assert np.array_equal(a.corrected, b.corrected)
+    assert np.array_equal(a.merge_info.pairs[0][0], b.merge_info.pairs[0][0])
+    assert a.merge_info.pairs[0][0].size > 1_000_000

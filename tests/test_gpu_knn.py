@@ -58,11 +58,34 @@ def test_query_knn_small_and_edge_shapes(oracle, nb):
     assert idx.shape == (0, 3)
 
 
-def test_query_knn_large_k_uses_exact_scan(oracle, nb):
-    X, Q = synth_batches(4, [400, 100], 10)
+@pytest.mark.parametrize("nx,nq,d,k", [(20000, 3000, 50, 37), (20000, 3000, 50, 50), (20000, 3000, 50, 100),
+                                       (30000, 2000, 100, 64), (9000, 1500, 20, 120), (2500, 400, 50, 50)])
+def test_query_knn_beyond_the_tiers_lists(oracle, nb, nx, nq, d, k):
+    """k > 36 (`prop.k`, R/MNN_tree.R:140-146; k = 50 is an everyday setting): the reference is dealt into ceil(k / 16) strided
+    partitions, each searched at k = 36 on the matrix cores, the candidates merged exactly with a certificate that no
+    partition's list ends inside the first k (knn.hip: large_k_search).  Same bar as everywhere: indices equal, distances
+    bitwise.  (The last shape is too small for partitions of 144 cells: it takes the FP64 scan, as k > 36 did before.)"""
+    X, Q = synth_batches(1, [nx, nq], d)
+    idx, dist = nb.query_knn(X, Q, k)
+    oi, od = oracle.query_knn(X, Q, k)
+    assert np.array_equal(idx, oi)
+    assert np.array_equal(dist, od)
+    if nx >= 9000:
+        assert nb.last_knn_exact_fallbacks() <= nq // 20        # (queries that went to the FP64 scan)
+
+
+def test_query_knn_beyond_the_tiers_lists_clustered(oracle, nb):
+    # a reference whose ORDER follows its geometry (cells sorted by cluster): the strided deal keeps every partition a fair
+    # sample of every cluster; with contiguous partitions a query's neighbours would all sit in one
+    rng = np.random.default_rng(77)
+    centres = rng.standard_normal((40, 30)) * 4.0
+    X = np.concatenate([c + 0.3 * rng.standard_normal((500, 30)) for c in centres])
+    Q = centres[rng.integers(0, 40, 1000)] + 0.3 * rng.standard_normal((1000, 30))
     idx, dist = nb.query_knn(X, Q, 80)
     oi, od = oracle.query_knn(X, Q, 80)
     assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+    # (500 cells 0.3 apart in 30 dimensions are near-ties for the fp16 pass whatever k is: many of these queries are finished
+    # by the bounded FP64 sweep inside their partitions' searches -- the point here is the merge)
 
 
 def test_query_knn_near_ties_take_the_bounded_exact_path(oracle, nb):
