@@ -439,6 +439,30 @@ int32_t bmx_total_variance(const double* data, int32_t n, int32_t d, double* out
 }
 
 
+// HIP-event time of the kernels of the last native (.Call-level) call on this thread: bench.py's roofline of
+// smooth_gaussian_kernel / adjust_shift_variance is taken over this, not over the call with its host transfers
+static thread_local double g_last_native_ms = 0.0;
+struct NativeTimer {
+    hipStream_t s;
+    hipEvent_t a = nullptr, b = nullptr;
+    explicit NativeTimer(hipStream_t stream) : s(stream) {
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) a = b = nullptr;
+        if (a) (void)hipEventRecord(a, s);
+    }
+    void stop() {
+        if (b) (void)hipEventRecord(b, s);
+    }
+    void read() {  // (after the stream has been waited for)
+        float ms = 0.f;
+        if (a && b && hipEventElapsedTime(&ms, a, b) == hipSuccess) g_last_native_ms = ms;
+    }
+    ~NativeTimer() {
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+    }
+};
+double bmx_last_native_kernel_ms(void) { return g_last_native_ms; }
+
 int32_t bmx_smooth_gaussian_kernel(const double* averaged, int32_t g, int32_t U, const int32_t* index,
                                    int32_t index_len, const double* mat, int32_t gd, int32_t n, double sigma2,
                                    double* out) {
@@ -459,9 +483,12 @@ int32_t bmx_smooth_gaussian_kernel(const double* averaged, int32_t g, int32_t U,
         const int32_t* pi = upload(dI, index, (size_t)U, s);
         double* po = dO.reserve((size_t)g * n);
         double* pd = dD.reserve((size_t)n + (size_t)std::max(1, U));  // squared norms + densities
+        NativeTimer timer(s);
         bmx::smooth_gaussian_kernel_device(s, pa, g, U, pi, pm, gd, n, sigma2, po, pd);
+        timer.stop();
         BMX_HIP(hipMemcpyAsync(out, po, (size_t)g * n * sizeof(double), hipMemcpyDeviceToHost, s));
         BMX_HIP(hipStreamSynchronize(s));
+        timer.read();
     });
 }
 
@@ -495,9 +522,12 @@ int32_t bmx_adjust_shift_variance(const double* data1, int32_t g1, int32_t n1, c
         double* po = dO.reserve(n2);
         const bmx::AsvPlan plan = bmx::adjust_shift_variance_plan(g, n2, nr1, nr2, 0);
         double* pw = dW.reserve(plan.main_doubles + plan.extra_doubles);
+        NativeTimer timer(s);
         bmx::adjust_shift_variance_device(s, p1, g, n1, p2, n2, pv, sigma2, q1, nr1, q2, nr2, po, pw, plan);
+        timer.stop();
         BMX_HIP(hipMemcpyAsync(out, po, (size_t)n2 * sizeof(double), hipMemcpyDeviceToHost, s));
         BMX_HIP(hipStreamSynchronize(s));
+        timer.read();
     });
 }
 

@@ -1197,7 +1197,7 @@ void search_tiers(hipStream_t stream, KnnWorkspace& ws, const Tier* tiers, int n
 // The reference is dealt into P strided partitions (row j of the list goes to partition j mod P: independent of how the
 // caller ordered its cells), every partition is searched for its 36 (or 20) nearest with the whole certified cascade above, and
 // the P x 36 candidates of a query are merged exactly: squared distances recomputed in the reference's order of operations
-// (sum over the dimensions of (q - x)^2, no contraction), sorted by (distance, position) -- the oracle's order --, the first
+// (sum over the dimensions of (q - x)^2, no contraction), sorted by (distance, position) -- the exact search's own order --, the first
 // k are the answer PROVIDED no partition's list ends inside them: a partition whose 36th neighbour ranks behind the k-th
 // merged candidate cannot hold anything nearer that it did not list.  With P = ceil(k / 16) a partition holds 16 of the k
 // on average; a query for which one holds more than 35 fails the test and goes to the exact scan.

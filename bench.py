@@ -112,12 +112,42 @@ def streaming_bytes(stats, d, k):
     return tot
 
 
+def host_fp64_peak_gflops():
+    """The host's FP64 peak as cores x flops per cycle x clock, from what /proc and /sys say (stated, not measured): physical
+    cores = distinct (physical id, core id) pairs; 32 flops per cycle and core with AVX-512 (two 512-bit FMA pipes), else 16;
+    clock = cpuinfo_max_freq, else the largest current 'cpu MHz'."""
+    try:
+        cores, flags, mhz = set(), "", 0.0
+        phys = core = None
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("physical id"):
+                    phys = ln.split(":")[1].strip()
+                elif ln.startswith("core id"):
+                    core = ln.split(":")[1].strip()
+                    cores.add((phys, core))
+                elif ln.startswith("flags") and not flags:
+                    flags = ln
+                elif ln.startswith("cpu MHz"):
+                    mhz = max(mhz, float(ln.split(":")[1]))
+        try:
+            with open("/sys/devices/system/cpu/cpu0/cpufreq/cpuinfo_max_freq") as f:
+                mhz = float(f.read()) / 1e3
+        except OSError:
+            pass
+        ncores = len(cores) or (os.cpu_count() or 1)
+        per = 32 if " avx512f" in flags else 16
+        return ncores * per * mhz / 1e3, f"{ncores} physical cores x {per} FP64 flops/cycle x {mhz / 1e3:.2f} GHz"
+    except Exception as exc:  # noqa: BLE001
+        return None, f"unknown ({exc})"
+
+
 def cpu_baselines(batches, stats, d, k):
     """The reference R/Rcpp path cannot run on this box (no R), so two CPU statements of its dominant step -- the
     exact kNN searches, > 98 % of the CPU time -- are timed on a bounded sample of the same workload and extrapolated by
     pair evaluations to the whole job (oracle/cpu_baselines.py):
       A  one thread, pruned exact search in the manner of KmknnParam() / SerialParam(), fastMNN()'s defaults;
-      B  all host cores, blocked brute force on the host BLAS;
+      B  all host threads, blocked brute force on the host BLAS with a fused running-threshold filter;
       C  all host cores, the oracle's OpenMP brute force (no BLAS).
     Returns (main, variants): main = the faster one in the contract's cpu_baseline form."""
     from oracle import cpu_baselines as cb
@@ -153,9 +183,13 @@ def cpu_baselines(batches, stats, d, k):
     dt = time.perf_counter() - t0
     rate_b = nq_b * L.shape[0] / dt
     whole_b = "one whole block of the job" if nq_b == R.shape[0] else "a sample of the block"
+    peak_gf, peak_how = host_fp64_peak_gflops()
     out["B"] = {"value": n_cells / (total_pairs / rate_b), "unit": "cells/s", "cores": info_b["workers"], "kind": "port",
                 "gflops": rate_b * flop_per_pair / 1e9,
-                "sample": (f"blocked brute force on the host BLAS ({info_b['blas']}; FP64 DGEMM + argpartition + exact "
+                "host_fp64_peak_gflops": peak_gf, "host_fp64_peak_how": peak_how,
+                "frac_of_host_fp64_peak": (rate_b * flop_per_pair / 1e9 / peak_gf) if peak_gf else None,
+                "sample": (f"blocked brute force on the host BLAS ({info_b['blas']}; FP64 DGEMM tiles of 256 queries x 4096 "
+                           f"reference cells with a fused running-threshold filter + exact "
                            f"re-evaluation of the kept), {info_b['workers']} worker threads x {info_b['blas_threads_per_worker']} "
                            f"BLAS thread(s) of {cores} host threads: {whole_b}, {nq_b} queries x {L.shape[0]} reference cells in "
                            f"{dt:.1f} s ({rate_b:.3g} pair evaluations/s = {rate_b * flop_per_pair / 1e9:.0f} GFLOP/s); scaled by "
@@ -310,6 +344,10 @@ def run_sgk(args):
     t0 = time.perf_counter()
     out = nat.smooth_gaussian_kernel(averaged, index, mat, s2)
     dt = time.perf_counter() - t0
+    import ctypes
+    from batchelor_amd import _lib as _bl
+    _bl.lib().bmx_last_native_kernel_ms.restype = ctypes.c_double
+    kern_ms = float(_bl.lib().bmx_last_native_kernel_ms())
     cells = rng.choice(n, 64, replace=False)
     m = mat[:, index]
     d_mm = ((m[:, :, None] - m[:, None, :]) ** 2).sum(axis=0) if U <= 2000 else None
@@ -329,6 +367,14 @@ def run_sgk(args):
                       "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64 MFMA",
                       "data": "synthetic", "config": {"workload": f"sgk: n={n} cells, U={U} MNN cells, {gd} dims, sigma2={s2}",
                                                       "max_rel_err_vs_dense_spec_on_64_cells": err},
+                      # src/smooth_gaussian_kernel.cpp:36-98 in GEMM form: the distance products of every (MNN cell, cell)
+                      # and (MNN cell, MNN cell) pair + the weighted sum of the averaged vectors, 2 flops per multiply-add;
+                      # peak: the FP64 matrix rate of the MI355X data sheet (not in the in-container guide)
+                      "roofline": {"bound": "mfma", "kernel": "sgk_flash<true> (+ sgk_flash<false>, row_norms2)",
+                                   "achieved": flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else None, "peak": 78.6,
+                                   "unit": "TFLOP/s", "frac": flops / (kern_ms * 1e-3) / 1e12 / 78.6 if kern_ms > 0 else None,
+                                   "kernel_ms": kern_ms, "traffic": None,
+                                   "peak_note": "FP64 matrix peak from AMD's MI355X data sheet; not in the in-container guide"},
                       "algorithmic_flops": flops}), flush=True)
     assert err < 1e-9, err
 

@@ -106,6 +106,9 @@ int32_t bmx_dev_set(const char* name, int32_t value);
  * "asv_fallback_cells" (ill-conditioned cells with too many significant pairs for the re-run: histogram quantile, may pick a
  * neighbouring quantile), "asv_tally_reset" (zeroes them).  Waits for the device. */
 int32_t bmx_dev_get(const char* name, int64_t* value);
+/* HIP-event milliseconds of the device kernels of this thread's last bmx_smooth_gaussian_kernel / bmx_adjust_shift_variance
+ * call (the host transfers of the call excluded): what bench.py's roofline of the two legacy natives is taken over. */
+double bmx_last_native_kernel_ms(void);
 /* Testing hook, needs no GPU: dst[0, bytes) = src[0, bytes) by the pool of host threads that moves the boundary's
  * matrices between the caller's memory and the pinned staging buffers (csrc/host_xfer.hpp) -- lets a CPU test hammer that
  * pool from several threads at once. */

@@ -5,11 +5,11 @@ its dominant step, the exact kNN inside findMutualNN (R/MNN_tree.R:129) and quer
 
 A. `kmknn_knn`: ONE thread, pruned exact search in the manner of BiocNeighbors::KmknnParam() -- what fastMNN() runs by
    default (BNPARAM=KmknnParam(), BPPARAM=SerialParam(): R/fastMNN.R:287).  oracle/kmknn_baseline.c.
-B. `blas_knn`: ALL cores, blocked brute force on the host BLAS: |q|^2 + |r|^2 - 2 q.r by DGEMM blocks, argpartition,
-   exact re-evaluation of the k kept -- the strongest simple CPU formulation of the same search.  The selection
-   (argpartition) is single-threaded in numpy and costs more than the DGEMM, so the parallelism is over QUERY BLOCKS: a
-   pool of worker threads, each running its blocks with the BLAS pinned to one thread (threadpoolctl); both numbers are
-   reported.
+B. `blas_knn`: ALL host threads, blocked brute force on the host BLAS: |r|^2 - 2 q.r by DGEMM tiles of 256 queries x 4 096
+   reference cells with a fused running-threshold filter (a query's current (k + 8)-th best: only values below it leave the
+   tile; round 4's argpartition over 100 000-wide rows cost more than the DGEMM), exact re-evaluation of the kept -- the
+   strongest simple CPU formulation of the same search.  The parallelism is over QUERY BLOCKS: a pool of worker threads, one
+   per host thread, each running its blocks with the BLAS pinned to one thread (threadpoolctl).
 """
 from __future__ import annotations
 
@@ -69,7 +69,54 @@ def _blas_block(X, rn, q, k, keep):
     return part[rows, order], np.sqrt(d2[rows, order])
 
 
-def blas_knn(X, Q, k, block=256, workers=None):
+def _blas_block_filtered(X, rn, q, k, keep, chunk):
+    """One query block against the reference in chunks of `chunk` rows with a RUNNING THRESHOLD per query: the first chunk is
+    partitioned, every later chunk only hands over the values below the query's current keep-th best (a fused filter on the
+    DGEMM tile, k log(n / chunk) insertions per query in all) -- no argpartition over n-wide rows."""
+    nq, n = q.shape[0], X.shape[0]
+    c1 = min(chunk, n)
+    v = rn[None, :c1] - 2.0 * (q @ X[:c1].T)
+    kk = min(keep, c1)
+    part = np.argpartition(v, kk - 1, axis=1)[:, :kk]
+    rows = np.arange(nq)[:, None]
+    best_v = np.full((nq, keep), np.inf)
+    best_i = np.zeros((nq, keep), dtype=np.int64)
+    best_v[:, :kk] = v[rows, part]
+    best_i[:, :kk] = part
+    thr = best_v.max(axis=1)
+    for c0 in range(c1, n, chunk):
+        c2 = min(c0 + chunk, n)
+        v = rn[None, c0:c2] - 2.0 * (q @ X[c0:c2].T)
+        hr, hc = np.nonzero(v < thr[:, None])
+        if hr.size == 0:
+            continue
+        # the rows with a hit: their kept values and this chunk's hits side by side, keep the `keep` smallest
+        ur, start = np.unique(hr, return_index=True)           # (nonzero returns row-major order: hits of a row are contiguous)
+        cnt = np.diff(np.append(start, hr.size))
+        width = int(cnt.max())
+        slot = np.arange(hr.size) - np.repeat(start, cnt)
+        hv = np.full((ur.size, width), np.inf)
+        hi = np.zeros((ur.size, width), dtype=np.int64)
+        rpos = np.repeat(np.arange(ur.size), cnt)
+        hv[rpos, slot] = v[hr, hc]
+        hi[rpos, slot] = hc + c0
+        mv = np.concatenate([best_v[ur], hv], axis=1)
+        mi = np.concatenate([best_i[ur], hi], axis=1)
+        sel = np.argpartition(mv, keep - 1, axis=1)[:, :keep]
+        rr = np.arange(ur.size)[:, None]
+        best_v[ur] = mv[rr, sel]
+        best_i[ur] = mi[rr, sel]
+        thr[ur] = best_v[ur].max(axis=1)
+    valid = np.isfinite(best_v)
+    part = np.where(valid, best_i, 0)
+    diff = X[part] - q[:, None, :]
+    d2 = np.einsum("ijk,ijk->ij", diff, diff)
+    d2 = np.where(valid, d2, np.inf)
+    order = np.lexsort((part, d2), axis=1)[:, :k]
+    return part[rows, order], np.sqrt(d2[rows, order])
+
+
+def blas_knn(X, Q, k, block=256, workers=None, chunk=4096):
     """Exact kNN on the host BLAS.  `workers` threads each take query blocks of `block` rows with the BLAS limited to one
     thread per worker (numpy releases the GIL in the DGEMM, the partition and the gathers).  Returns (idx 1-based, dist,
     info) with info = {"workers", "blas_threads_per_worker", "blas"}."""
@@ -84,7 +131,8 @@ def blas_knn(X, Q, k, block=256, workers=None):
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     if workers is None:
         # a block holds block x n doubles twice (values + the partition's indices): bound the pool by ~32 GB of them
-        workers = max(1, min(cores, 64, int(32e9 // max(1, 2 * block * X.shape[0] * 8))))
+        # (all host threads: a worker holds a block x chunk tile of values, not block x n)
+        workers = max(1, cores if chunk and X.shape[0] > 2 * chunk else min(cores, 64, int(32e9 // max(1, 2 * block * X.shape[0] * 8))))
     info = {"workers": workers, "blas_threads_per_worker": 1, "blas": "numpy default"}
     try:
         from threadpoolctl import threadpool_info, threadpool_limits
@@ -97,7 +145,10 @@ def blas_knn(X, Q, k, block=256, workers=None):
     starts = list(range(0, nq, block))
 
     def work(b0):
-        i, dd = _blas_block(X, rn, Q[b0:b0 + block], k, keep)
+        if chunk and X.shape[0] > 2 * chunk:
+            i, dd = _blas_block_filtered(X, rn, Q[b0:b0 + block], k, keep, chunk)
+        else:
+            i, dd = _blas_block(X, rn, Q[b0:b0 + block], k, keep)
         idx[b0:b0 + block] = i
         dist[b0:b0 + block] = dd
 
