@@ -67,6 +67,13 @@ def dev_get(name):
     return int(v.value)
 
 
+def dev_get_bytes(name, n):
+    """Testing hook (bmx_dev_get_bytes): e.g. "asv_modes" after dev_set("asv_modes", n)."""
+    out = np.zeros(int(n), dtype=np.uint8)
+    check(lib().bmx_dev_get_bytes(name.encode(), out.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(int(n))))
+    return out
+
+
 def device_count():
     return int(lib().bmx_device_count())
 

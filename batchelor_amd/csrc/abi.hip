@@ -166,6 +166,7 @@ int32_t bmx_dev_set(const char* name, int32_t value) {
     else if (n == "asv_fast") k.asv_fast = value;
     else if (n == "asv_cap") k.asv_cap = value;
     else if (n == "sample_split") k.sample_split = value;
+    else if (n == "asv_modes") k.asv_modes = value;
     else if (n == "exchange_always") k.exchange_always = value;
     else if (n == "refine_wave") k.refine_wave = value;
     else if (n == "reset") k = bmx::DevKnobs();
@@ -190,6 +191,14 @@ int32_t bmx_dev_get(const char* name, int64_t* value) {
         } else {
             throw bmx::Error(BMX_ERR_ARG, "bmx_dev_get: unknown counter '" + n + "'");
         }
+    });
+}
+
+int32_t bmx_dev_get_bytes(const char* name, void* dst, int64_t n) {
+    if (!name || (n > 0 && !dst) || n < 0) return BMX_ERR_ARG;
+    return guarded([&] {
+        if (std::string(name) != "asv_modes") throw bmx::Error(BMX_ERR_ARG, std::string("bmx_dev_get_bytes: unknown array '") + name + "'");
+        bmx::asv_modes_read(static_cast<unsigned char*>(dst), (size_t)n);
     });
 }
 

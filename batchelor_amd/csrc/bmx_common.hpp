@@ -56,6 +56,7 @@ struct DevKnobs {
     int no_margin = 0;        // fp16 tier: lists cut at their KS-th best only (round 2's rule)
     int asv_fast = 0;         // adjust_shift_variance: the tiled form whatever the size
     int asv_cap = -1;         // tiled form: kept addends per chain of the literal re-run (-1: default, 0: no re-run)
+    int asv_modes = 0;        // tiled form: record which way each of the first n cells of a call went (bmx_dev_get_bytes)
     int sample_split = 0;     // ranges of the threshold sample of a search with few query blocks (0: never -- measured: no gain; -1: automatic)
     int exchange_always = 0;  // a single rank goes through its exchange transport too (an all-gather of one)
     int refine_wave = 0;      // the exact re-rank takes a whole wave for every query (no half-wave form)

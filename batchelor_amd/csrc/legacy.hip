@@ -400,7 +400,9 @@ __host__ __device__ inline size_t asv_tile_npad(size_t N) {
 }
 // addends a chain of the literal re-run may keep (its sort buffer and two 16 KB bin arrays must fit the LDS beside the tile)
 // (a power of two: the lists are padded to one for the sorting networks)
-inline int asv_tile_lcap_default(int) { return 32768; }
+// (BASELINE config 5 at full size, sigma 0.1: 7 % of the root merge's cells keep more than 32 768 addends in a chain, 33 cells of
+// the whole tree more than 65 536, none more than 131 072 -- at 4 % of the step's time for the longer lists)
+inline int asv_tile_lcap_default(int) { return 131072; }
 // ... of which this many are sorted in the LDS (beside the tile); longer lists are sorted where they lie, in global memory
 __host__ __device__ inline int asv_tile_lsort(int g) { return g <= 128 ? 4096 : 2048; }
 // doubles of the kernel's multi-purpose LDS region (see there)
@@ -1129,6 +1131,7 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
             const double prob2 = sc_mx2[c];  // (taken online by the stream, see above)
             double ref_quan = __builtin_nan("");
             bool literal = false;
+            int cell_mode = 0;  // 0: the histogram way (not flagged), 1: re-run literally, 2: flagged, beyond the re-run
             if (nr1 > 0) {
                 const double mx = sc_mx1[c];
                 const double FIX = 1099511627776.0;  // 2^40
@@ -1478,6 +1481,7 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                         }
                     }
                     if (!literal) ++n_back;
+                    cell_mode = literal ? 1 : 2;
                 }
                 if (!literal)
                 for (int round = 0; round < 40; ++round) {
@@ -1588,6 +1592,9 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                 }
             }
             if (!literal && tid == 0) out[c0 + c] = (ref_quan - curproj) / l2;  // :160
+            // (testing hook "asv_modes": which way every cell went, one byte per cell behind the tallies)
+            if (tid == 0 && tally && (unsigned long long)(c0 + c) < tally[3])
+                reinterpret_cast<unsigned char*>(tally + 4)[c0 + c] = (unsigned char)cell_mode;
             __syncthreads();
         }
         // ---- the literal re-run's chains: one lane per chain, the reference's sequential sums (:96-109, :127-131), then
@@ -1678,16 +1685,46 @@ void smooth_gaussian_kernel_device(hipStream_t stream, const double* averaged, i
 // Counters of the tiled form, per device, for tests and bench.py (bmx_dev_get "asv_literal_cells" / "asv_fallback_cells" /
 // "asv_tiled_cells"): cells re-run literally, flagged cells that went the histogram way (more than lcap kept addends),
 // all cells the tiled form has handled.  Added up until "asv_tally_reset".
+// Testing hook "asv_modes" = n: the tiled form also records which way each of the first n cells of a call went (one byte
+// per cell behind the four tally words: 0 the histogram way, 1 re-run literally, 2 flagged but beyond the re-run); the LAST
+// call's bytes stay (bmx_dev_get_bytes "asv_modes").
 static unsigned long long* g_tally[64] = {};
+static size_t g_tally_modes[64] = {};
+static long long g_tally_cap_set[64] = {};  // what word 3 holds + 1 (0: unknown)
 unsigned long long* asv_tally_device() {
     int dev = 0;
     BMX_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return nullptr;
-    if (!g_tally[dev]) {
-        BMX_HIP(hipMalloc(reinterpret_cast<void**>(&g_tally[dev]), 4 * sizeof(unsigned long long)));
-        BMX_HIP(hipMemset(g_tally[dev], 0, 4 * sizeof(unsigned long long)));
+    const size_t want = (size_t)std::max(0, dev_knobs().asv_modes);
+    if (!g_tally[dev] || g_tally_modes[dev] < want) {
+        unsigned long long keep[4] = {0, 0, 0, 0};
+        if (g_tally[dev]) {
+            BMX_HIP(hipDeviceSynchronize());
+            BMX_HIP(hipMemcpy(keep, g_tally[dev], 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            (void)hipFree(g_tally[dev]);
+            g_tally[dev] = nullptr;
+        }
+        BMX_HIP(hipMalloc(reinterpret_cast<void**>(&g_tally[dev]), 4 * sizeof(unsigned long long) + want + 8));
+        BMX_HIP(hipMemset(g_tally[dev], 0, 4 * sizeof(unsigned long long) + want + 8));
+        BMX_HIP(hipMemcpy(g_tally[dev], keep, 3 * sizeof(unsigned long long), hipMemcpyHostToDevice));
+        g_tally_modes[dev] = want;
+        g_tally_cap_set[dev] = 0;
+    }
+    if (g_tally_cap_set[dev] != (long long)want + 1) {  // (only when the hook changes: a blocking copy otherwise never happens)
+        const unsigned long long cap = (unsigned long long)want;  // (0: no modes recorded)
+        BMX_HIP(hipMemcpy(g_tally[dev] + 3, &cap, sizeof(cap), hipMemcpyHostToDevice));
+        g_tally_cap_set[dev] = (long long)want + 1;
     }
     return g_tally[dev];
+}
+void asv_modes_read(unsigned char* dst, size_t n) {
+    unsigned long long* t = asv_tally_device();
+    int dev = 0;
+    BMX_HIP(hipGetDevice(&dev));
+    BMX_HIP(hipDeviceSynchronize());
+    const size_t have = std::min(n, g_tally_modes[dev]);
+    if (have) BMX_HIP(hipMemcpy(dst, t + 4, have, hipMemcpyDeviceToHost));
+    for (size_t i = have; i < n; ++i) dst[i] = 255;
 }
 void asv_tally_read(unsigned long long out[3], bool reset) {
     unsigned long long* t = asv_tally_device();
@@ -1695,7 +1732,7 @@ void asv_tally_read(unsigned long long out[3], bool reset) {
     if (!t) return;
     BMX_HIP(hipDeviceSynchronize());
     BMX_HIP(hipMemcpy(out, t, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    if (reset) BMX_HIP(hipMemset(t, 0, 4 * sizeof(unsigned long long)));
+    if (reset) BMX_HIP(hipMemset(t, 0, 3 * sizeof(unsigned long long)));
 }
 
 AsvPlan adjust_shift_variance_plan(int g, int n2, int nr1, int nr2, int vect_row_major) {

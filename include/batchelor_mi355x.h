@@ -106,6 +106,10 @@ int32_t bmx_dev_set(const char* name, int32_t value);
  * "asv_fallback_cells" (ill-conditioned cells with too many significant pairs for the re-run: histogram quantile, may pick a
  * neighbouring quantile), "asv_tally_reset" (zeroes them).  Waits for the device. */
 int32_t bmx_dev_get(const char* name, int64_t* value);
+/* "asv_modes" (after bmx_dev_set "asv_modes" = n): which way each of the first n cells of the LAST tiled adjust_shift_variance
+ * call went -- 0 the histogram quantile (a well-conditioned cell), 1 re-run in the reference's order of operations, 2
+ * ill-conditioned with more significant pairs than the re-run holds; 255 beyond what was recorded. */
+int32_t bmx_dev_get_bytes(const char* name, void* dst, int64_t n);
 /* HIP-event milliseconds of the device kernels of this thread's last bmx_smooth_gaussian_kernel / bmx_adjust_shift_variance
  * call (the host transfers of the call excluded): what bench.py's roofline of the two legacy natives is taken over. */
 double bmx_last_native_kernel_ms(void);

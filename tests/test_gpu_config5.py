@@ -160,7 +160,7 @@ def test_config5_scaled_tree_every_merge_adjustment_matches_oracle_on_its_inputs
     whole-tree equality with the oracle's own run is not a property any two implementations have there.  What IS checked, at
     every one of the 15 merges, tiled form: the merge's adjust_shift_variance on the engine's own inputs against the oracle's
     on the same inputs, every cell to 1e-8 (the re-run cells are bit-equal, the histogram-way cells carry the matrix cores'
-    projection).  Every chain of these merges keeps fewer addends than the re-run holds (32 768; at sigma 0.3 the root's
+    projection).  Every chain of these merges keeps fewer addends than the re-run holds (131 072; at sigma 0.3 the root's
     chains keep thousands of the 7 128 reference cells: sorted in global memory), so EVERY cell must be equal.  (A call whose
     ill-conditioned cells keep more -- sigma 0.3 at BASELINE config 5's full size: a tenth of 2.5 million reference cells per
     chain -- sends those cells the histogram way; tests/test_gpu_primitives.py pins that path, DESIGN.md quantifies it.)"""
@@ -267,11 +267,16 @@ def test_full_size_config5_with_variance_adjustment(oracle, full5, sigma):
     eng.upload(B)
     eng.set_snapshot(14)
     _lib.dev_get("asv_tally_reset")
-    eng.run(k=k, merge_tree=resolve_merge_order(len(sizes), tree), var_adj=True, sigma=sigma)
-    out = eng.download()
-    tally = [_lib.dev_get(n) for n in ("asv_literal_cells", "asv_fallback_cells", "asv_tiled_cells")]
-    snap = eng.snapshot_var_adj()
-    eng.close()
+    _lib.dev_set("asv_modes", 400000)       # (testing hook: which way each cell of the LAST call -- the root merge's -- went)
+    try:
+        eng.run(k=k, merge_tree=resolve_merge_order(len(sizes), tree), var_adj=True, sigma=sigma)
+        out = eng.download()
+        tally = [_lib.dev_get(n) for n in ("asv_literal_cells", "asv_fallback_cells", "asv_tiled_cells")]
+        snap = eng.snapshot_var_adj()
+        modes = _lib.dev_get_bytes("asv_modes", snap["right"].shape[0])
+    finally:
+        _lib.dev_set("asv_modes", 0)
+        eng.close()
     assert np.all(np.isfinite(out.corrected)) and len(out.merge_info.pairs) == 15
     assert out.merge_info.left == plain.merge_info.left and out.merge_info.right == plain.merge_info.right
     leaf_merges = [m for m in range(15) if len(plain.merge_info.left[m]) == 1 and len(plain.merge_info.right[m]) == 1]
@@ -281,11 +286,21 @@ def test_full_size_config5_with_variance_adjustment(oracle, full5, sigma):
         assert np.array_equal(out.merge_info.pairs[m][1], plain.merge_info.pairs[m][1])
     assert not np.array_equal(out.corrected, plain.corrected)
     assert tally[2] > 0 and (sigma >= 1.0 or tally[0] > 0)     # (every call of the tree takes the tiled form at this size)
+    assert set(np.unique(modes).tolist()) <= {0, 1, 2}
     cells = np.sort(np.random.default_rng(514).choice(snap["right"].shape[0], 192, replace=False)).astype(np.int32)
-    share = _check_var_adj_snapshot(oracle, snap, sigma, cells=cells, bitwise=False)
+    got = snap["scaling"][cells]
+    ref = oracle.adjust_shift_variance(snap["left"].T, snap["right"].T, snap["correction"], sigma, snap["restrict1"],
+                                       snap["restrict2"], cells=cells)
+    close = np.isclose(got, ref, rtol=1e-8, atol=1e-12, equal_nan=True)
+    way = modes[cells]
     print(f"config 5 at full size, sigma {sigma}: tiled cells {tally[2]}, re-run literally {tally[0]}, flagged beyond the re-run "
-          f"{tally[1]}; root merge ({snap['left'].shape[0]} x {snap['right'].shape[0]} cells): {share:.4f} of 192 sampled "
-          f"cells equal to the oracle on the same inputs")
-    assert share >= 0.99, share
-
-
+          f"{tally[1]}; root merge ({snap['left'].shape[0]} x {snap['right'].shape[0]} cells): of its cells "
+          f"{(modes == 0).mean():.4f} took the histogram way unflagged, {(modes == 1).mean():.4f} the re-run, "
+          f"{(modes == 2).mean():.4f} were flagged beyond it; of 192 sampled cells {close.mean():.4f} equal the oracle on the same "
+          f"inputs ({close[way == 2].mean() if (way == 2).any() else float('nan'):.3f} of the {int((way == 2).sum())} beyond the re-run)")
+    # every sampled cell the re-run took is the oracle's bit for bit; every well-conditioned one to rounding; what parts is
+    # confined to the ill-conditioned cells with more significant pairs than the re-run holds (adjust_shift_variance)
+    assert np.array_equal(got[way == 1], ref[way == 1])
+    assert close[way != 2].all(), int((~close[way != 2]).sum())
+    assert close.mean() >= 0.99, close.mean()
+    assert (modes == 2).mean() < 0.01
