@@ -87,9 +87,13 @@ __global__ void row_norms2(const double* __restrict__ X, int64_t n, int gd, doub
 }
 
 constexpr int SG_KC = 32;    // distance genes staged per step
-constexpr int SG_GT = 128;   // output genes per workgroup
+// SG_GT: output genes per workgroup -- 64 where that covers all of them (the PC-space calls of the merge engine's world: half the
+// weighted-sum MFMAs of a 128-gene tile would multiply zeros, and two workgroups fit a CU: one's exp() under the other's
+// MFMAs), 128 for gene-space calls (every gene tile repeats the distance products)
 
-template <bool APPLY>
+// NKB > 0: the distance genes fit NKB steps of 32 and the cells' operands of all of them stay in registers for the whole
+// sweep over the MNN cells (staged once); NKB = 0: any number of genes, the cells' tile staged again with every MNN tile
+template <bool APPLY, int SG_GT, int NKB>
 __global__ __launch_bounds__(256) void sgk_flash(const double* __restrict__ X, int gd, const double* __restrict__ xn2,
                                                  const int32_t* __restrict__ cells, int64_t ncells,
                                                  const int32_t* __restrict__ index, int U, double inv_s2,
@@ -114,6 +118,21 @@ __global__ __launch_bounds__(256) void sgk_flash(const double* __restrict__ X, i
     for (int t = 0; t < (APPLY ? SG_GT / 16 : 1); ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
     const int lr = tid >> 2, seg = (tid & 3) * 8;
     const int64_t xrow = c0 + lr < ncells ? (cells ? cells[c0 + lr] : c0 + lr) : -1;
+    double bx[NKB > 0 ? NKB * 8 : 1];
+    if constexpr (NKB > 0) {
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = kb * SG_KC + seg + e;
+                xs[lr * P + seg + e] = (xrow >= 0 && k < gd) ? X[xrow * gd + k] : 0.0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < SG_KC / 4; ++kk) bx[kb * 8 + kk] = xs[cl * P + 4 * kk + (lane >> 4)];
+            __syncthreads();
+        }
+    }
     for (int i0 = 0; i0 < U; i0 += 64) {
         // ---- scores: S_t[reg] = m_i . x_c, i = i0 + 16 t + 4 reg + (lane >> 4), c = cl
         d4 S[4];
@@ -125,6 +144,26 @@ __global__ __launch_bounds__(256) void sgk_flash(const double* __restrict__ X, i
             mi2[tid] = r >= 0 ? xn2[r] : 0.0;
             di[tid] = (r >= 0 && dens) ? dens[i0 + tid] : 0.0;
         }
+        if constexpr (NKB > 0) {
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int k = kb * SG_KC + seg + e;
+                    ms[lr * P + seg + e] = (mrow >= 0 && k < gd) ? X[mrow * gd + k] : 0.0;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int kk = 0; kk < SG_KC / 4; ++kk) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const double a = ms[(16 * t + (lane & 15)) * P + 4 * kk + (lane >> 4)];
+                        S[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bx[kb * 8 + kk], S[t], 0, 0, 0);
+                    }
+                }
+                __syncthreads();
+            }
+        } else {
         for (int k0 = 0; k0 < gd; k0 += SG_KC) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -143,6 +182,7 @@ __global__ __launch_bounds__(256) void sgk_flash(const double* __restrict__ X, i
                 }
             }
             __syncthreads();
+        }
         }
         if constexpr (APPLY) {
             // stage the averaged vectors of this MNN tile: as_[i][gene]
@@ -1670,10 +1710,27 @@ void smooth_gaussian_kernel_device(hipStream_t stream, const double* averaged, i
     double* dens = ws + n;
     hipLaunchKernelGGL(row_norms2, dim3((unsigned)cdiv(n, 4)), dim3(256), 0, stream, mat, (int64_t)n, gd, xn2);
     // densities: the log-sum-exp of every MNN cell over the MNN cells (:56-65)
-    hipLaunchKernelGGL(sgk_flash<false>, dim3((unsigned)cdiv(U, 64), 1), dim3(256), 0, stream, mat, gd, xn2, index,
-                       (int64_t)U, index, U, 1.0 / sigma2, nullptr, nullptr, 0, nullptr, dens);
-    hipLaunchKernelGGL(sgk_flash<true>, dim3((unsigned)cdiv(n, 64), (unsigned)cdiv(g, SG_GT)), dim3(256), 0, stream, mat, gd,
-                       xn2, nullptr, (int64_t)n, index, U, 1.0 / sigma2, dens, averaged, g, out, nullptr);
+    const int nkb = gd <= 128 ? (gd + SG_KC - 1) / SG_KC : 0;
+#define BMX_SGK(NKB)                                                                                                              \
+    case NKB:                                                                                                                     \
+        hipLaunchKernelGGL((sgk_flash<false, 64, NKB>), dim3((unsigned)cdiv(U, 64), 1), dim3(256), 0, stream, mat, gd, xn2, index,  \
+                           (int64_t)U, index, U, 1.0 / sigma2, nullptr, nullptr, 0, nullptr, dens);                               \
+        if (g <= 64)                                                                                                              \
+            hipLaunchKernelGGL((sgk_flash<true, 64, NKB>), dim3((unsigned)cdiv(n, 64), 1), dim3(256), 0, stream, mat, gd, xn2,      \
+                               nullptr, (int64_t)n, index, U, 1.0 / sigma2, dens, averaged, g, out, nullptr);                     \
+        else                                                                                                                      \
+            hipLaunchKernelGGL((sgk_flash<true, 128, NKB>), dim3((unsigned)cdiv(n, 64), (unsigned)cdiv(g, 128)), dim3(256), 0,     \
+                               stream, mat, gd, xn2, nullptr, (int64_t)n, index, U, 1.0 / sigma2, dens, averaged, g, out, nullptr); \
+        break
+    switch (nkb) {
+        BMX_SGK(1);
+        BMX_SGK(2);
+        BMX_SGK(3);
+        BMX_SGK(4);
+        default:
+            BMX_SGK(0);
+    }
+#undef BMX_SGK
     BMX_LAUNCH_CHECK();
 }
 
