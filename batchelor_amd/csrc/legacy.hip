@@ -1182,10 +1182,15 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                 // Flagged: (i) the own batch's cumulative probability at the cell is 1 to within 1e-6, i.e. the walk over the
                 // reference batch runs to where all but 1e-6 of the weight has gone by -- and is decided by single addends of
                 // relative size <= 1e-6, far enough down for the rounding of the two summation orders to matter; (ii) it is below
-                // e^-12 (a cell that is not in its own batch's restrict vector can sit far below all the weight): the walk ends among
-                // addends the 2^-40 fixed-point weights of the histogram do not resolve.  (Cells in between cross on addends the
-                // histogram way resolves.)
+                // e^-12 (a cell that is not in its own batch's restrict vector can sit far below all the weight): the walk ends
+                // among addends the 2^-40 fixed-point weights of the histogram do not resolve.  (Cells in between cross on
+                // addends the histogram way resolves.)  How long a re-run a flagged cell is worth: within 1e-9 of 1 (or below
+                // e^-12) the walk IS a statement about rounding and the histogram way picks another quantile on most such cells:
+                // up to lcap addends per chain; between 1e-9 and 1e-6 the histogram way is right on all but a few cells of a
+                // small call (and on every sampled cell of config 5 at sigma 1), and a re-run of tens of thousands of addends for
+                // each of the 2.5 % of config 5's cells that sit there doubled the step: up to 8 192.
                 const bool flagged = lit_on && (-prob2 < 1e-6 || prob2 < -12.0);
+                const int lcap_c = (-prob2 < 1e-9 || prob2 < -12.0) ? lcap : (lcap < 8192 ? lcap : 8192);
                 const unsigned long long NEGBITS = 0xFFF0000000000000ull;  // -inf
                 // ---- the first histogram of the walk; for a flagged cell also every bin's largest log-weight and the number
                 // of reference cells within 38.5 of the largest one (all of those are kept addends)
@@ -1229,7 +1234,7 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                     }
                     const int cGtot = smi[0];
                     __syncthreads();
-                    if (cGtot <= lcap) {
+                    if (cGtot <= lcap_c) {
                         // ================= the literal re-run (see the comment in front of asv_noop_below) =================
                         const double cn_c = sc_n[c];
                         const double mb = 1e-3 + 1e-13 * (cn_c + nmax_s) / sigma2;      // >= the rounding of a GEMM-form log-weight
@@ -1299,7 +1304,7 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                                     for (int o2 = 1; o2 < 64; o2 <<= 1) r = fmax(r, __shfl_xor(r, o2));
                                     double* smx = sm + par * 8;
                                     if (lane == 0) smx[w] = r;
-                                    if (tid == 0) smx[4] = (sh_sel[1] > lcap || sh_sel[2] > lcap) ? 1.0 : 0.0;
+                                    if (tid == 0) smx[4] = (sh_sel[1] > lcap_c || sh_sel[2] > lcap_c) ? 1.0 : 0.0;
                                     __syncthreads();
                                     Mr = fmax(Mr, fmax(fmax(smx[0], smx[1]), fmax(smx[2], smx[3])));
                                     mT = NEG;
@@ -1321,7 +1326,7 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                                 });
                             __syncthreads();
                         }
-                        bool ok = sh_sel[1] <= lcap && sh_sel[2] <= lcap;
+                        bool ok = sh_sel[1] <= lcap_c && sh_sel[2] <= lcap_c;
                         // (d) the own batch: kept addends of totalprob2's and prob2's chains (one list: an addend that is a
                         // no-op for one of them is one in the re-run as well).  The cell's own first place in restrict2 (spos: the
                         // first code-3 element, found by the scan as it goes) splits the chains into their two regimes: elements in
@@ -1370,7 +1375,7 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                                         smx[w * 4 + 1] = r3;
                                         smx[w * 4 + 2] = (double)rs_;
                                     }
-                                    if (tid == 0) smx[16] = sh_sel[0] > lcap ? 1.0 : 0.0;
+                                    if (tid == 0) smx[16] = sh_sel[0] > lcap_c ? 1.0 : 0.0;
                                     __syncthreads();
                                     double pTx = NEG, pPx = NEG, ps = 2147483647.0;
                                     for (int ww = 0; ww < 4; ++ww) {
@@ -1404,7 +1409,7 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                                     }
                                 });
                             __syncthreads();
-                            ok = sh_sel[0] <= lcap;
+                            ok = sh_sel[0] <= lcap_c;
                         }
                         if (ok) {
                             // (e) the kept addends, recomputed in the reference's order of operations
