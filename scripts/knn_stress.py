@@ -17,7 +17,7 @@ for case in range(cases):
     nx = int(rng.choice([64, 70, 130, 500, 2100, 4095, 4100, 9000, 20000, 33000, 70000]))
     nq = int(rng.choice([1, 31, 257, 900, 2500, 6000]))
     d = int(rng.integers(2, 126))
-    k = int(min(rng.choice([1, 5, 20, 21, 36]), nx))
+    k = int(min(rng.choice([1, 5, 20, 21, 36, 37, 50, 64, 100, 150]), nx))  # (beyond 36: the partitioned search of knn.hip)
     force_c = str(rng.choice(["", "1", "2", "3", "5", "7"]))
     sample = str(rng.choice(["", "", "0", "1024", "4096"]))
     _lib.dev_set("force_c", int(force_c) if force_c else 0)  # testing hooks of the library (bmx_dev_set)

@@ -90,4 +90,34 @@ for case in range(cases):
         assert np.array_equal(nat.adjust_shift_variance(data1, data2, cv, sig, r1, r2),
                               oracle.adjust_shift_variance(data1, data2, cv, sig, r1, r2))
     check("adjust_shift_variance", asv)
+
+    def asv_tiled():
+        # the form taken beyond 4e7 pairs (testing hook "asv_fast"): random shapes, bandwidths from 10 to 0.01 times the data's
+        # scale, restrict vectors with repeats and omissions; >= 0.999 of the cells to 1e-8, and bit for bit when every cell
+        # took the re-run
+        from batchelor_amd import _lib
+        _lib.dev_set("asv_fast", 1)
+        try:
+            m1, m2 = int(rng.choice([150, 700, 2500, 6000])), int(rng.choice([100, 500, 1500]))
+            g = int(rng.choice([3, 12, 25, 50, 100, 130]))
+            scale = float(rng.choice([0.1, 1.0]))
+            spec = 1.0 / np.sqrt(1.0 + np.arange(g) / 5.0)
+            data1 = (rng.standard_normal((m1, g)) * spec * scale).T
+            data2 = (rng.standard_normal((m2, g)) * spec * scale + 0.3 * scale).T
+            cv = rng.standard_normal((m2, g)) * 0.2 - 0.3
+            r1 = np.concatenate([rng.permutation(m1)[:max(5, (2 * m1) // 3)], rng.integers(0, m1, 7)])
+            r2 = np.concatenate([rng.permutation(m2)[:max(5, (2 * m2) // 3)], rng.integers(0, m2, 7)])
+            sig = float(rng.choice([10.0, 1.0, 0.5, 0.3, 0.1, 0.03, 0.01])) * scale * scale
+            _lib.dev_get("asv_tally_reset")
+            out = nat.adjust_shift_variance(data1, data2, cv, sig, r1, r2)
+            lit, back, tiled = (_lib.dev_get(n) for n in ("asv_literal_cells", "asv_fallback_cells", "asv_tiled_cells"))
+            ref = oracle.adjust_shift_variance(data1, data2, cv, sig, r1, r2)
+            close = np.isclose(out, ref, rtol=1e-8, atol=1e-12, equal_nan=True)
+            print("   asv tiled", m1, m2, g, sig, "literal", lit, "beyond", back, "of", tiled, "equal", round(float(close.mean()), 4), flush=True)
+            assert close.mean() >= 0.999, close.mean()
+            if lit == tiled:
+                assert np.array_equal(out, ref, equal_nan=True)
+        finally:
+            _lib.dev_set("asv_fast", 0)
+    check("adjust_shift_variance (tiled form)", asv_tiled)
 print("cases", cases, "mismatches", bad, flush=True)
