@@ -663,6 +663,16 @@ def main():
             # (MI355X_MICROARCH.md) lists no FP64 MFMA figure, so this one is NOT from it.
             from batchelor_amd import _lib as _bl
             a_tf = 4.0 * d * asv["asv_pairs"] / (asv["asv_ms"] * 1e-3) / 1e12
+            # HBM bytes per launch from the committed --pmc passes of this very command at sigma 1 (2 x FETCH_SIZE + WRITE_SIZE
+            # over the 15 launches of a step); another bandwidth runs other code paths: no number then
+            asv_traffic, asv_traffic_note = None, "profiles/r05_asv_tile_pmc.json holds the counters of the sigma = 1 run only"
+            if args.sigma == 1.0 and args.workload == "config5":
+                try:
+                    rec = json.load(open(os.path.join(ROOT, "profiles", "r05_asv_tile_pmc.json")))["all_launches_total"]
+                    asv_traffic = (rec["hbm_read_bytes"] + rec["hbm_write_bytes"]) / 15.0
+                    asv_traffic_note = "profiles/r05_asv_tile_pmc.json: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 over a step's 15 launches / 15"
+                except (OSError, ValueError, KeyError):
+                    pass
             line["metric"] = "cells/sec corrected (reducedMNN engine + adjust_shift_variance, 100 PCs)"
             line["dtype"] = "f64 (FP64 MFMA) for adjust_shift_variance; " + kern["dtype"] + " for the searches"
             line["config"]["var_adj_sigma"] = args.sigma
@@ -671,7 +681,7 @@ def main():
                 "bound": "mfma", "kernel": "asv_tile_kernel<13> (adjust_shift_variance, tiled FP64-MFMA form)",
                 "achieved": a_tf, "peak": 78.6, "unit": "TFLOP/s", "frac": a_tf / 78.6,
                 "peak_note": "FP64 matrix peak from AMD's MI355X data sheet; not in the in-container guide",
-                "traffic": None, "traffic_note": "profiles/r05_asv_tile_pmc.json (own rocprofv3 --pmc passes)",
+                "traffic": asv_traffic, "traffic_note": asv_traffic_note,
                 "launches_per_step": asv["asv_launches"] / max(1, args.steps),
                 "avg_launch_ms": asv["asv_ms"] / max(1, asv["asv_launches"]),
                 "pairs_per_step": asv["asv_pairs"] / max(1, args.steps),
