@@ -449,3 +449,20 @@ def test_cpu_baselines_are_exact(oracle):
     ib, db, _ = cb.blas_knn(X, Q, 12)
     assert np.array_equal(ib, oi)
     np.testing.assert_allclose(db, od, rtol=1e-12)
+
+
+def test_cpu_baseline_b_filtered_brute_force_is_an_exact_knn():
+    """bench.py's CPU baseline B (oracle/cpu_baselines.py: DGEMM tiles + a fused running-threshold filter + exact
+    re-evaluation of the kept) against the oracle's brute force: same neighbours in the same order, same distances to
+    rounding -- the number quoted as `cpu_baseline` is the time of a search that really is the reference's search."""
+    from oracle import cpu_baselines as cb
+    from oracle import fastmnn_oracle as orc
+    rng = np.random.default_rng(11)
+    X = rng.standard_normal((9000, 30)) / np.sqrt(1.0 + np.arange(30) / 5.0)
+    Q = rng.standard_normal((700, 30)) / np.sqrt(1.0 + np.arange(30) / 5.0) + 0.2
+    for chunk in (2048, 0):          # the filtered form (several chunks) and the one-partition form
+        idx, dist, info = cb.blas_knn(X, Q, 20, block=128, workers=2, chunk=chunk)
+        oi, od = orc.query_knn(X, Q, 20)
+        assert np.array_equal(idx, oi)
+        np.testing.assert_allclose(dist, od, rtol=1e-12)
+        assert info["workers"] == 2
