@@ -204,3 +204,12 @@ def test_optimistic_run_starts_over_when_a_search_cannot_be_completed_on_the_dev
         eng.close()
     ref = oracle.reduced_mnn(*B)
     assert_same_result(out, ref)
+
+
+def test_large_k_with_restriction_and_three_batches(oracle, bx):
+    # k = 50 (beyond the candidate tiers' lists: the partitioned search of knn.hip) through the whole engine, with a restrict
+    # vector on two of three batches (the searches then run over row LISTS) and prop.k on top
+    B = synth_batches(41, [5000, 4200, 3600], 50)
+    keep = [np.arange(1, 4001), None, np.arange(300, 3500)]
+    assert_same_result(bx.reducedMNN(*B, k=50, restrict=keep), oracle.reduced_mnn(*B, k=50, restrict=keep))
+    assert_same_result(bx.reducedMNN(*B, k=20, prop_k=0.02, restrict=keep), oracle.reduced_mnn(*B, k=20, prop_k=0.02, restrict=keep))

@@ -211,6 +211,32 @@ def test_adjust_shift_variance_tiled_form_edges(oracle, nat, dev, sigma):
     assert np.isnan(out[17]) and np.isnan(ref[17])                  # 0 / 0, as the reference (:160)
 
 
+@pytest.mark.parametrize("sigma", [1.0, 0.05])
+def test_adjust_shift_variance_tiled_form_tiny_and_empty(oracle, nat, dev, sigma):
+    # the tiled form's smallest inputs: an empty restrict2 (prob2 keeps its starting value 0, :76), one and three reference
+    # cells (all projections in one histogram bin), fewer cells than a tile, a single dimension, one cell against one cell
+    dev("asv_fast", 1)
+    rng = np.random.default_rng(100035)
+    for g, n1, n2, nr1, nr2 in [(7, 50, 20, 50, 0), (7, 50, 20, 1, 20), (7, 50, 20, 3, 5), (1, 40, 30, 40, 30),
+                                (100, 3, 2, 3, 2), (25, 1, 1, 1, 1), (50, 300, 17, 300, 17)]:
+        d1 = rng.standard_normal((g, n1)) * 0.5
+        d2 = rng.standard_normal((g, n2)) * 0.5 + 0.2
+        cv = rng.standard_normal((n2, g))
+        r1 = rng.permutation(n1)[:nr1]
+        r2 = rng.permutation(n2)[:nr2]
+        out = nat.adjust_shift_variance(d1, d2, cv, sigma, r1, r2)
+        ref = oracle.adjust_shift_variance(d1, d2, cv, sigma, r1, r2)
+        close = np.isclose(out, ref, rtol=1e-8, atol=1e-12, equal_nan=True)
+        if g == 1:
+            # one dimension: every cell lies ON every line, all weights are exactly 1 and the walk crosses where log(j) meets
+            # log(a / b) + log(n) for INTEGERS j, a, b, n -- an exact tie that the reference's floating-point chains settle by
+            # rounding and integer weights settle exactly: wherever n a / b is an integer (a sixth of the cells here) the two
+            # may land on neighbouring reference cells.  Not a property of continuous data, and outside the re-run's flag.
+            assert close.mean() >= 0.75, (close.mean(), out, ref)
+        else:
+            assert close.all(), (g, n1, n2, nr1, nr2, out, ref)
+
+
 def test_adjust_shift_variance_tiled_form_beyond_the_rerun(oracle, nat, dev):
     """What the tiled form does to an ill-conditioned cell that keeps more addends than the re-run holds (bandwidths of the
     order of the squared distances on a large call: sigma 0.3 .. 0.7 at BASELINE config 5's size): it goes the histogram
