@@ -1431,7 +1431,8 @@ void knn_device(hipStream_t stream, KnnWorkspace& ws, const double* X, const int
     }
     // (k beyond the tiers' lists: P partitions of the reference at k = 36 each, merged exactly; a seeded search goes unseeded --
     // the full k nearest serve its caller just as well)
-    if (ntiers == 0 && !ws.force_exact && k > 36 && dev_knobs().knn_tier != 3 &&
+    // (also k in (20, 36] where no tier holds lists that long: rows of more than 61 columns, BASELINE config 5's 100 PCs)
+    if (ntiers == 0 && !ws.force_exact && k > 20 && dev_knobs().knn_tier != 3 &&
         large_k_search(stream, ws, X, ref_rows, nr, Qs, qrs, nq, d, k, io, dout, centre)) {
         ws.exact_total += ws.last_exact;
         return;
