@@ -878,7 +878,9 @@ void Engine::merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p,
         // Several ranks (without var_adj): every rank has the neighbour lists of ITS slice of the right cells from the search;
         // it corrects those rows and the CORRECTED ROWS are all-gathered (n x d x 8 bytes) instead of the lists (n x k x 12):
         // the same order of bytes, and the apply is sharded with the search instead of being repeated on every rank.
-        const bool rows_sharded = !p.var_adj && (world_ > 1 || emu_mode_ == 1);
+        // (testing hook "exchange_always": a single rank with a transport takes this way too, an all-gather of one)
+        const bool rows_sharded = !p.var_adj && (world_ > 1 || emu_mode_ == 1 ||
+                                                 (dev_knobs().exchange_always != 0 && (comm_ || gather_fn_)));
         sec.reset();
         knn(right.data.p, srows, mo.U, right.data.p, nullptr, right.n, safe_k, idxT, distT, nullptr, mu_r, nullptr, !rows_sharded);
         sec = std::make_unique<Section>(this);  // streaming section 3: tricube apply, rbind

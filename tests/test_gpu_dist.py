@@ -171,7 +171,7 @@ eng.upload(B)
 eng.run()
 got = eng.download()
 st = eng.exchange_stats()
-assert st["calls"] == 2 * (2 + 2 + 2), st  # per merge: index + distance, index + k-th distance, tricube index + distance
+assert st["calls"] == 2 * (2 + 2 + 1), st  # per merge: index + distance, index + k-th distance, the tricube-corrected rows
 assert np.array_equal(got.corrected, ref.corrected)
 for (a, b), (c, d) in zip(got.merge_info.pairs, ref.merge_info.pairs):
     assert np.array_equal(a, c) and np.array_equal(b, d)
