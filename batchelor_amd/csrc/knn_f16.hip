@@ -353,6 +353,13 @@ __global__ __launch_bounds__((NCONS + NPROD + serv_waves(NS)) * 64) void knn_top
     int* wrL = done + NSLOT;    // [NCONS] records pushed so far (written by the consumer)
     int* rdL = wrL + NCONS;                            // [NCONS] records worked off so far (written by its service wave)
     int* stL = rdL + NCONS;  // [NCONS] consumer state: 0 sweeping, 1 waiting for room in its queue, 2 through
+#ifdef BMX_EXP_ROWFILTER
+    // timing experiment (EXPERIMENTS.md, round 5: what a SECOND, per-reference filter would cost the sweep -- the one sweep for
+    // both findMutualNN directions of DESIGN section 7): 32 per-row thresholds a tile, read by every consumer for every tile
+    // and held against all 16 accumulator registers; they stand at -inf, nothing ever passes
+    float* rtau = reinterpret_cast<float*>(stL + NCONS);  // [2][16] in the fixed area's spare bytes
+    if (threadIdx.x < 32) rtau[threadIdx.x] = -__builtin_inff();
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: branches on it are scalar
@@ -905,6 +912,11 @@ __global__ __launch_bounds__((NCONS + NPROD + serv_waves(NS)) * 64) void knn_top
 
     // ---- filter of one tile (products in `acc`, tile number t) and, where a value is below its query's threshold, the
     // spill.  Returns the lane minimum (SAMPLE uses nothing else).
+#ifdef BMX_EXP_ROWFILTER
+    f32x4 rt[4];
+    float rt0 = -__builtin_inff();
+    asm volatile("" : "+v"(rt0));
+#endif
     auto sift = [&](const f32x16& acc, const int t) __attribute__((always_inline)) {
         // group minima (4 consecutive references each), then the lane minimum.  Every fminf below is half of a
         // three-way minimum: the compiler forms v_min3_f32 from such pairs and, unlike for a lone v_min_f32, does not put
@@ -917,6 +929,23 @@ __global__ __launch_bounds__((NCONS + NPROD + serv_waves(NS)) * 64) void knn_top
             g[u] = fminf(fminf(m3, acc[4 * u + 3]), tau);
         }
         const float mn = fminf(fminf(fminf(fminf(g[0], g[1]), g[2]), g[3]), tau);
+#ifdef BMX_EXP_ROWFILTER
+        if constexpr (!SAMPLE) {
+            // register e of a lane holds row 8 (e / 4) + 4 (lane / 32) + (e % 4) of the tile: the lane half's 16 thresholds
+            // (rt[]: asked for at the top of the tile pair, like the fragments)
+            // (one subtraction per register, the minimum of the differences by v_min3, ONE compare: 16 v_cmp writing scalar
+            // masks OR-ed in a chain measured 2.3x the whole sweep)
+            float dm[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float a0 = acc[4 * u] - rt[u][0], a1 = acc[4 * u + 1] - rt[u][1], a2 = acc[4 * u + 2] - rt[u][2],
+                            a3 = acc[4 * u + 3] - rt[u][3];
+                dm[u] = fminf(fminf(fminf(a0, a1), a2), a3);
+            }
+            const unsigned long long hm = __builtin_amdgcn_ballot_w64(fminf(fminf(fminf(dm[0], dm[1]), dm[2]), dm[3]) < 0.f);
+            if (hm != 0) wr += 1;  // (never: the thresholds stand at -inf)
+        }
+#endif
         if constexpr (SAMPLE) {
             return mn;
         } else {
@@ -1030,6 +1059,23 @@ __global__ __launch_bounds__((NCONS + NPROD + serv_waves(NS)) * 64) void knn_top
         // check, the polls and the hand-back happen once per four tiles.
         auto tile_pair = [&](const lds_f4ptr tp, const int t0, const int hand_back_pos) __attribute__((always_inline)) {
             f32x16 accA, accB;
+#ifdef BMX_EXP_ROWFILTER
+            if constexpr (!SAMPLE) {
+#ifdef BMX_EXP_ROWFILTER_NOLDS
+                // (the arithmetic alone: thresholds from registers, made opaque to the optimiser once per tile pair)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    rt[u] = f32x4{rt0, rt0, rt0, rt0};
+                    asm volatile("" : "+v"(rt[u]));
+                }
+#else
+                typedef __attribute__((address_space(3))) volatile f32x4* lds_vf4;
+                lds_vf4 rp = (lds_vf4)(rtau + (lane >> 5) * 16);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) rt[u] = rp[u];
+#endif
+            }
+#endif
 #pragma unroll
             for (int e = 0; e < 16; ++e) accA[e] = accB[e] = 0.f;
             __builtin_amdgcn_sched_barrier(0);
