@@ -1,6 +1,8 @@
+"""Developer helper (GPU box): k in (20, 50] at 100 PCs -- rows too long for the tiers with lists of 48 -- through the partitioned
+search of knn.hip, a sample of the queries against the oracle.   python scripts/k30_d100_probe.py"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from batchelor_amd import neighbors as nb
 from tests.conftest import synth_batches
 from oracle import fastmnn_oracle as orc
