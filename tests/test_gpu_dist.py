@@ -186,3 +186,37 @@ print("rccl-engine-ok")
     env = dict(os.environ, BMX_ROOT=ROOT, BMX_PORT=str(port), PYTHONPATH=ROOT)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "rccl-engine-ok" in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
+
+
+def test_emulated_rank_of_n_equals_the_single_rank_run():
+    """bmx_engine_emulate (bench.py --emulate-world): one rank's share of an N-rank run on one GPU -- its slice of every search,
+    the other ranks' slices of every exchange replayed from a recorded single-rank run.  Whatever the rank and the world size,
+    the emulated rank must end with the recorded run's result bit for bit (else what bench.py times is not the job)."""
+    import batchelor_amd as bx
+    from tests.conftest import synth_batches
+    B = synth_batches(13, [3001, 2500, 1777], 50)
+    eng = bx.MnnEngine(0)
+    eng.upload(B)
+    eng.run()
+    base = eng.download()
+    with pytest.raises(bx.BatchelorMI355XError, match="more exchanges than the recorded run"):
+        eng.emulate(2, 1, 4)          # nothing recorded yet
+        eng.run()
+    eng.emulate(1)
+    eng.run()
+    for world, rank in [(2, 0), (2, 1), (3, 2), (4, 1), (8, 7)]:
+        eng.emulate(2, rank, world)
+        eng.run()
+        got = eng.download()
+        assert np.array_equal(got.corrected, base.corrected), (world, rank)
+        for (a, b), (c, d) in zip(got.merge_info.pairs, base.merge_info.pairs):
+            assert np.array_equal(a, c) and np.array_equal(b, d)
+        assert eng.exchange_stats()["calls"] == 2 * (3 + 3 + 2)   # (the same exchanges a real rank makes)
+    with pytest.raises(bx.BatchelorMI355XError, match="auto-merge"):
+        eng.run(auto_merge=True)
+    with pytest.raises(bx.BatchelorMI355XError, match="invalid rank"):
+        eng.emulate(2, 4, 4)
+    eng.emulate(0)
+    eng.run()
+    assert np.array_equal(eng.download().corrected, base.corrected)
+    eng.close()
