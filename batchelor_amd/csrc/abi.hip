@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <limits>
 #include <memory>
 #include <thread>
 #include <vector>
@@ -167,6 +168,7 @@ int32_t bmx_dev_set(const char* name, int32_t value) {
     else if (n == "asv_cap") k.asv_cap = value;
     else if (n == "sample_split") k.sample_split = value;
     else if (n == "asv_modes") k.asv_modes = value;
+    else if (n == "asv_sync") k.asv_sync = value;
     else if (n == "exchange_always") k.exchange_always = value;
     else if (n == "refine_wave") k.refine_wave = value;
     else if (n == "reset") k = bmx::DevKnobs();
@@ -185,6 +187,9 @@ int32_t bmx_dev_get(const char* name, int64_t* value) {
         if (n == "asv_literal_cells" || n == "asv_fallback_cells" || n == "asv_tiled_cells") {
             bmx::asv_tally_read(t, false);
             *value = (int64_t)t[n == "asv_literal_cells" ? 0 : (n == "asv_fallback_cells" ? 1 : 2)];
+        } else if (n == "asv_ticks_stream" || n == "asv_ticks_wait" || n == "asv_ticks_cells") {
+            bmx::asv_ticks_read(t);
+            *value = (int64_t)t[n == "asv_ticks_stream" ? 0 : (n == "asv_ticks_wait" ? 1 : 2)];
         } else if (n == "asv_tally_reset") {
             bmx::asv_tally_read(t, true);
             *value = 0;
@@ -451,12 +456,30 @@ int32_t bmx_total_variance(const double* data, int32_t n, int32_t d, double* out
 // HIP-event time of the kernels of the last native (.Call-level) call on this thread: bench.py's roofline of
 // smooth_gaussian_kernel / adjust_shift_variance is taken over this, not over the call with its host transfers
 static thread_local double g_last_native_ms = 0.0;
+// (one pair of events per host thread, made at the thread's first native call and kept: no create / destroy per call)
 struct NativeTimer {
     hipStream_t s;
     hipEvent_t a = nullptr, b = nullptr;
     explicit NativeTimer(hipStream_t stream) : s(stream) {
-        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) a = b = nullptr;
-        if (a) (void)hipEventRecord(a, s);
+        // a call that throws, or whose events cannot be made, must not leave the PREVIOUS call's time behind
+        g_last_native_ms = std::numeric_limits<double>::quiet_NaN();
+        static thread_local hipEvent_t ev[2] = {nullptr, nullptr};
+        if (!ev[0] || !ev[1]) {
+            for (hipEvent_t& e : ev) {
+                if (e) (void)hipEventDestroy(e);
+                e = nullptr;
+            }
+            if (hipEventCreate(&ev[0]) != hipSuccess) ev[0] = nullptr;
+            if (ev[0] && hipEventCreate(&ev[1]) != hipSuccess) {
+                (void)hipEventDestroy(ev[0]);
+                ev[0] = ev[1] = nullptr;
+            }
+        }
+        if (ev[0] && ev[1]) {
+            a = ev[0];
+            b = ev[1];
+            (void)hipEventRecord(a, s);
+        }
     }
     void stop() {
         if (b) (void)hipEventRecord(b, s);
@@ -464,10 +487,6 @@ struct NativeTimer {
     void read() {  // (after the stream has been waited for)
         float ms = 0.f;
         if (a && b && hipEventElapsedTime(&ms, a, b) == hipSuccess) g_last_native_ms = ms;
-    }
-    ~NativeTimer() {
-        if (a) (void)hipEventDestroy(a);
-        if (b) (void)hipEventDestroy(b);
     }
 };
 double bmx_last_native_kernel_ms(void) { return g_last_native_ms; }
@@ -762,6 +781,20 @@ int32_t bmx_engine_snapshot(bmx_engine_t* e, double* left_rm, double* right_rm, 
 int32_t bmx_engine_snapshot_var_adj(bmx_engine_t* e, double* left_rm, double* right_rm, double* corr_rm, double* scaling,
                                     int32_t* restrict1, int32_t* restrict2, int64_t* sizes4) {
     return guarded([&] { e->impl->snapshot_var_adj(left_rm, right_rm, corr_rm, scaling, restrict1, restrict2, sizes4); });
+}
+
+int32_t bmx_engine_var_adj_tally(bmx_engine_t* e, int32_t merge, int64_t* out3) {
+    return guarded([&] {
+        if (!out3) throw bmx::Error(BMX_ERR_ARG, "null output");
+        e->impl->var_adj_tally(merge, out3);
+    });
+}
+
+int32_t bmx_engine_snapshot_var_adj_modes(bmx_engine_t* e, uint8_t* dst, int64_t n) {
+    return guarded([&] {
+        if (n < 0 || (n > 0 && !dst)) throw bmx::Error(BMX_ERR_ARG, "null output");
+        e->impl->snapshot_var_adj_modes(dst, n);
+    });
 }
 
 int32_t bmx_engine_profile_var_adj(bmx_engine_t* e, double* out3) {

@@ -57,7 +57,8 @@ struct DevKnobs {
     int asv_fast = 0;         // adjust_shift_variance: the tiled form whatever the size
     int asv_cap = -1;         // tiled form: kept addends per chain of the literal re-run (-1: default, 0: no re-run)
     int asv_modes = 0;        // tiled form: record which way each of the first n cells of a call went (bmx_dev_get_bytes)
-    int sample_split = 0;     // ranges of the threshold sample of a search with few query blocks (0: never -- measured: no gain; -1: automatic)
+    int asv_sync = 1;         // tiled form: the workgroups start each round of tiles together (0: free-running, round 5)
+    int sample_split = -1;    // ranges of the threshold sample of a search with few query blocks (-1: automatic, 0: never, n: that many)
     int exchange_always = 0;  // a single rank goes through its exchange transport too (an all-gather of one)
     int refine_wave = 0;      // the exact re-rank takes a whole wave for every query (no half-wave form)
 };
@@ -330,6 +331,7 @@ struct KnnWorkspace {
     DevBuf<float> cand_v;          // [nq][C][KS] approximate values of the candidates (refine pre-ranks by them)
     DevBuf<uint32_t> tau_g;        // [nq] per-query thresholds shared across reference ranges
     DevBuf<float> margin;          // [nq] twice the fp16 pass's error bound per query, in the pass's own units
+    DevBuf<float> samp_lists;      // [nq][ranges][KS] a split threshold sample's per-range lists (knn_f16.hip: sample_merge_kernel)
     DevBuf<uint32_t> tau_seed;     // [nq] seeded search: each query's seed threshold in the pass's units (orderable image)
     bool slots_clean = false;      // maxslots is zero (knn_refine leaves it so behind an fp16 search)
     DevBuf<unsigned long long> maxslots;  // 64 x 16 words: per-slot maxima of the reference norms (prep kernels)

@@ -1,6 +1,7 @@
 // Device-level building blocks of the merge loop (implemented in pairs.hip / correct.hip / legacy.hip).
 // All pointers are device pointers, all matrices row-major [cells x d] FP64, all launches go to `stream`.
 #pragma once
+#include <functional>
 #include "bmx_common.hpp"
 
 namespace bmx {
@@ -57,8 +58,10 @@ void select_listed_rows(hipStream_t stream, ScanWorkspace& ws, const int32_t* id
 // seed[c] (c < nsel, zero on entry) = the largest squared distance (rounded up to f32) at which a right cell lists the c-th
 // selected left cell: idxRL / distRL [n_entries] = the right cells' neighbour lists with their Euclidean distances, lpos2c
 // maps a listed left cell to its row among the selected ones.  No mutual partner of that left cell lies farther.
+// (nsel_dev / rank / world: with several ranks only the seeds of this rank's slice of the selected cells are taken)
 void seed_thresholds(hipStream_t stream, const int32_t* idxRL, const double* distRL, int64_t n_entries,
-                     const int32_t* lpos2c, int nsel, float* seed);
+                     const int32_t* lpos2c, int nsel, float* seed, const int32_t* nsel_dev = nullptr, int rank = 0,
+                     int world = 1);
 // out[i] = rows[sel[i]]
 void compose_row_list(hipStream_t stream, const int32_t* sel, int n, const int32_t* rows, int32_t* out);
 
@@ -111,10 +114,17 @@ void sum_vector(hipStream_t stream, const double* in, int d, double scale, doubl
 // (with_sums) overall [d] = colMeans(averaged), msq [d] = colMeans(averaged^2) and *magnitude = .get_batch_magnitude
 // (R/fastMNN.R:481,582-595; magnitude nullable) have come out of the same pass, and srows (nullable) [U] holds each cell's
 // row in its node (rrows[second_u[u]]); false: the caller does those itself.
+// (shard: a rank of a multi-GPU run takes its share of the workgroups of the averaging whose vectors nobody reads and
+// all-gathers the workgroups' column sums through `exchange` (buffer, bytes per rank): section 5 of DESIGN.md)
+struct AvgShard {
+    int rank, world;
+    std::function<void(void*, int64_t)> exchange;
+};
 bool average_correction(hipStream_t stream, ReduceWorkspace& ws, const double* L, const int32_t* lrows, const double* R,
                         const int32_t* rrows, int d, const int32_t* second_u, int U, const int32_t* partR, const int32_t* cntR,
                         int k1, double* averaged, bool with_sums = false, double* overall = nullptr, double* msq = nullptr,
-                        double* magnitude = nullptr, int32_t* srows = nullptr, const int32_t* dup_next = nullptr);
+                        double* magnitude = nullptr, int32_t* srows = nullptr, const int32_t* dup_next = nullptr,
+                        const AvgShard* shard = nullptr);
 // (dup_next, nullable: right cells named by several positions of the restrict list -- position r's cell continues at
 // dup_next[r], -1 ends the chain; second_u then holds first positions only and a cell's pairs are those of its whole chain)
 
@@ -168,6 +178,7 @@ struct AsvPlan {
 AsvPlan adjust_shift_variance_plan(int g, int n2, int nr1, int nr2, int vect_row_major);
 // counters of the tiled form on the current device: {cells re-run literally, flagged cells beyond lcap, all cells}
 void asv_tally_read(unsigned long long out[3], bool reset);
+void asv_ticks_read(unsigned long long out[3]);  // diagnostics: 100 MHz ticks in the stream / at the round barrier / per-cell phase
 void asv_modes_read(unsigned char* dst, size_t n);  // testing hook "asv_modes": the way each cell of the last call went
 // out[c] for the cells c in [cell_begin, cell_end) only (cell_end < 0: n2) -- the unit a multi-GPU run shards by
 void adjust_shift_variance_device(hipStream_t stream, const double* data1, int g, int n1, const double* data2, int n2,

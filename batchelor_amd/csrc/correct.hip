@@ -164,14 +164,17 @@ __global__ __launch_bounds__(256) void average_correction_half(
     const double* __restrict__ L, const int32_t* __restrict__ lrows, const double* __restrict__ R,
     const int32_t* __restrict__ rrows, int d, const int32_t* __restrict__ second_u, int U,
     const int32_t* __restrict__ partR, const int32_t* __restrict__ cntR, int k1, double* __restrict__ averaged,
-    double* __restrict__ partial, int32_t* __restrict__ srows) {
+    double* __restrict__ partial, int32_t* __restrict__ srows, int bid0, int nblocks) {
     typedef double d2 __attribute__((ext_vector_type(2)));
     __shared__ double red[8][2][64];
     const int lane = threadIdx.x & 63, hl = lane & 31, half = lane >> 5;
     const int np = d >> 1;
     const bool act = hl < np;
     d2 cs = d2{0.0, 0.0}, cq = d2{0.0, 0.0};
-    for (int u0 = blockIdx.x * 8; u0 < U; u0 += gridDim.x * 8) {
+    // (logical workgroup bid of nblocks: a rank of a multi-GPU run launches its share of them, the cells a workgroup takes
+    // and the order it adds them in do not depend on how many ranks there are)
+    const int bid = bid0 + (int)blockIdx.x;
+    for (int u0 = bid * 8; u0 < U; u0 += nblocks * 8) {
         const int u = u0 + (threadIdx.x >> 6) * 2 + half;
         const bool live = u < U;
         const int r = second_u[live ? u : 0];
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(256) void average_correction_half(
             double t = 0.0;
 #pragma unroll
             for (int q = 0; q < 8; ++q) t += red[q][which][c];
-            partial[(int64_t)blockIdx.x * 2 * d + e] = t;
+            partial[(int64_t)bid * 2 * d + e] = t;
         }
     }
 }
@@ -705,13 +708,32 @@ void sum_vector(hipStream_t stream, const double* in, int d, double scale, doubl
 bool average_correction(hipStream_t stream, ReduceWorkspace& ws, const double* L, const int32_t* lrows, const double* R,
                         const int32_t* rrows, int d, const int32_t* second_u, int U, const int32_t* partR, const int32_t* cntR,
                         int k1, double* averaged, bool with_sums, double* overall, double* msq, double* magnitude,
-                        int32_t* srows, const int32_t* dup_next) {
+                        int32_t* srows, const int32_t* dup_next, const AvgShard* shard) {
     if (U <= 0) return false;
     if ((d & 1) == 0 && d <= 64 && k1 <= 32 && !dup_next) {
         const int grid = std::min(cdiv(U, 8), 1024);
+        if (with_sums && shard && !srows) {
+            // Several ranks, the averaging whose VECTORS nobody reads (R/fastMNN.R:480-481 wants overall.batch and the
+            // magnitude only; the vectors are taken again after the centring): every rank runs its share of the workgroups and
+            // the workgroups' column sums -- [grid][2 d] doubles -- are all-gathered; average_final adds them in block order as
+            // ever, so the result has the single rank's bits for any number of ranks.
+            const int per = cdiv(grid, shard->world);
+            const int lo = std::min(grid, per * shard->rank), hi = std::min(grid, lo + per);
+            double* partial = ws.partial.reserve((size_t)per * shard->world * 2 * d);
+            if (hi > lo) {
+                hipLaunchKernelGGL(average_correction_half, dim3(hi - lo), dim3(256), 0, stream, L, lrows, R, rrows, d, second_u, U,
+                                   partR, cntR, k1, averaged, partial, srows, lo, grid);
+                BMX_LAUNCH_CHECK();
+            }
+            shard->exchange(partial, (int64_t)per * 2 * d * (int64_t)sizeof(double));
+            hipLaunchKernelGGL(average_final, dim3(1), dim3(1024), 0, stream, (const double*)partial, grid, d, 1.0 / (double)U,
+                               overall, msq, magnitude);
+            BMX_LAUNCH_CHECK();
+            return true;
+        }
         double* partial = with_sums ? ws.partial.reserve((size_t)grid * 2 * d) : nullptr;
         hipLaunchKernelGGL(average_correction_half, dim3(grid), dim3(256), 0, stream, L, lrows, R, rrows, d, second_u, U, partR,
-                           cntR, k1, averaged, partial, srows);
+                           cntR, k1, averaged, partial, srows, 0, grid);
         BMX_LAUNCH_CHECK();
         if (with_sums) {
             hipLaunchKernelGGL(average_final, dim3(1), dim3(1024), 0, stream, (const double*)partial, grid, d, 1.0 / (double)U,

@@ -183,6 +183,7 @@ Engine::~Engine() {
 }
 
 void Engine::set_shard(int rank, int world, bmx_allgather_fn fn, void* ctx) {
+    if (emu_mode_ != 0) throw Error(BMX_ERR_ARG, "the engine is emulating a rank (bmx_engine_emulate): switch that off first");
     if (world < 1 || rank < 0 || rank >= world) throw Error(BMX_ERR_ARG, "invalid rank / world size");
     if (world > 1 && !fn) throw Error(BMX_ERR_ARG, "a multi-rank engine needs an all-gather callback");
     if (comm_ && rccl::api().CommDestroy) {  // a callback replaces an RCCL communicator
@@ -199,6 +200,7 @@ void Engine::set_shard(int rank, int world, bmx_allgather_fn fn, void* ctx) {
 void Engine::init_rccl(int rank, int world, const void* unique_id) {
     CacheScope cache_scope(&cache_);
     BMX_HIP(hipSetDevice(device_));
+    if (emu_mode_ != 0) throw Error(BMX_ERR_ARG, "the engine is emulating a rank (bmx_engine_emulate): switch that off first");
     if (world < 1 || rank < 0 || rank >= world) throw Error(BMX_ERR_ARG, "invalid rank / world size");
     if (!unique_id) throw Error(BMX_ERR_ARG, "null RCCL unique id");
     rccl::Api& a = rccl::api();
@@ -310,6 +312,10 @@ void Engine::exchange(void* buf, int64_t bytes_per_rank, bool flags_only) {
         }
         if (emu_next_ >= emu_rec_.size()) throw Error(BMX_ERR_ARG, "emulated run: more exchanges than the recorded run made");
         const auto& r = emu_rec_[emu_next_++];
+        // (the recording must be of THIS job: the same sequence of exchanges, each no larger than this call's padded array)
+        if (r.second > (int64_t)world_ * bytes_per_rank)
+            throw Error(BMX_ERR_ARG, "emulated run: an exchange of the recorded run is larger than this run's (other inputs, "
+                                     "parameters or tree than the recording?)");
         // bytes [0, mine) and [mine + per, total) of the recording, where they exist
         const int64_t total = r.second, lo = std::min(mine, total), hi = std::min(mine + bytes_per_rank, total);
         const int64_t n16 = (lo >> 4) + ((total - hi + 15) >> 4);
@@ -368,6 +374,12 @@ void Engine::upload(int nbatches, int d, const double* const* data, const int32_
     BMX_HIP(hipSetDevice(device_));
     root_.reset();  // results of an earlier run describe other inputs
     merges_.clear();
+    if (emu_mode_ != 0) {  // a recording describes the exchanges of the inputs it was made on
+        emu_rec_.clear();
+        emu_mode_ = 0;
+        rank_ = 0;
+        world_ = 1;
+    }
     if (nbatches < 2) throw Error(BMX_ERR_ARG, "at least two batches must be specified");  // R/fastMNN.R:345
     if (d < 1 || d > 256) throw Error(BMX_ERR_ARG, "number of dimensions must be in [1, 256]");
     B_ = nbatches;
@@ -563,7 +575,7 @@ Engine::MnnOut Engine::find_mnn(const Node& left, const Node& right, int k, doub
     // A right cell r can only pair with a left cell l if it lists l, at a distance search 1 has just measured: the
     // largest such distance bounds how far search 2 has to look for l -- a tight starting threshold for free.  Rows may
     // come back short, padded with -1.  (The seeds only need the selected cells' positions, not their number.)
-    seed_thresholds(stream_, idxRL, distRL, (int64_t)nR * o.k1, offSel, nL, seed);
+    seed_thresholds(stream_, idxRL, distRL, (int64_t)nR * o.k1, offSel, nL, seed, st + 2, rank_, world_);
     const int32_t nsel = read_state()[2];
     o.nsel = nsel;
     if (debug_prints()) fprintf(stderr, "[bmx] find_mnn: %d of %d left cells are in some right cell's list\n", nsel, nL);
@@ -831,8 +843,11 @@ void Engine::merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p,
     }
     double* mag = rec.bs_slot >= 0 ? scal_.p + rec.bs_slot : nullptr;
     const int32_t* rnext = right.restrict_dups ? right.dup_next.p : nullptr;
+    // (several ranks: this averaging's workgroups are dealt over them, the column sums all-gathered -- see AvgShard)
+    const bool avg_sharded = world_ > 1 || emu_mode_ == 1 || (dev_knobs().exchange_always != 0 && (comm_ || gather_fn_));
+    AvgShard ash{rank_, world_, [this](void* buf, int64_t bytes) { exchange(buf, bytes); }};
     if (!average_correction(stream_, red_ws_, left.data.p, lrows, right.data.p, rrows, d_, second_u_.p, mo.U, partR_.p, cntR_.p,
-                            mo.k1, averaged, true, overall, msq, mag, nullptr, rnext)) {
+                            mo.k1, averaged, true, overall, msq, mag, nullptr, rnext, avg_sharded ? &ash : nullptr)) {
         if (rec.batch_size_na) {
             col_reduce(stream_, red_ws_, averaged, nullptr, 0, mo.U, d_, 0, nullptr, 1.0 / (double)mo.U, overall);
         } else {
@@ -931,9 +946,23 @@ void Engine::merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p,
                 aev = knn_ws_.next_events(4);
                 (void)hipEventRecord(aev.first, stream_);
             }
+            // (testing hook "asv_modes": this merge's share of the tiled form's tallies, and the snapshot merge's per-cell ways --
+            // both wait for the device, which a test may)
+            const bool tallies = dev_knobs().asv_modes > 0 && !plan.exact;
+            unsigned long long t0[3] = {0, 0, 0};
+            if (tallies) asv_tally_read(t0, false);
             adjust_shift_variance_device(stream_, left.data.p, d_, left.n, right.data.p, right.n, corr, p.sigma, r1, nLs, r2,
                                          nRs, scaling, ws, plan, /* vect_row_major */ 1, (int)cb, (int)ce);
             if (aev.second) (void)hipEventRecord(aev.second, stream_);
+            if (tallies) {
+                unsigned long long t1[3] = {0, 0, 0};
+                asv_tally_read(t1, false);
+                for (int i = 0; i < 3; ++i) rec.asv_tally[i] = (int64_t)(t1[i] - t0[i]);
+                if (mdx == snap_merge_) {
+                    snap_modes_.assign((size_t)right.n, 255);
+                    asv_modes_read(snap_modes_.data(), snap_modes_.size());
+                }
+            }
             asv_pairs_ += (double)(ce - cb) * ((double)nLs + (double)nRs);
             sec = std::make_unique<Section>(this);
             queued_work_s_ += 5e-8 * (double)(ce - cb) * ((double)nLs + (double)nRs);
@@ -1602,6 +1631,15 @@ void Engine::snapshot_var_adj(double* left_rm, double* right_rm, double* corr_rm
     out(r1, snap_ai1_.p, (size_t)snap_ar1_ * sizeof(int32_t));
     out(r2, snap_ai2_.p, (size_t)snap_ar2_ * sizeof(int32_t));
     BMX_HIP(hipStreamSynchronize(stream_));
+}
+
+void Engine::var_adj_tally(int merge, int64_t* out3) const {
+    if (merge < 0 || merge >= (int)merges_.size()) throw Error(BMX_ERR_ARG, "merge index out of range");
+    for (int i = 0; i < 3; ++i) out3[i] = merges_[merge].asv_tally[i];
+}
+
+void Engine::snapshot_var_adj_modes(unsigned char* dst, int64_t n) const {
+    for (int64_t i = 0; i < n; ++i) dst[i] = (size_t)i < snap_modes_.size() ? snap_modes_[(size_t)i] : 255;
 }
 
 void Engine::merge_stats(int merge, int64_t* out6) const {

@@ -48,6 +48,7 @@ struct MergeRecord {
     double batch_size = 0.0;
     bool batch_size_na = true;
     bool skipped = false;
+    int64_t asv_tally[3] = {-1, -1, -1};  // testing hook "asv_modes": cells this merge's tiled adjust_shift_variance re-ran / flagged beyond the re-run / handled
     int bs_slot = -1;              // slot of batch.size in the device scalar buffer
     std::vector<int> var_batches;  // per segment (left segments first): batch id, ...
     std::vector<int> old_slot, new_slot;  // ... slots of its total variance before / after the merge's centring
@@ -96,6 +97,10 @@ class Engine {
     void profile_var_adj(double* out3);  // {ms, launches, (cell, restricted cell) pairs} of the run's adjust_shift_variance calls
     void snapshot_var_adj(double* left_rm, double* right_rm, double* corr_rm, double* scaling, int32_t* r1, int32_t* r2,
                           int64_t* sizes4);
+    // testing hook "asv_modes" on during the run: per merge the tiled form's tallies (re-run, flagged beyond it, handled; -1:
+    // not recorded), and the way every right cell of the snapshot merge went (dst[0, n): 0 / 1 / 2, 255 beyond the record)
+    void var_adj_tally(int merge, int64_t* out3) const;
+    void snapshot_var_adj_modes(unsigned char* dst, int64_t n) const;
     void profile(double* topk_ms, int64_t* launches, int64_t* fallbacks);
     // out[0..9]: full-pass ms / launches of the fp16 kernel, of the split-bf16 kernel, sample-pass ms / launches,
     // streaming-section ms (everything of the merges that is not a kNN search), queries that took the exact path,
@@ -220,6 +225,7 @@ class Engine {
     DevBuf<double> snap_al_, snap_ar_, snap_ac_, snap_as_;  // the snapshot merge's variance adjustment: inputs and scalings
     DevBuf<int32_t> snap_ai1_, snap_ai2_;
     int64_t snap_anl_ = 0, snap_anr_ = 0, snap_ar1_ = 0, snap_ar2_ = 0;
+    std::vector<unsigned char> snap_modes_;
     double asv_pairs_ = 0.0;  // (cell, restricted cell) pairs of this rank's adjust_shift_variance calls in the last run
 
     int B_ = 0;

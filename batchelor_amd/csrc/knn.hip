@@ -35,6 +35,8 @@ void f16_prep_all(hipStream_t stream, const double* X, const int32_t* rrows, int
                   double* rn2, double* qn2, unsigned long long* maxbits, unsigned long long* slots, int32_t* flagged0,
                   float* margin, const sel::PassEps& pe, const float* seed_d2, uint32_t* tau_seed, uint32_t* tau_init);
 bool f16_launch(hipStream_t stream, KnnWorkspace& ws, int NS, int KS, const Bf16Launch& L);
+void f16_sample_merge(hipStream_t stream, const float* lists, int nranges, int KS, int nq, int k, const float* margin,
+                      uint32_t* tau_g);
 
 namespace {
 
@@ -814,6 +816,7 @@ void candidate_pass(hipStream_t stream, KnnWorkspace& ws, const Tier& T, const d
     // cheap tiles the balance is flat between 16k and 32k rows at 50 PCs and lower for longer rows (a sampled tile
     // costs the full matrix work).  The fp16 kernel samples small references too (a quarter of the rows): its sweep
     // hands every survivor to another wave, which makes a start without thresholds expensive
+    const bool no_margin_knob = dev_knobs().no_margin != 0;
     int S_auto = nr >= 32768 ? 4096 : 0;
     if (T.id == 1 && nr >= 4096) S_auto = std::max(1024, std::min(nr / 4, NS <= 4 ? 24576 : 12288));
     // (a seeded search samples too, but a sixth of the rows: the odd query whose seed is loose -- a left cell listed by
@@ -824,11 +827,13 @@ void candidate_pass(hipStream_t stream, KnnWorkspace& ws, const Tier& T, const d
     // the sample with a fifth of the chip, every block over all of it: the sample is split into CS ranges instead, block x
     // range items fill the CUs, each range of at least 24 ring slots (a lane keeps the KS / 2 <= 24 smallest of its per-slot
     // minima) hands its queries a threshold of its own and the tightest one counts (atomicMin on the shared word).
+    // Round 6: the ranges leave their lists and the k-th smallest of the union is taken (f16_sample_merge): the threshold of the
+    // unsplit sample, so the split is on by default (testing hook "sample_split": 0 never, n that many ranges).
     int CS = 1;
-    if (T.id == 1 && S > 0 && nqb < 128 && dev_knobs().sample_split != 0) {
+    if (T.id == 1 && S > 0 && nqb < 128 && dev_knobs().sample_split != 0 && !no_margin_knob) {
         const int rs = f16_rows_per_slot(NS, KS);
-        CS = std::max(1, std::min({256 / std::max(nqb, 1), 8, S / (24 * rs)}));
-        if (dev_knobs().sample_split > 0) CS = std::max(1, std::min(dev_knobs().sample_split, S / rs));
+        CS = std::max(1, std::min({256 / std::max(nqb, 1), 8, S / (8 * rs)}));
+        if (dev_knobs().sample_split > 0) CS = std::max(1, std::min({dev_knobs().sample_split, S / rs, 512 / KS}));
     }
     int C = 1, n_full = 0;
     {
@@ -930,12 +935,19 @@ void candidate_pass(hipStream_t stream, KnnWorkspace& ws, const Tier& T, const d
         zero_slots = slots;  // knn_refine leaves them zeroed for the next search
         ws.slots_clean = false;
         if (S > 0) {
+            float* lists = nullptr;
             if (CS > 1) {  // block x range items over the sample rows [0, S)
                 const int rs = f16_rows_per_slot(NS, KS);
                 L.range_len = (int)round_up(cdiv(S, CS), rs);
                 L.nranges = cdiv(S, L.range_len);
+                if (L.nranges > 1 && margin) {
+                    lists = ws.samp_lists.reserve((size_t)nq_pad * L.nranges * KS);
+                    L.cand_v = lists;  // (a sample pass has no other use for it)
+                }
             }
             ok = go(L);
+            if (lists) f16_sample_merge(stream, lists, L.nranges, KS, nq, k, margin, tau_g);
+            L.cand_v = cand_v;
         }
     } else {
         ws.slots_clean = false;
@@ -1104,7 +1116,7 @@ void exact_search(hipStream_t stream, KnnWorkspace& ws, const double* X, const i
         BMX_HIP(hipMemsetAsync(slow, 0, sizeof(int32_t), stream));
         const size_t lds = (size_t)(XF_TILE + XF_QCH) * (d + 1) * sizeof(double);
         ensure_dynamic_lds(reinterpret_cast<const void*>(&knn_exact_filter), lds);
-        hipLaunchKernelGGL(knn_exact_filter, dim3(std::min(cdiv(nr, XF_TILE), 16384)), dim3(256), lds, stream, X, ref_rows, nr, Qs, qrs,
+        hipLaunchKernelGGL(knn_exact_filter, dim3(std::min(cdiv(nr, XF_TILE), 2048)), dim3(256), lds, stream, X, ref_rows, nr, Qs, qrs,
                            d, list, bounds, count, 0, xcnt, xd, xi);
         BMX_LAUNCH_CHECK();
         hipLaunchKernelGGL(knn_exact_pick, dim3(cdiv(count, 4)), dim3(256), 0, stream, list, count, 0, k, seeded ? 1 : 0, xcnt,
@@ -1161,7 +1173,7 @@ void search_tiers(hipStream_t stream, KnnWorkspace& ws, const Tier* tiers, int n
         int32_t* xi = ws.xi.reserve((size_t)KnnWorkspace::OPT_CAP * XF_CAP);
         const size_t lds = (size_t)(XF_TILE + XF_QCH) * (d + 1) * sizeof(double);
         ensure_dynamic_lds(reinterpret_cast<const void*>(&knn_exact_filter), lds);
-        hipLaunchKernelGGL(knn_exact_filter, dim3(std::min(cdiv(nr, XF_TILE), 16384)), dim3(256), lds, stream, X, ref_rows, nr, Qs, qrs,
+        hipLaunchKernelGGL(knn_exact_filter, dim3(std::min(cdiv(nr, XF_TILE), 2048)), dim3(256), lds, stream, X, ref_rows, nr, Qs, qrs,
                            d, flagged, bound, 0, KnnWorkspace::OPT_CAP, xcnt, xd, xi);
         BMX_LAUNCH_CHECK();
         hipLaunchKernelGGL(knn_exact_pick, dim3(KnnWorkspace::OPT_CAP / 4), dim3(256), 0, stream, flagged, 0,
@@ -1220,7 +1232,7 @@ __global__ __launch_bounds__(256) void lk_merge(const double* __restrict__ X, co
                                                 int kp, const double* __restrict__ Q, const int32_t* __restrict__ qrs, int nq,
                                                 int d, int k, const int32_t* __restrict__ sub_idx, int32_t* __restrict__ idx_out,
                                                 double* __restrict__ dist_out, int32_t* __restrict__ flagged,
-                                                int32_t* __restrict__ opt) {
+                                                int32_t* __restrict__ opt, double* __restrict__ kth_out) {
     __shared__ double kd[LK_MAXE];
     __shared__ int32_t ki[LK_MAXE];
     __shared__ int sh_fail;
@@ -1281,6 +1293,8 @@ __global__ __launch_bounds__(256) void lk_merge(const double* __restrict__ X, co
         if (sub_idx[((int64_t)p * nq + q) * kp + kp - 1] == l) sh_fail = 1;
     }
     __syncthreads();
+    // (the intersection's probe skips a row whose k-th distance it knows to be too small: exact here when the merge stands)
+    if (tid == 0 && kth_out) kth_out[q] = sh_fail ? __builtin_inf() : sqrt(kd[k - 1]);
     if (tid == 0 && sh_fail) {
         if (opt) atomicOr(opt, 1);  // optimistic run: the engine repeats it with host-checked searches
         else flagged[1 + atomicAdd(&flagged[0], 1)] = q;
@@ -1295,7 +1309,8 @@ __global__ __launch_bounds__(256) void lk_merge_wave(const double* __restrict__ 
                                                      int kp, const double* __restrict__ Q, const int32_t* __restrict__ qrs,
                                                      int nq, int d, int k, const int32_t* __restrict__ sub_idx,
                                                      int32_t* __restrict__ idx_out, double* __restrict__ dist_out,
-                                                     int32_t* __restrict__ flagged, int32_t* __restrict__ opt) {
+                                                     int32_t* __restrict__ flagged, int32_t* __restrict__ opt,
+                                                     double* __restrict__ kth_out) {
     __shared__ double kd_[4][512];
     __shared__ int32_t ki_[4][512];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1334,6 +1349,7 @@ __global__ __launch_bounds__(256) void lk_merge_wave(const double* __restrict__ 
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     bool fail = false;
+    double kthv = -1.0;  // the k-th merged candidate's squared distance, on the lane that ranks it
     for (int e = lane; e < E; e += 64) {
         const int p = e / kp, j = e - p * kp;
         const double de = kd[e];
@@ -1355,9 +1371,15 @@ __global__ __launch_bounds__(256) void lk_merge_wave(const double* __restrict__ 
             idx_out[(int64_t)q * k + rank] = ge;
             if (dist_out) dist_out[(int64_t)q * k + rank] = sqrt(de);
             fail |= j == kp - 1;  // a partition's list ends inside the first k
+            if (rank == k - 1) kthv = de;
         }
     }
-    if (__builtin_amdgcn_ballot_w64(fail) != 0 && lane == 0) {
+    const bool any_fail = __builtin_amdgcn_ballot_w64(fail) != 0;
+    if (kth_out) {
+        for (int o = 32; o > 0; o >>= 1) kthv = fmax(kthv, __shfl_xor(kthv, o));
+        if (lane == 0) kth_out[q] = any_fail || kthv < 0.0 ? __builtin_inf() : sqrt(kthv);
+    }
+    if (any_fail && lane == 0) {
         if (opt) atomicOr(opt, 1);
         else flagged[1 + atomicAdd(&flagged[0], 1)] = q;
     }
@@ -1365,7 +1387,8 @@ __global__ __launch_bounds__(256) void lk_merge_wave(const double* __restrict__ 
 
 // false: the shape does not suit the partitioned search (too few reference cells a partition, too many candidates)
 bool large_k_search(hipStream_t stream, KnnWorkspace& ws, const double* X, const int32_t* ref_rows, int nr, const double* Qs,
-                    const int32_t* qrs, int nq, int d, int k, int32_t* io, double* dout, const double* centre) {
+                    const int32_t* qrs, int nq, int d, int k, int32_t* io, double* dout, const double* centre,
+                    double* kth_out) {
     // neighbours asked of a partition: 36 where a tier holds that many (rows of up to 61 columns), else 20 (up to 125); a
     // partition holds 0.45 of that of a query's k on average, so that one holding all of it is rare
     Tier tiers[2];
@@ -1390,10 +1413,10 @@ bool large_k_search(hipStream_t stream, KnnWorkspace& ws, const double* X, const
     if (!opt) BMX_HIP(hipMemsetAsync(flagged, 0, sizeof(int32_t), stream));
     if (P * kp <= 512)
         hipLaunchKernelGGL(lk_merge_wave, dim3(cdiv(nq, 4)), dim3(256), 0, stream, X, (const int32_t*)rows, nr, P, kp, Qs, qrs, nq,
-                           d, k, (const int32_t*)sub, io, dout, flagged, opt);
+                           d, k, (const int32_t*)sub, io, dout, flagged, opt, kth_out);
     else
         hipLaunchKernelGGL(lk_merge, dim3(nq), dim3(256), 0, stream, X, (const int32_t*)rows, nr, P, kp, Qs, qrs, nq, d, k,
-                           (const int32_t*)sub, io, dout, flagged, opt);
+                           (const int32_t*)sub, io, dout, flagged, opt, kth_out);
     BMX_LAUNCH_CHECK();
     if (!opt) {
         const int count = read_count(stream, ws, flagged);
@@ -1433,7 +1456,7 @@ void knn_device(hipStream_t stream, KnnWorkspace& ws, const double* X, const int
     // the full k nearest serve its caller just as well)
     // (also k in (20, 36] where no tier holds lists that long: rows of more than 61 columns, BASELINE config 5's 100 PCs)
     if (ntiers == 0 && !ws.force_exact && k > 20 && dev_knobs().knn_tier != 3 &&
-        large_k_search(stream, ws, X, ref_rows, nr, Qs, qrs, nq, d, k, io, dout, centre)) {
+        large_k_search(stream, ws, X, ref_rows, nr, Qs, qrs, nq, d, k, io, dout, centre, kth_out ? kth_out + q_begin : nullptr)) {
         ws.exact_total += ws.last_exact;
         return;
     }

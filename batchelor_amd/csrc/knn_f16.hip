@@ -1150,9 +1150,18 @@ __global__ __launch_bounds__((NCONS + NPROD + serv_waves(NS)) * 64) void knn_top
         // (a seeded search: the tighter of the sampled threshold and the seed's, prep wrote the latter's image)
         // A sample split into ranges (few query blocks, see knn.hip): every range's threshold is valid by itself -- k of ITS
         // references lie at or below it -- so the tightest of them is; prep has written the seed (or +inf) there.
+        // Round 6: the ranges also leave their lists (cand_v is free in a sample pass: [query][range][2 x KS / 2] values, all
+        // of distinct references), and sample_merge_kernel takes the k-th smallest of their UNION -- what the unsplit sample
+        // arrives at, so that splitting costs the full pass nothing (the tightest single range, round 5, left it 10 % looser).
         if (h == 0) {
             if (nrng > 1) atomicMin(&tau_g[q], start);
             else tau_g[q] = tau_seed ? min(start, tau_seed[q]) : start;
+        }
+        if (nrng > 1 && cand_v) {
+            float* dst = cand_v + ((int64_t)q * nrng + rng) * KS + h * (KS / 2);
+#pragma unroll
+            for (int e = 0; e < KS / 2; e += 4)
+                *reinterpret_cast<f32x4*>(dst + e) = f32x4{best[e], best[e + 1], best[e + 2], best[e + 3]};
         }
 #ifdef BMX_STAMPS
         if (lane == 0) {
@@ -1235,6 +1244,44 @@ void launch(hipStream_t stream, KnnWorkspace& ws, const Bf16Launch& L) {
 }
 
 }  // namespace
+
+namespace {
+// The split sample's thresholds (see the SAMPLE epilogue of knn_topk_f16): one wave per query, n = nranges x KS values of
+// distinct references; the k-th smallest of them -- every value's rank by counting, ties by position -- plus twice the pass's
+// error bound is a valid starting threshold (the margin form of the unsplit sample), taken if tighter than what stands there.
+__global__ __launch_bounds__(256) void sample_merge_kernel(const float* __restrict__ lists, int n, int nq, int k,
+                                                           const float* __restrict__ margin_g, uint32_t* __restrict__ tau_g) {
+    __shared__ float sv[4][512];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + w;
+    if (q >= nq) return;  // (whole waves: nothing below synchronises the block)
+    float* v = sv[w];
+    for (int i = lane; i < n; i += 64) v[i] = lists[(int64_t)q * n + i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    float uk = __builtin_inff();
+    for (int i = lane; i < n; i += 64) {
+        const float x = v[i];
+        int r = 0;
+        for (int j = 0; j < n; ++j) r += (v[j] < x || (v[j] == x && j < i)) ? 1 : 0;
+        uk = r == k - 1 ? x : uk;
+    }
+    for (int o = 32; o > 0; o >>= 1) uk = fminf(uk, __shfl_xor(uk, o));
+    if (lane == 0) {
+        const float tm = uk + margin_g[q] + fabsf(uk) * 2.384185791015625e-07f;  // (the f32 sum rounded up)
+        if (tm == tm && tm < __builtin_inff()) atomicMin(&tau_g[q], f32_orderable(tm));
+    }
+}
+}  // namespace
+
+void f16_sample_merge(hipStream_t stream, const float* lists, int nranges, int KS, int nq, int k, const float* margin,
+                      uint32_t* tau_g) {
+    const int n = nranges * KS;
+    if (n > 512 || nq <= 0 || k < 1 || k > n || !margin) return;  // (the ranges' own thresholds stand)
+    hipLaunchKernelGGL(sample_merge_kernel, dim3(cdiv(nq, 4)), dim3(256), 0, stream, lists, n, nq, k, margin, tau_g);
+    BMX_LAUNCH_CHECK();
+}
 
 // MFMA k-steps (16 fp16 each) for d + 3 columns; 0 = this tier does not take the shape
 int f16_pick_ns(int d, int KS) {

@@ -217,16 +217,25 @@ __global__ void mark_listed(const int32_t* __restrict__ idx, int64_t n, int32_t*
 
 // seed[c] = max over the right cells r that list left cell l (c = row of l among the selected left cells) of
 // d(r, l)^2, rounded up to f32: every right cell that can be a mutual partner of l lies within it
+// Several ranks: a rank searches its slice of the selected left cells only (bmx_shard_range over their number, which is
+// still on the device here: nsel_dev), so it takes the seeds of that slice only -- 7 of 8 entries end after one lookup.
 __global__ void seed_from_lists(const int32_t* __restrict__ idxRL, const double* __restrict__ distRL, int64_t n,
-                                const int32_t* __restrict__ lpos2c, uint32_t* __restrict__ seed_bits) {
+                                const int32_t* __restrict__ lpos2c, uint32_t* __restrict__ seed_bits,
+                                const int32_t* __restrict__ nsel_dev, int rank, int world) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const int32_t c_ = lpos2c[idxRL[i]];
+    if (world > 1) {
+        const int nsel = *nsel_dev, per = (nsel + world - 1) / world;
+        const int lo = min(nsel, per * rank), hi = min(nsel, lo + per);
+        if (c_ < lo || c_ >= hi) return;
+    }
     const double dd = distRL[i] * distRL[i] * (1.0 + 1e-15);  // sqrt, then squared again: never below the true value
     float f = (float)dd;
     if ((double)f < dd) f = __uint_as_float(__float_as_uint(f) + 1u);  // dd >= 0: the next float up
     // non-negative floats order like their bits.  A cell is listed ~25 times at the first merge; only the few entries that
     // raise its running maximum need the atomic (a stale read merely sends one too many)
-    uint32_t* slot = seed_bits + lpos2c[idxRL[i]];
+    uint32_t* slot = seed_bits + c_;
     const uint32_t bits = __float_as_uint(f);
     if (bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, bits);
 }
@@ -316,11 +325,12 @@ void select_listed_rows(hipStream_t stream, ScanWorkspace& ws, const int32_t* id
 }
 
 void seed_thresholds(hipStream_t stream, const int32_t* idxRL, const double* distRL, int64_t n_entries,
-                     const int32_t* lpos2c, int nsel, float* seed) {
+                     const int32_t* lpos2c, int nsel, float* seed, const int32_t* nsel_dev, int rank, int world) {
     if (nsel <= 0) return;
+    if (!nsel_dev) world = 1;
     if (n_entries > 0) {  // (seed[0, nsel) was zeroed by select_listed_rows)
         hipLaunchKernelGGL(seed_from_lists, dim3(cdiv(n_entries, 256)), dim3(256), 0, stream, idxRL, distRL, n_entries,
-                           lpos2c, reinterpret_cast<uint32_t*>(seed));
+                           lpos2c, reinterpret_cast<uint32_t*>(seed), nsel_dev, rank, world);
         BMX_LAUNCH_CHECK();
     }
 }

@@ -181,6 +181,23 @@ class MnnEngine:
                      _lib.f64p(out["scaling"]), _lib.i32p(out["restrict1"]), _lib.i32p(out["restrict2"]), None))
         return out
 
+    def var_adj_tally(self):
+        """Per merge (runs made with the testing hook "asv_modes" on): cells the tiled adjust_shift_variance re-ran in the
+        reference's order of operations, flagged beyond the re-run, handled in all (-1: not recorded)."""
+        out = []
+        for m in range(self.nbatches - 1):
+            a = np.zeros(3, dtype=np.int64)
+            _lib.check(_lib.lib().bmx_engine_var_adj_tally(self._h, m, a.ctypes.data_as(_lib.c_i64p)))
+            out.append(dict(zip(("rerun", "beyond", "tiled"), a.tolist())))
+        return out
+
+    def snapshot_var_adj_modes(self, n):
+        """The way every right cell of the snapshot merge's tiled adjust_shift_variance went (0 / 1 / 2; 255: not recorded)."""
+        a = np.zeros(int(n), dtype=np.uint8)
+        _lib.check(_lib.lib().bmx_engine_snapshot_var_adj_modes(self._h, a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
+                                                              ctypes.c_int64(int(n))))
+        return a
+
     def profile_detail(self):
         a = np.zeros(10, dtype=np.float64)
         _lib.check(_lib.lib().bmx_engine_profile_detail(self._h, _lib.f64p(a)))

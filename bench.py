@@ -214,6 +214,29 @@ def cpu_baselines(batches, stats, d, k):
     return main, out
 
 
+def cpu_baseline_var_adj(batches, d, sigma, asv_pairs_per_step):
+    """adjust_shift_variance on the host cores: the oracle's restatement of src/adjust_shift_variance.cpp:51-161 (OpenMP over
+    the cells, which the reference's loop treats independently) on a bounded sample -- 8 cells per host thread of one batch against
+    ~200 000 reference cells + its own batch -- scaled by (cell, restricted cell) pairs to the step's calls."""
+    from oracle import fastmnn_oracle as orc
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    order = np.argsort([-b.shape[0] for b in batches])
+    ref = batches[order[0]][:200000]
+    own = batches[order[1]][:60000]
+    rng = np.random.default_rng(3)
+    cells = np.sort(rng.choice(own.shape[0], min(8 * cores, own.shape[0]), replace=False)).astype(np.int32)
+    vect = rng.standard_normal((own.shape[0], d)) * 0.2
+    r1, r2 = np.arange(ref.shape[0]), np.arange(own.shape[0])
+    t0 = time.perf_counter()
+    orc.adjust_shift_variance(ref.T, own.T, vect, sigma, r1, r2, cells=cells)
+    dt = time.perf_counter() - t0
+    rate = cells.size * float(ref.shape[0] + own.shape[0]) / dt
+    return {"seconds_per_step": asv_pairs_per_step / rate, "pairs_per_s": rate, "cores": cores, "kind": "port",
+            "sample": (f"oracle/mnn_oracle.c orc_adjust_shift_variance_cells (OpenMP, {cores} threads): {cells.size} cells x "
+                       f"({ref.shape[0]} + {own.shape[0]}) restricted cells, {d} dims, sigma {sigma}, in {dt:.1f} s = {rate:.3g} "
+                       f"(cell, restricted cell) pairs/s; scaled by pairs to the step's {asv_pairs_per_step:.3g}")}
+
+
 def run_config4(args):
     """BASELINE.json configs[3]: fastMNN end to end -- cosineNorm + multiBatchPCA(d = 50) over 20 000 genes + reducedMNN,
     4 batches x --cells cells (200 000 = the configuration as named: 128 GB of FP64 input).  The input never exists in one
@@ -362,6 +385,24 @@ def run_sgk(args):
     ref = (averaged @ w) / w.sum(axis=0)
     err = float(np.abs(out[:, cells] - ref).max() / np.abs(ref).max())
     flops = 2.0 * gd * U * (n + U) + 2.0 * gd * U * n
+    cpu = None
+    if not args.no_cpu_baseline:
+        # the reference's loop (src/smooth_gaussian_kernel.cpp:32-99: serial over the MNN cells, no threads) as the oracle
+        # restates it, on a bounded sample -- 400 of the MNN cells against themselves + 20 000 other cells -- scaled by
+        # (MNN cell, cell) pairs to the whole call
+        from oracle import fastmnn_oracle as orc
+        Us, ns_ = 400, 20000
+        sel = np.concatenate([index[:Us], np.setdiff1d(np.arange(n), index[:Us])[:ns_]])
+        t1 = time.perf_counter()
+        orc.smooth_gaussian_kernel(averaged[:, :Us], np.arange(Us), mat[:, sel], s2)
+        dtc = time.perf_counter() - t1
+        rate = Us * float(sel.size) / dtc
+        cpu = {"value": n / (U * float(n) / rate), "unit": "cells/s", "cores": 1, "kind": "port",
+               "sample": (f"oracle/mnn_oracle.c orc_smooth_gaussian_kernel (the reference's serial loop, 1 thread): {Us} MNN cells x "
+                          f"{sel.size} cells in {dtc:.1f} s = {rate:.3g} (MNN cell, cell) pairs/s; scaled by pairs to U x n = "
+                          f"{U * float(n):.3g}")}
+    if kern_ms != kern_ms:  # (NaN: the call's events could not be read)
+        kern_ms = 0.0
     print(json.dumps({"metric": "cells/sec smoothed (smooth_gaussian_kernel, .Call level, host in / host out)",
                       "value": n / dt, "unit": "cells/s", "n_gpus": 1, "steps": 1, "warmup": 1, "ms_per_step": 1e3 * dt,
                       "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64 MFMA",
@@ -375,8 +416,51 @@ def run_sgk(args):
                                    "unit": "TFLOP/s", "frac": flops / (kern_ms * 1e-3) / 1e12 / 78.6 if kern_ms > 0 else None,
                                    "kernel_ms": kern_ms, "traffic": None,
                                    "peak_note": "FP64 matrix peak from AMD's MI355X data sheet; not in the in-container guide"},
+                      "cpu_baseline": cpu, "host_cores": os.cpu_count(),
                       "algorithmic_flops": flops}), flush=True)
     assert err < 1e-9, err
+
+
+def measure_exchange_call_overhead(batches, k, tree, run_kw, steps, warmup):
+    """What ONE exchange costs beside its bytes, measured: an engine with its own RCCL communicator of ONE rank (the only
+    world this pool offers) runs the job with and without the testing hook "exchange_always" -- with it every list goes
+    through ncclAllGather on the engine's stream (in place, one rank: a launch and its latency, no link traffic) and the
+    sharded forms of the tricube apply and of the first averaging run with their copy kernels.  (ms per step without, with,
+    calls per step) -> the per-call term of the exchange model."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    import batchelor_amd as bx
+    from batchelor_amd import _lib as _bl
+    from batchelor_amd.dist import init_engine_rccl
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    eng = bx.MnnEngine(0)
+    try:
+        init_engine_rccl(eng)
+        eng.upload(batches)
+        out = {}
+        for rep in range(2):
+            for flag in (0, 1):
+                _bl.dev_set("exchange_always", flag)
+                for _ in range(warmup):
+                    eng.run(k=k, merge_tree=tree, **run_kw)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    eng.run(k=k, merge_tree=tree, **run_kw)
+                torch.cuda.synchronize()
+                out.setdefault(flag, []).append(1e3 * (time.perf_counter() - t0) / steps)
+                if flag:
+                    calls = eng.exchange_stats()["calls"]
+        return min(out[0]), min(out[1]), calls
+    finally:
+        _bl.dev_set("exchange_always", 0)
+        eng.close()
+        dist.destroy_process_group()
 
 
 def run_emulation(args):
@@ -416,6 +500,15 @@ def run_emulation(args):
 
     t1, cand1, stream1 = timed(args.steps, args.warmup)
     base = eng.download(with_pairs=True)
+    per_call_us, per_call_note = 15.0, "assumed"
+    if args.measure_exchange:
+        try:
+            ms0, ms1, calls1 = measure_exchange_call_overhead(batches, k, tree, run_kw, args.steps, args.warmup)
+            per_call_us = max(0.0, 1e3 * (ms1 - ms0) / max(calls1, 1))
+            per_call_note = (f"measured: one-rank ncclAllGather on the engine's stream for every exchange, {ms0:.2f} -> {ms1:.2f} ms "
+                             f"per step over {calls1} calls (the sharded forms' copy kernels included)")
+        except Exception as exc:  # noqa: BLE001
+            per_call_note = f"assumed (measurement failed: {exc})"
     eng.emulate(1)
     eng.run(k=k, merge_tree=tree, **run_kw)   # the recorded run
     # xGMI: 7 links x ~153 GB/s per GPU (task statement); a ring all-gather moves (N-1)/N of the gathered bytes through every
@@ -436,7 +529,7 @@ def run_emulation(args):
                 for (a0, a1), (b0, b1) in zip(got.merge_info.pairs, base.merge_info.pairs):
                     assert np.array_equal(a0, b0) and np.array_equal(a1, b1)
         links = min(world - 1, 7)
-        model_ms = 1e3 * (xst["bytes"] * (world - 1) / world) / (0.6 * 153e9 * links) + 0.015 * xst["calls"]
+        model_ms = 1e3 * (xst["bytes"] * (world - 1) / world) / (0.6 * 153e9 * links) + 1e-3 * per_call_us * xst["calls"]
         worst = max(per_rank)
         print(json.dumps({
             "metric": "one rank's ms per step, emulated on one GPU (rank r of N: its share of every search, every replicated kernel)",
@@ -446,7 +539,7 @@ def run_emulation(args):
             "ideal_ms_per_step": t1 / world, "sharding_efficiency": (t1 / world) / worst,
             "exchange_calls_per_step": xst["calls"], "exchange_bytes_per_step": xst["bytes"],
             "exchange_model_ms_per_step": model_ms,
-            "exchange_model": "bytes (N-1)/N over min(N-1, 7) xGMI links at 60 % of 153 GB/s + 15 us per launch, serial",
+            "exchange_model": f"bytes (N-1)/N over min(N-1, 7) xGMI links at 60 % of 153 GB/s + {per_call_us:.1f} us per call ({per_call_note}), serial",
             "projected_speedup_compute_only": t1 / worst, "projected_speedup_with_modelled_exchange": t1 / (worst + model_ms),
             "projected_cells_per_s": n_cells / ((worst + model_ms) * 1e-3),
             "results_identical_to_one_gpu": True}), flush=True)
@@ -470,6 +563,8 @@ def main():
     ap.add_argument("--emulate-world", default=None, metavar="N[,N...]",
                     help="measure one rank's share of an N-rank run on this one GPU (bmx_engine_emulate); e.g. 2,4,8")
     ap.add_argument("--emulate-ranks", default="all", help="--emulate-world: which ranks to measure (all, or e.g. 0,3,7)")
+    ap.add_argument("--measure-exchange", action="store_true",
+                    help="--emulate-world: measure the per-call term of the exchange model with a one-rank RCCL communicator")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-to-host", action="store_true")
     args = ap.parse_args()
@@ -699,6 +794,15 @@ def main():
             try:
                 line["cpu_baseline"], line["cpu_baseline_variants"] = cpu_baselines(batches, stats, d, k)
                 line["host_cores"] = os.cpu_count()
+                if args.var_adj and asv["asv_ms"] > 0:
+                    # the step is searches + adjust_shift_variance: both on the host cores, added up
+                    va = cpu_baseline_var_adj(batches, d, args.sigma, asv["asv_pairs"] / max(1, args.steps))
+                    knn_s = n_cells / line["cpu_baseline"]["value"]
+                    line["cpu_baseline_searches_only"] = dict(line["cpu_baseline"])
+                    line["cpu_baseline"] = {
+                        "value": n_cells / (knn_s + va["seconds_per_step"]), "unit": "cells/s", "cores": va["cores"], "kind": "port",
+                        "adjust_shift_variance_s_per_step": va["seconds_per_step"], "searches_s_per_step": knn_s,
+                        "sample": "searches: " + line["cpu_baseline"]["sample"] + " | adjust_shift_variance: " + va["sample"]}
                 try:  # (the CPU baseline is reported with the host's core count and CPU model)
                     with open("/proc/cpuinfo") as f:
                         line["host_cpu_model"] = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), None)

@@ -99,7 +99,11 @@ void bmx_set_force_exact_knn(int32_t on);
  * "asv_fast" (the tiled form of adjust_shift_variance at any size), "exchange_always" (a single rank goes through its
  * exchange transport too), "refine_wave" (the exact re-rank spends a whole wave on every query), "asv_cap" (tiled
  * adjust_shift_variance: addends a chain of the literal re-run of an ill-conditioned cell may keep; -1 = default, 0 = no
- * re-run), "reset" (all back to their defaults).  Unknown name: BMX_ERR_ARG. */
+ * re-run), "asv_modes" (n: the tiled form records which way each of the first n cells of a call went, see
+ * bmx_dev_get_bytes), "asv_sync" (0: the tiled form's workgroups do not wait for each other at the start of a round of
+ * tiles -- round 5's free-running streams; default 1), "sample_split" (ranges the threshold sample of a search with few
+ * query blocks is split into; 0 = never, the default; -1 = automatic), "reset" (all back to their defaults).
+ * Unknown name: BMX_ERR_ARG. */
 int32_t bmx_dev_set(const char* name, int32_t value);
 /* Counters for tests and bench.py, current device: "asv_tiled_cells" (cells the tiled form of adjust_shift_variance has
  * handled), "asv_literal_cells" (of those, re-run in the reference's order of operations: bit-equal to the exact form),
@@ -220,6 +224,12 @@ int32_t bmx_engine_snapshot(bmx_engine_t* e, double* left_rm, double* right_rm, 
  * src/adjust_shift_variance.cpp on the same inputs, a sample of cells at a time. */
 int32_t bmx_engine_snapshot_var_adj(bmx_engine_t* e, double* left_rm, double* right_rm, double* corr_rm, double* scaling,
                                     int32_t* restrict1, int32_t* restrict2, int64_t* sizes4);
+/* Testing hooks of var_adj runs made with bmx_dev_set("asv_modes", n > 0) (they wait for the device after every merge):
+ * out3 = cells merge `merge`'s tiled adjust_shift_variance call re-ran in the reference's order of operations / flagged as
+ * ill-conditioned but beyond the re-run / handled in all (-1: not recorded, e.g. the exact form ran); and the way every right
+ * cell of the SNAPSHOT merge went (dst[0, n): 0 histogram quantile, 1 re-run, 2 flagged beyond it; 255 not recorded). */
+int32_t bmx_engine_var_adj_tally(bmx_engine_t* e, int32_t merge, int64_t* out3);
+int32_t bmx_engine_snapshot_var_adj_modes(bmx_engine_t* e, uint8_t* dst, int64_t n);
 /* Per kernel class (profiling on, since the last run started): out[0], out[1] = milliseconds and launches of the fp16
  * full pass, out[2], out[3] of the split-bf16 full pass, out[4], out[5] of the sample passes, out[6] = milliseconds of
  * the merges' streaming sections (everything that is not a kNN search), out[7] = queries that took the exact FP64

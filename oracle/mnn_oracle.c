@@ -209,10 +209,20 @@ int orc_find_mutual_nns(const int32_t* left, int32_t nL, int32_t k2, const int32
  * last-bit difference into a different cell.  So the sum is taken with the bit-reproducible exp / log1p of
  * portable_math.h (a few ulp from libm; tests/test_oracle_kat.py compares the two), which the HIP side repeats. */
 #include "portable_math.h"
-static inline double logspace_add(double lx, double ly) { return bmx_pm_logspace_add(lx, ly); }
-/* the same with the platform's libm, for the comparison test */
+/* the same with the platform's libm -- what an R built against this libc would compute -- for the comparison tests:
+ * orc_set_logspace_libm(1) makes adjust_shift_variance / smooth_gaussian_kernel below sum with it
+ * (tests/test_oracle_kat.py: how many cells land on another quantile when the math library changes) */
+static int g_logspace_libm = 0;
+void orc_set_logspace_libm(int on) { g_logspace_libm = on; }
 double orc_logspace_add_libm(double lx, double ly) { return (lx > ly ? lx : ly) + log1p(exp(-fabs(lx - ly))); }
 double orc_logspace_add(double lx, double ly) { return bmx_pm_logspace_add(lx, ly); }
+static inline double logspace_add(double lx, double ly) {
+    return g_logspace_libm ? orc_logspace_add_libm(lx, ly) : bmx_pm_logspace_add(lx, ly);
+}
+/* n pairs at once (the comparison test draws a million) */
+void orc_logspace_add_many(const double* lx, const double* ly, int64_t n, int libm, double* out) {
+    for (int64_t i = 0; i < n; ++i) out[i] = libm ? orc_logspace_add_libm(lx[i], ly[i]) : bmx_pm_logspace_add(lx[i], ly[i]);
+}
 
 /* ------------------------------------------------------------------------------------------------
  * smooth_gaussian_kernel -- follows src/smooth_gaussian_kernel.cpp:11-118.

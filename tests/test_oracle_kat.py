@@ -298,18 +298,101 @@ def _asv_ref(data1, data2, cell_vect, sigma):
     return out
 
 
+def _asv_reference_shape(seed=100032):
+    # the reference's own test shape (test-mnn-correct.R:96-98): data1 25 x 400, data2 25 x 1000 (rnorm, sd 0.1),
+    # corvect 1000 x 25 (runif) -- drawn with our RNG, R's stream is not reproducible here
+    rng = np.random.default_rng(seed)
+    data1 = rng.standard_normal((25, 400)) * 0.1
+    data2 = rng.standard_normal((25, 1000)) * 0.1
+    corvect = rng.random((1000, 25))
+    return data1, data2, corvect
+
+
 @pytest.mark.parametrize("sigma", [1.0, 0.1])
 def test_adjust_shift_variance_spec(oracle, sigma):
-    rng = np.random.default_rng(100032)
-    data1 = rng.standard_normal((25, 120)) * 0.1
-    data2 = rng.standard_normal((25, 200)) * 0.1
-    corvect = rng.random((200, 25))
+    # test-mnn-correct.R:94-151 at ITS shape: the oracle equals the reference's REF on EVERY cell -- what the reference's
+    # expect_equal(ref, test) (tolerance 1.5e-8) asserts (:143-149)
+    data1, data2, corvect = _asv_reference_shape()
     ref = _asv_ref(data1, data2, corvect, sigma)
-    out = oracle.adjust_shift_variance(data1, data2, corvect, sigma, np.arange(120), np.arange(200))
-    # the discrete quantile pick may flip on rounding for a handful of cells (the reference relaxes / skips this
-    # test on two platforms for the same reason: test-mnn-correct.R:141,396-399)
-    close = np.isclose(out, ref, rtol=1e-8, atol=1e-12)
-    assert close.mean() > 0.97, close.mean()
+    out = oracle.adjust_shift_variance(data1, data2, corvect, sigma, np.arange(400), np.arange(1000))
+    np.testing.assert_allclose(out, ref, rtol=1.5e-8, atol=1e-12)
+    assert np.abs(out / ref - 1.0).mean() < 1e-13  # measured 6e-15 .. 2e-14
+
+
+@pytest.mark.parametrize("sigma", [1.0, 0.1])
+def test_adjust_shift_variance_spec_swapped_shape(oracle, sigma):
+    # the same with the larger batch as the reference batch (25 x 1000 against 25 x 400)
+    data2, data1, _ = _asv_reference_shape(100034)
+    corvect = np.random.default_rng(5).random((400, 25))
+    ref = _asv_ref(data1, data2, corvect, sigma)
+    out = oracle.adjust_shift_variance(data1, data2, corvect, sigma, np.arange(1000), np.arange(400))
+    np.testing.assert_allclose(out, ref, rtol=1.5e-8, atol=1e-12)
+
+
+# ---------------------------------------------------------------- R::logspace_add, src/adjust_shift_variance.cpp:99,107,130,150
+def _logspace_many(oracle, lx, ly, libm):
+    import ctypes
+    f64p = ctypes.POINTER(ctypes.c_double)
+    out = np.empty_like(lx)
+    oracle.lib().orc_logspace_add_many(lx.ctypes.data_as(f64p), ly.ctypes.data_as(f64p), ctypes.c_int64(lx.size), int(libm),
+                                       out.ctypes.data_as(f64p))
+    return out
+
+
+LOGSPACE_DRAWS = {
+    # name: (draw, measured share of pairs on which the portable sum and glibc's differ at all)
+    "U(-50,0)": (lambda r, n: r.uniform(-50, 0, n), 0.0026),
+    "3*N(0,1)": (lambda r, n: 3.0 * r.standard_normal(n), 0.081),
+    "U(-5,0)": (lambda r, n: r.uniform(-5, 0, n), 0.155),
+}
+
+
+@pytest.mark.parametrize("name", list(LOGSPACE_DRAWS))
+def test_logspace_add_portable_against_libm(oracle, name, capsys):
+    """The oracle (and the HIP side, csrc/portable_math.hpp) sum with a bit-reproducible exp / log1p; Rmath's logspace_add
+    calls the platform's.  How far apart the two are, on a million random pairs per distribution: never more than 3 units in
+    the last place of max(|result|, |larger operand|, 0.5), and they differ at all on 0.3 % .. 16 % of the pairs depending on
+    how close the operands are (the closer, the more of log1p's argument range is exercised)."""
+    draw, measured = LOGSPACE_DRAWS[name]
+    rng = np.random.default_rng(20250601)
+    lx, ly = draw(rng, 10 ** 6), draw(rng, 10 ** 6)
+    a, b = _logspace_many(oracle, lx, ly, False), _logspace_many(oracle, lx, ly, True)
+    scale = np.spacing(np.maximum(np.maximum(np.abs(a), np.abs(np.maximum(lx, ly))), 0.5))
+    ulps = np.abs(a - b) / scale
+    share = float((a != b).mean())
+    with capsys.disabled():
+        print(f"\n[logspace_add {name}] portable != libm on {share:.4f} of 1e6 pairs, max {ulps.max():.1f} ulp")
+    assert ulps.max() <= 4.0, ulps.max()
+    assert share <= 2.5 * measured + 0.01, share
+    # and both are the true sum to within a few ulp: against extended precision
+    ref = np.logaddexp(lx.astype(np.longdouble), ly.astype(np.longdouble))
+    assert (np.abs(a.astype(np.longdouble) - ref) / scale).max() <= 4.0
+
+
+@pytest.mark.parametrize("shape", ["reference", "100 dimensions"])
+@pytest.mark.parametrize("sigma", [1.0, 0.1, 0.01])
+def test_adjust_shift_variance_math_library_moves_no_cell(oracle, shape, sigma, capsys):
+    """adjust_shift_variance summed with the platform's exp / log1p (orc_set_logspace_libm(1): what an R linked against this
+    libc computes) against the oracle's portable arithmetic, on the reference's own test shape (test-mnn-correct.R:96-98) and
+    on a 100-dimension shape where the walk is decided by the last bit: the share of cells that land on
+    another quantile.  Measured: none on either shape at any bandwidth -- the chains' decisions are made by which addends are
+    absorbed, which a <= 3 ulp difference in log1p(exp(.)) of the absorbed addend does not change."""
+    if shape == "reference":
+        data1, data2, corvect = _asv_reference_shape()
+    else:
+        rng = np.random.default_rng(7)
+        data1, data2, corvect = rng.standard_normal((100, 600)), rng.standard_normal((100, 800)), rng.random((800, 100))
+    r1, r2 = np.arange(data1.shape[1]), np.arange(data2.shape[1])
+    out = oracle.adjust_shift_variance(data1, data2, corvect, sigma, r1, r2)
+    oracle.lib().orc_set_logspace_libm(1)
+    try:
+        out_libm = oracle.adjust_shift_variance(data1, data2, corvect, sigma, r1, r2)
+    finally:
+        oracle.lib().orc_set_logspace_libm(0)
+    moved = float((out != out_libm).mean())
+    with capsys.disabled():
+        print(f"\n[adjust_shift_variance {shape}, sigma {sigma}] cells moved by the math library: {moved:.4f}")
+    assert moved <= 0.01, moved
 
 
 def test_adjust_shift_variance_restrict_identity(oracle):
