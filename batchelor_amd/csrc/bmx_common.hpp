@@ -57,7 +57,8 @@ struct DevKnobs {
     int asv_fast = 0;         // adjust_shift_variance: the tiled form whatever the size
     int asv_cap = -1;         // tiled form: kept addends per chain of the literal re-run (-1: default, 0: no re-run)
     int asv_modes = 0;        // tiled form: record which way each of the first n cells of a call went (bmx_dev_get_bytes)
-    int asv_sync = 1;         // tiled form: the workgroups start each round of tiles together (0: free-running, round 5)
+    int asv_sync = 0;         // tiled form: 1 = the workgroups start each round of tiles together (measured slower twice: rounds 4 and 6)
+    int tau_replay = 0;       // developer experiment: 1 record every search's final thresholds, 2 start the full passes from them
     int sample_split = -1;    // ranges of the threshold sample of a search with few query blocks (-1: automatic, 0: never, n: that many)
     int exchange_always = 0;  // a single rank goes through its exchange transport too (an all-gather of one)
     int refine_wave = 0;      // the exact re-rank takes a whole wave for every query (no half-wave form)
@@ -331,6 +332,8 @@ struct KnnWorkspace {
     DevBuf<float> cand_v;          // [nq][C][KS] approximate values of the candidates (refine pre-ranks by them)
     DevBuf<uint32_t> tau_g;        // [nq] per-query thresholds shared across reference ranges
     DevBuf<float> margin;          // [nq] twice the fp16 pass's error bound per query, in the pass's own units
+    std::vector<DevBuf<uint32_t>> tau_rec;  // developer experiment "tau_replay": per search of a run, its queries' final thresholds
+    size_t replay_idx = 0;
     DevBuf<float> samp_lists;      // [nq][ranges][KS] a split threshold sample's per-range lists (knn_f16.hip: sample_merge_kernel)
     DevBuf<uint32_t> tau_seed;     // [nq] seeded search: each query's seed threshold in the pass's units (orderable image)
     bool slots_clean = false;      // maxslots is zero (knn_refine leaves it so behind an fp16 search)

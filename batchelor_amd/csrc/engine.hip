@@ -1132,6 +1132,7 @@ void Engine::run_once(const bmx_params_t& p, const int32_t* tree, int tree_len) 
     xchg_calls_ = xchg_bytes_ = 0;
     emu_next_ = 0;
     knn_ws_.events_used = 0;
+    knn_ws_.replay_idx = 0;
     asv_pairs_ = 0.0;
     vecs_.reserve((size_t)(2 * B_ + 8) * d_);
     // statistics slots (column means [d] + total variance) and batch.size scalars: a merge takes at most one per

@@ -773,6 +773,23 @@ __global__ void scatter_flagged(const int32_t* __restrict__ flagged, int n, int 
     if (dist_out) dist_out[o] = sub_dist[e];
 }
 
+// Developer experiment (testing hook "tau_replay", EXPERIMENTS.md round 6): what the full pass would cost if every query
+// STARTED from the threshold it ends with.  1: every search of a run records its queries' final thresholds (the smallest over
+// its reference ranges: each is at least the k-th best value of ITS range plus the margin, hence of the whole reference);
+// 2: the same sequence of searches starts its full passes from the recording.  Any valid threshold leaves the results as they
+// are; only the number of survivors changes.
+__global__ void tau_record_kernel(const float* __restrict__ tau, int nchunks, int nq, uint32_t* __restrict__ rec) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    float t = __builtin_inff();
+    for (int c = 0; c < nchunks; ++c) t = fminf(t, tau[(int64_t)q * nchunks + c]);
+    rec[q] = f32_orderable(t);
+}
+__global__ void tau_apply_kernel(const uint32_t* __restrict__ rec, int nq, uint32_t* __restrict__ tau_g) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < nq) tau_g[q] = min(tau_g[q], rec[q]);
+}
+
 #ifndef BMX_SEEDED_SAMPLE
 #define BMX_SEEDED_SAMPLE 4096
 #endif
@@ -973,7 +990,20 @@ void candidate_pass(hipStream_t stream, KnnWorkspace& ws, const Tier& T, const d
     L.n_full = C > 1 ? n_full : 0;
     L.r_limit = nr_pad;
     L.sample = 0;
+    const int replay = T.id == 1 ? dev_knobs().tau_replay : 0;
+    if (replay == 2 && ws.replay_idx < ws.tau_rec.size() && ws.tau_rec[ws.replay_idx].cap >= (size_t)nq_pad) {
+        hipLaunchKernelGGL(tau_apply_kernel, dim3(cdiv(nq_pad, 256)), dim3(256), 0, stream,
+                           (const uint32_t*)ws.tau_rec[ws.replay_idx].p, nq_pad, tau_g);
+        BMX_LAUNCH_CHECK();
+    }
     ok = ok && go(L);
+    if (replay == 1) {
+        if (ws.tau_rec.size() <= ws.replay_idx) ws.tau_rec.resize(ws.replay_idx + 1);
+        hipLaunchKernelGGL(tau_record_kernel, dim3(cdiv(nq_pad, 256)), dim3(256), 0, stream, (const float*)tau, nchunks, nq_pad,
+                           ws.tau_rec[ws.replay_idx].reserve((size_t)nq_pad));
+        BMX_LAUNCH_CHECK();
+    }
+    if (replay) ++ws.replay_idx;
     if (!ok) throw Error(BMX_ERR_ARG, "kNN: unsupported padded dimension");
     {
         // rows of an even number of doubles are 16-byte aligned: the quad gather, instantiated for the row length.  The queries
@@ -1385,6 +1415,172 @@ __global__ __launch_bounds__(256) void lk_merge_wave(const double* __restrict__ 
     }
 }
 
+// The merge for k beyond ~900 (`prop.k` = 0.05 of 100 000 cells is k = 5 000, R/MNN_tree.R:140-146): up to LKB_MAXE candidates a
+// query, one workgroup of 1 024 threads per query.  No rank counting (E x P binary searches would be 2e7 steps a query at
+// P = 358) and no sort of all E: every thread keeps its <= 14 candidates in registers; the k-th smallest (squared distance,
+// position) is found by bisection on the distances' bit patterns -- non-negative doubles order like unsigned integers; a round is
+// a count and a block reduction --, the k selected candidates are compacted into the LDS and only THEY are sorted (bitonic
+// network over the next power of two: 12 bytes an entry, 96 KB at k = 5 000).  The certificate is the partitioned search's: no
+// partition's last entry may be among the selected.
+constexpr int LKB_T = 1024;
+constexpr int LKB_PER = 14;                    // candidates a thread holds
+constexpr int LKB_MAXE = LKB_T * LKB_PER;      // 14 336
+constexpr int LKB_MAXK = 8192;                 // the sort's entries: 12 B x 8 192 = 96 KB of LDS
+
+__global__ __launch_bounds__(LKB_T) void lk_merge_big(const double* __restrict__ X, const int32_t* __restrict__ rows, int nr, int P,
+                                                      int kp, const double* __restrict__ Q, const int32_t* __restrict__ qrs,
+                                                      int nq, int d, int k, const int32_t* __restrict__ sub_idx,
+                                                      int32_t* __restrict__ idx_out, double* __restrict__ dist_out,
+                                                      int32_t* __restrict__ flagged, int32_t* __restrict__ opt,
+                                                      double* __restrict__ kth_out) {
+    extern __shared__ __attribute__((aligned(16))) char lkb_smem[];
+    __shared__ int sh_cnt[LKB_T / 64];
+    __shared__ int sh_fail, sh_base;
+    const int E = P * kp, q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int np2 = 1;
+    while (np2 < k) np2 <<= 1;
+    double* kd = reinterpret_cast<double*>(lkb_smem);    // [np2] the selected candidates, then sorted
+    int32_t* ki = reinterpret_cast<int32_t*>(kd + np2);  // [np2]
+    const double* qv = Q + (int64_t)(qrs ? qrs[q] : q) * d;
+    const int base = nr / P, rem = nr % P;
+    // ---- exact squared distances in the reference's order of operations; this thread's candidates stay in registers
+    unsigned long long mine[LKB_PER];
+    int gmine[LKB_PER];
+#pragma unroll
+    for (int u = 0; u < LKB_PER; ++u) {
+        const int e = tid + u * LKB_T;
+        unsigned long long bits = 0x7FF0000000000000ull;  // +inf: beyond E, or an empty place of a list
+        int g = 0x7fffffff;
+        if (e < E) {
+            const int p = e / kp, j = e - p * kp;
+            const int l = sub_idx[((int64_t)p * nq + q) * kp + j];
+            if (l >= 0) {
+                const double* x = X + (int64_t)rows[(int64_t)p * base + (p < rem ? p : rem) + l] * d;
+                double s_ = 0.0;
+                int c = 0;
+                for (; c + 8 <= d; c += 8) {
+                    double xv[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) xv[t] = x[c + t];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const double dd = qv[c + t] - xv[t];
+                        s_ += dd * dd;
+                    }
+                }
+                for (; c < d; ++c) {
+                    const double dd = qv[c] - x[c];
+                    s_ += dd * dd;
+                }
+                bits = (unsigned long long)__double_as_longlong(s_);
+                g = l * P + p;  // its position in the caller's reference list
+            }
+        }
+        mine[u] = bits;
+        gmine[u] = g;
+    }
+    // block-wide count of this thread's candidates that satisfy pred
+    auto count_block = [&](auto pred) -> int {
+        int c = 0;
+#pragma unroll
+        for (int u = 0; u < LKB_PER; ++u) c += pred(mine[u], gmine[u]) ? 1 : 0;
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+        __syncthreads();
+        if (lane == 0) sh_cnt[w] = c;
+        __syncthreads();
+        int t = 0;
+        for (int ww = 0; ww < LKB_T / 64; ++ww) t += sh_cnt[ww];
+        return t;
+    };
+    // ---- the k-th smallest distance: the smallest bit pattern with at least k candidates at or below it
+    unsigned long long vk = 0;
+    for (int b = 62; b >= 0; --b) {  // (bit 63 is the sign: never set)
+        const unsigned long long trial = vk | ((1ull << b) - 1ull);  // the largest value with the bits decided so far and this bit clear
+        const int c = count_block([&](unsigned long long v, int) { return v <= trial; });
+        if (c < k) vk |= 1ull << b;
+    }
+    // ... and among the candidates AT that distance the m with the smallest positions (exact duplicates: rare)
+    const int below = count_block([&](unsigned long long v, int) { return v < vk; });
+    const int ties = count_block([&](unsigned long long v, int) { return v == vk; });
+    int gk = 0x7fffffff;
+    if (ties > k - below) {
+        int lo = 0;  // the smallest position bound with at least k - below ties at or below it
+        for (int b = 30; b >= 0; --b) {
+            const int trial = lo | ((1 << b) - 1);
+            const int c = count_block([&](unsigned long long v, int g) { return v == vk && g <= trial; });
+            if (c < k - below) lo |= 1 << b;
+        }
+        gk = lo;
+    }
+    auto selected = [&](unsigned long long v, int g) { return v < vk || (v == vk && g <= gk); };
+    // ---- the certificate: no partition's last entry among the selected (it sits at e = p kp + kp - 1)
+    if (tid == 0) sh_fail = 0;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < LKB_PER; ++u) {
+        const int e = tid + u * LKB_T;
+        if (e < E && (e % kp) == kp - 1 && selected(mine[u], gmine[u])) sh_fail = 1;
+    }
+    // ---- the selected to the front (k of them: vk is finite whenever k <= the candidates there are), sorted
+    if (tid == 0) sh_base = 0;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < LKB_PER; ++u) {
+        const bool s1 = selected(mine[u], gmine[u]);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(s1);
+        if (lane == 0) sh_cnt[w] = __popcll(m);
+        __syncthreads();
+        int off = sh_base;
+        for (int ww = 0; ww < w; ++ww) off += sh_cnt[ww];
+        if (s1) {
+            const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
+            kd[pos] = __longlong_as_double((long long)mine[u]);
+            ki[pos] = gmine[u];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int t = 0;
+            for (int ww = 0; ww < LKB_T / 64; ++ww) t += sh_cnt[ww];
+            sh_base += t;
+        }
+        __syncthreads();
+    }
+    for (int i = k + tid; i < np2; i += LKB_T) {
+        kd[i] = __builtin_inf();
+        ki[i] = 0x7fffffff;
+    }
+    __syncthreads();
+    for (int kk = 2; kk <= np2; kk <<= 1)
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < np2; i += LKB_T) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const double a = kd[i], b = kd[ixj];
+                    const int ia = ki[i], ib = ki[ixj];
+                    const bool gt = a > b || (a == b && ia > ib);
+                    if (((i & kk) == 0) ? gt : !gt) {
+                        kd[i] = b;
+                        kd[ixj] = a;
+                        ki[i] = ib;
+                        ki[ixj] = ia;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    for (int r = tid; r < k; r += LKB_T) {
+        idx_out[(int64_t)q * k + r] = ki[r];
+        if (dist_out) dist_out[(int64_t)q * k + r] = sqrt(kd[r]);
+    }
+    if (tid == 0) {
+        if (kth_out) kth_out[q] = sh_fail ? __builtin_inf() : sqrt(kd[k - 1]);
+        if (sh_fail) {
+            if (opt) atomicOr(opt, 1);
+            else flagged[1 + atomicAdd(&flagged[0], 1)] = q;
+        }
+    }
+}
+
 // false: the shape does not suit the partitioned search (too few reference cells a partition, too many candidates)
 bool large_k_search(hipStream_t stream, KnnWorkspace& ws, const double* X, const int32_t* ref_rows, int nr, const double* Qs,
                     const int32_t* qrs, int nq, int d, int k, int32_t* io, double* dout, const double* centre,
@@ -1394,8 +1590,12 @@ bool large_k_search(hipStream_t stream, KnnWorkspace& ws, const double* X, const
     Tier tiers[2];
     int kp = 36;
     if (candidate_tiers(d, kp, std::max(nr / cdiv(k, 16), 1), tiers) == 0) kp = 20;
-    const int P = std::max(2, cdiv(k, kp == 36 ? 16 : 9));
-    if ((int64_t)P * kp > LK_MAXE || nr / P < 4 * kp) return false;
+    int P = std::max(2, cdiv(k, kp == 36 ? 16 : 9));
+    // beyond what the rank-counting merges take (2 048 candidates): the big merge, with partitions dealt a little finer -- 14
+    // (8) of a query's k each on average -- so that a partition holding all kp of them is rarer still (one such query would
+    // send an optimistic engine run back to its start)
+    if ((int64_t)P * kp > LK_MAXE) P = cdiv(k, kp == 36 ? 14 : 8);
+    if ((int64_t)P * kp > LKB_MAXE || k > LKB_MAXK || nr / P < 4 * kp) return false;
     if (candidate_tiers(d, kp, nr / P, tiers) == 0) return false;
     int32_t* rows = ws.lk_rows.reserve((size_t)nr);
     int32_t* sub = ws.lk_idx.reserve((size_t)P * nq * kp);
@@ -1411,7 +1611,14 @@ bool large_k_search(hipStream_t stream, KnnWorkspace& ws, const double* X, const
     int32_t* flagged = ws.flagged_t[0].reserve((size_t)nq + 1);
     int32_t* opt = ws.optimistic ? ws.opt_state_ptr(stream) : nullptr;
     if (!opt) BMX_HIP(hipMemsetAsync(flagged, 0, sizeof(int32_t), stream));
-    if (P * kp <= 512)
+    if (P * kp > LK_MAXE) {
+        size_t np2 = 1;
+        while (np2 < (size_t)k) np2 <<= 1;
+        const size_t lds = np2 * 12;
+        ensure_dynamic_lds(reinterpret_cast<const void*>(&lk_merge_big), lds);
+        hipLaunchKernelGGL(lk_merge_big, dim3(nq), dim3(LKB_T), lds, stream, X, (const int32_t*)rows, nr, P, kp, Qs, qrs, nq, d, k,
+                           (const int32_t*)sub, io, dout, flagged, opt, kth_out);
+    } else if (P * kp <= 512)
         hipLaunchKernelGGL(lk_merge_wave, dim3(cdiv(nq, 4)), dim3(256), 0, stream, X, (const int32_t*)rows, nr, P, kp, Qs, qrs, nq,
                            d, k, (const int32_t*)sub, io, dout, flagged, opt, kth_out);
     else

@@ -19,7 +19,6 @@
 #include "portable_math.hpp"
 
 #include <algorithm>
-#include <type_traits>
 #include <mutex>
 #include <cstdlib>
 
@@ -135,13 +134,57 @@ __global__ __launch_bounds__(256) void sgk_flash(const double* __restrict__ X, i
             __syncthreads();
         }
     }
+    // Round 6 (NKB > 0): the NEXT tile's MNN rows, norms, densities and averaged vectors are on their way into registers while
+    // this tile multiplies.  Before, a tile was four dependent round trips to the L2 (row ids, the rows of each 32-gene step,
+    // the averaged vectors) with two workgroups per CU to hide them: 35 us a tile against 3.4 us of matrix work.
+    constexpr int AVN = APPLY ? 64 * SG_GT / 256 : 1;  // averaged values a thread stages per tile
+    double pm[NKB > 0 ? NKB * 8 : 1], pav[NKB > 0 ? AVN : 1], pmi = 0.0, pdi = 0.0;
+    auto fetch_rows = [&](int i0n, int kb) __attribute__((always_inline)) {
+        const int64_t mrow = i0n + lr < U ? index[i0n + lr] : -1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = kb * SG_KC + seg + e;
+            pm[kb * 8 + e] = (mrow >= 0 && k < gd) ? X[mrow * gd + k] : 0.0;
+        }
+    };
+    auto fetch_rest = [&](int i0n) __attribute__((always_inline)) {
+        if (tid < 64) {
+            const int64_t r = i0n + tid < U ? index[i0n + tid] : -1;
+            pmi = r >= 0 ? xn2[r] : 0.0;
+            pdi = (r >= 0 && dens) ? dens[i0n + tid] : 0.0;
+        }
+        if constexpr (APPLY) {
+#pragma unroll
+            for (int j = 0; j < AVN; ++j) {
+                const int e = tid + j * 256, ii = e / SG_GT, gg = e - ii * SG_GT;
+                pav[j] = (i0n + ii < U && g0 + gg < g) ? Av[(int64_t)(i0n + ii) * g + g0 + gg] : 0.0;
+            }
+        }
+    };
+    if constexpr (NKB > 0) {
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) fetch_rows(0, kb);
+        fetch_rest(0);
+    }
     for (int i0 = 0; i0 < U; i0 += 64) {
         // ---- scores: S_t[reg] = m_i . x_c, i = i0 + 16 t + 4 reg + (lane >> 4), c = cl
         d4 S[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) S[t] = d4{0.0, 0.0, 0.0, 0.0};
-        const int64_t mrow = i0 + lr < U ? index[i0 + lr] : -1;
-        if (tid < 64) {
+        const int64_t mrow = (NKB > 0) ? -1 : (i0 + lr < U ? index[i0 + lr] : -1);
+        if constexpr (NKB > 0) {
+            if (tid < 64) {
+                mi2[tid] = pmi;
+                di[tid] = pdi;
+            }
+            if constexpr (APPLY) {
+#pragma unroll
+                for (int j = 0; j < AVN; ++j) {
+                    const int e = tid + j * 256, ii = e / SG_GT, gg = e - ii * SG_GT;
+                    as_[ii * PA + gg] = pav[j];
+                }
+            }
+        } else if (tid < 64) {
             const int64_t r = i0 + tid < U ? index[i0 + tid] : -1;
             mi2[tid] = r >= 0 ? xn2[r] : 0.0;
             di[tid] = (r >= 0 && dens) ? dens[i0 + tid] : 0.0;
@@ -150,11 +193,12 @@ __global__ __launch_bounds__(256) void sgk_flash(const double* __restrict__ X, i
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int k = kb * SG_KC + seg + e;
-                    ms[lr * P + seg + e] = (mrow >= 0 && k < gd) ? X[mrow * gd + k] : 0.0;
-                }
+                for (int e = 0; e < 8; ++e) ms[lr * P + seg + e] = pm[kb * 8 + e];
                 __syncthreads();
+                // (this step's registers are free: the next tile's rows of the same step are asked for; the last tile asks for
+                // nothing -- rows beyond U read as zeros without a load)
+                fetch_rows(i0 + 64, kb);
+                if (kb == NKB - 1) fetch_rest(i0 + 64);
 #pragma unroll
                 for (int kk = 0; kk < SG_KC / 4; ++kk) {
 #pragma unroll
@@ -186,7 +230,7 @@ __global__ __launch_bounds__(256) void sgk_flash(const double* __restrict__ X, i
             __syncthreads();
         }
         }
-        if constexpr (APPLY) {
+        if constexpr (APPLY && NKB == 0) {
             // stage the averaged vectors of this MNN tile: as_[i][gene]
             for (int e = tid; e < 64 * SG_GT; e += 256) {
                 const int ii = e / SG_GT, gg = e - ii * SG_GT;
@@ -430,14 +474,7 @@ constexpr int AT_CAP = 2048;    // collected entries of the crossing bin
 constexpr int AT_U = 8;         // scratch elements per thread and batch in the per-cell passes (two batches in flight)
 
 constexpr int AT_NP = 2 * AT_R; // the stream is padded to whole pairs of steps (zero rows)
-// Threads of the TILED form's workgroup (round 6): EIGHT waves, two per SIMD.  With one wave per SIMD (rounds 3-5) the matrix
-// pipe idled through every step's epilogue -- ~700 vector instructions (distances, the division by sigma, the own batch's exp,
-// maxima, stores) between two blocks of 52 FP64 MFMAs that only this wave could have issued: the stream ran at 2.0x its
-// matrix floor (measured by phase: scripts/asv_phase_probe.py).  Now a SIMD's two waves take alternate 64-row blocks of the
-// stream and one's epilogue runs under the other's MFMAs.  The per-cell phase has twice the loads in flight.
-constexpr int TT = 512;
-constexpr int AT_W = TT / 64;   // waves
-constexpr int AT_SM = AT_W * AT_C * 6;  // doubles of the block-reduction area: six values per (wave, cell) after the stream (>= TT)
+constexpr int AT_SM = 4 * AT_C * 6;  // doubles of the block-reduction area: six values per (wave, cell) after the stream (>= T)
 
 __host__ __device__ inline int asv_tile_gp(int g) { return (g + AT_KC - 1) / AT_KC * AT_KC + 2; }
 __host__ __device__ inline int asv_tile_nb8(int g) { return g <= 128 ? (g + 7) / 8 : 0; }  // 8-dimension blocks of a row; 0: the staged form
@@ -469,12 +506,12 @@ __host__ __device__ inline int64_t asv_tile_list_doubles(int lcap) { return (int
 inline size_t asv_tile_lds_bytes(int g, int lcap) {
     const int nb8 = asv_tile_nb8(g);
     return ((size_t)2 * AT_C * asv_tile_gp(g) + (size_t)asv_tile_ub_doubles(g, lcap) +
-            (nb8 == 0 ? (size_t)2 * AT_R * (AT_KC + 2) : 0) + 8 * AT_C + AT_SM) * sizeof(double) +
+            (nb8 == 0 ? (size_t)AT_R * (AT_KC + 2) : 0) + 8 * AT_C + AT_SM) * sizeof(double) +
            (size_t)2 * AT_NB * sizeof(unsigned long long);
 }
 
 // The weighted-quantile walk (src/adjust_shift_variance.cpp:137-157: the first entry at which the cumulative weight reaches
-// the target) over up to 8 TT integer weights in the LDS, by the whole block instead of one thread going entry by entry:
+// the target) over up to 8 T integer weights in the LDS, by the whole block instead of one thread going entry by entry:
 // every thread sums its eight consecutive entries, a scan over the threads gives each its starting weight, the thread whose
 // stretch holds the first crossing reports it.  Integer sums: the result is what the sequential walk finds.
 // target_of(total weight of v) -> target.  Returns the index (-1: never reached), *cum_before = base + weight before it.
@@ -499,7 +536,7 @@ __device__ __forceinline__ int asv_first_crossing(const unsigned long long* v, i
     if (tid == 0) *sh_idx = 0x7fffffff;
     __syncthreads();
     unsigned long long woff = 0, total = 0;
-    for (int ww = 0; ww < TT / 64; ++ww) {
+    for (int ww = 0; ww < T / 64; ++ww) {
         const unsigned long long t = smu[ww];
         total += t;
         if (ww < w) woff += t;
@@ -523,7 +560,7 @@ __device__ __forceinline__ int asv_first_crossing(const unsigned long long* v, i
 }
 
 // One cell's scratch row, elements [jstart, jstart + n) of the stream, past the block: thread t visits jstart + t,
-// + TT, ... in batches of AT_U, the next batch on its way while the current one is consumed (one wave per SIMD: nothing
+// + T, ... in batches of AT_U, the next batch on its way while the current one is consumed (one wave per SIMD: nothing
 // else hides the round trip to the scratch).  Straight-line code: every load is issued (block numbers clamped to the
 // row's last block) and `proc` gets the element number to tell the ones beyond n -- with the loads or their first use
 // under per-element branches the compiler waited for ALL outstanding loads before the first use: no overlap at all.
@@ -538,7 +575,7 @@ __device__ __forceinline__ void asv_row_scan(const double* __restrict__ P, const
     auto fetch = [&](double (&p)[AT_U], double (&w)[AT_U], int o0) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < AT_U; ++u) {
-            const int o = o0 + u * TT;  // (o - tid is a multiple of TT = 4 blocks)
+            const int o = o0 + u * T;  // (o - tid is a multiple of T = 4 blocks)
             int jb = jb_t + ((o - tid) >> 6);
             jb = jb < last_block ? jb : last_block;
             const int64_t off = (int64_t)jb * (AT_C * 64) + (((crot + jb) & (AT_C - 1)) << 6) + jlow;
@@ -548,14 +585,14 @@ __device__ __forceinline__ void asv_row_scan(const double* __restrict__ P, const
     };
     auto consume = [&](const double (&p)[AT_U], const double (&w)[AT_U], int o0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int u = 0; u < AT_U; ++u) proc(p[u], w[u], o0 + u * TT);
+        for (int u = 0; u < AT_U; ++u) proc(p[u], w[u], o0 + u * T);
     };
     fetch(pa, wa, tid);
-    for (int o0 = tid; o0 < n; o0 += 2 * AT_U * TT) {
-        fetch(pb, wb, o0 + AT_U * TT);
+    for (int o0 = tid; o0 < n; o0 += 2 * AT_U * T) {
+        fetch(pb, wb, o0 + AT_U * T);
         consume(pa, wa, o0);
-        fetch(pa, wa, o0 + 2 * AT_U * TT);
-        consume(pb, wb, o0 + AT_U * TT);
+        fetch(pa, wa, o0 + 2 * AT_U * T);
+        consume(pb, wb, o0 + AT_U * T);
     }
 }
 
@@ -649,11 +686,11 @@ __device__ __forceinline__ void asv_sort_global(E* a, int np2, E* win, int B, in
     // the steps j = jtop, jtop / 2, ..., 1 of stage k inside every window (jtop < B)
     auto windows = [&](int k_lo, int k_hi, bool all_steps) {
         for (int w0 = 0; w0 < np2; w0 += B) {
-            for (int i = tid; i < B; i += TT) win[i] = a[w0 + i];
+            for (int i = tid; i < B; i += T) win[i] = a[w0 + i];
             __syncthreads();
             for (int k = k_lo; k <= k_hi; k <<= 1)
                 for (int j = all_steps ? (k >> 1) : (B >> 1); j > 0; j >>= 1) {
-                    for (int p = tid; p < B / 2; p += TT) {
+                    for (int p = tid; p < B / 2; p += T) {
                         const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1)), q = i | j;
                         const E x = win[i], y = win[q];
                         const bool up = ((w0 + i) & k) == 0;
@@ -664,7 +701,7 @@ __device__ __forceinline__ void asv_sort_global(E* a, int np2, E* win, int B, in
                     }
                     __syncthreads();
                 }
-            for (int i = tid; i < B; i += TT) a[w0 + i] = win[i];
+            for (int i = tid; i < B; i += T) a[w0 + i] = win[i];
             __syncthreads();
         }
         pass_done();
@@ -674,7 +711,7 @@ __device__ __forceinline__ void asv_sort_global(E* a, int np2, E* win, int B, in
     for (int k = 2 * B; k <= np2; k <<= 1) {
         for (int j = k >> 1; j >= B; j >>= 1) {
 #pragma unroll 4
-            for (int p = tid; p < np2 / 2; p += TT) {
+            for (int p = tid; p < np2 / 2; p += T) {
                 const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1)), q = i | j;
                 const E x = a[i], y = a[q];
                 const bool sw = ((i & k) == 0) ? less(y, x) : less(x, y);
@@ -689,7 +726,7 @@ __device__ __forceinline__ void asv_sort_global(E* a, int np2, E* win, int B, in
 
 // asv_row_scan in PIECES with a block-wide step in the middle of each: `pre` sees every element of a piece, then `hook(end)`
 // runs -- it may synchronise the block (every thread makes every call, the loop bounds are uniform) and returns true to end
-// the scan --, then `test` sees the piece's elements again (they are still in registers).  A piece is a row of TT elements
+// the scan --, then `test` sees the piece's elements again (they are still in registers).  A piece is a row of T elements
 // over the first two batches (the bounds of a chain tighten fastest at its start) and a batch of AT_U rows from then on.
 template <class Load, class Pre, class Hook, class Test>
 __device__ __forceinline__ void asv_row_scan_pieces(Load load, int64_t jstart, int n, int crot, int last_block, int tid,
@@ -700,7 +737,7 @@ __device__ __forceinline__ void asv_row_scan_pieces(Load load, int64_t jstart, i
     auto fetch = [&](double (&p)[AT_U], double (&w)[AT_U], int base) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < AT_U; ++u) {
-            int jb = jb_t + ((base + u * TT) >> 6);
+            int jb = jb_t + ((base + u * T) >> 6);
             jb = jb < last_block ? jb : last_block;
             const int64_t off = (int64_t)jb * (AT_C * 64) + (((crot + jb) & (AT_C - 1)) << 6) + jlow;
             load(off, p[u], w[u]);
@@ -708,30 +745,30 @@ __device__ __forceinline__ void asv_row_scan_pieces(Load load, int64_t jstart, i
     };
     bool stop = false;
     auto consume = [&](const double (&p)[AT_U], const double (&w)[AT_U], int base) __attribute__((always_inline)) {
-        if (base < 2 * AT_U * TT) {
+        if (base < 2 * AT_U * T) {
 #pragma unroll
             for (int u = 0; u < AT_U; ++u) {
                 if (stop) break;
-                pre(p[u], w[u], base + u * TT + tid);
-                stop = hook(base + (u + 1) * TT);
-                if (!stop) test(p[u], w[u], base + u * TT + tid);
+                pre(p[u], w[u], base + u * T + tid);
+                stop = hook(base + (u + 1) * T);
+                if (!stop) test(p[u], w[u], base + u * T + tid);
             }
         } else {
 #pragma unroll
-            for (int u = 0; u < AT_U; ++u) pre(p[u], w[u], base + u * TT + tid);
-            stop = hook(base + AT_U * TT);
+            for (int u = 0; u < AT_U; ++u) pre(p[u], w[u], base + u * T + tid);
+            stop = hook(base + AT_U * T);
             if (!stop) {
 #pragma unroll
-                for (int u = 0; u < AT_U; ++u) test(p[u], w[u], base + u * TT + tid);
+                for (int u = 0; u < AT_U; ++u) test(p[u], w[u], base + u * T + tid);
             }
         }
     };
     fetch(pa, wa, 0);
-    for (int base = 0; base < n && !stop; base += 2 * AT_U * TT) {
-        fetch(pb, wb, base + AT_U * TT);
+    for (int base = 0; base < n && !stop; base += 2 * AT_U * T) {
+        fetch(pb, wb, base + AT_U * T);
         consume(pa, wa, base);
-        fetch(pa, wa, base + 2 * AT_U * TT);
-        if (base + AT_U * TT < n && !stop) consume(pb, wb, base + AT_U * TT);
+        fetch(pa, wa, base + 2 * AT_U * T);
+        if (base + AT_U * T < n && !stop) consume(pb, wb, base + AT_U * T);
     }
 }
 
@@ -789,7 +826,7 @@ __global__ __launch_bounds__(256) void asv_max_norm(double* __restrict__ snrm, i
 __device__ unsigned long long g_asv_ticks[4];
 
 template <int NB8>
-__global__ __launch_bounds__(TT) void asv_tile_kernel(int g, const double* __restrict__ data2, int n2,
+__global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __restrict__ data2, int n2,
                                                      const double* __restrict__ vect, double sigma2, int nr1, int nr2,
                                                      const double* __restrict__ S, const double* __restrict__ snrm,
                                                      const int32_t* __restrict__ sid, double* __restrict__ out,
@@ -805,8 +842,8 @@ __global__ __launch_bounds__(TT) void asv_tile_kernel(int g, const double* __res
     const int ub_doubles = asv_tile_ub_doubles(g, lcap);
     double* lp = ub;                                                             // [CAP] collected projections
     unsigned long long* lw_ = reinterpret_cast<unsigned long long*>(lp + AT_CAP);  // [CAP] and their weights
-    double* rs = ub + ub_doubles;  // [128][KC + 2] a step of streamed cells (staged form only)
-    double* sc_proj = rs + (NB8 == 0 ? 2 * AT_R * (AT_KC + 2) : 0);  // per cell: own projection, |x|^2, |vect|, maxima, projection range
+    double* rs = ub + ub_doubles;  // [64][KC + 2] a step of streamed cells (staged form only)
+    double* sc_proj = rs + (NB8 == 0 ? AT_R * (AT_KC + 2) : 0);  // per cell: own projection, |x|^2, |vect|, maxima, projection range
     double* sc_n = sc_proj + AT_C;
     double* sc_l2 = sc_n + AT_C;
     double* sc_mx1 = sc_l2 + AT_C;
@@ -851,7 +888,7 @@ __global__ __launch_bounds__(TT) void asv_tile_kernel(int g, const double* __res
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int c0 = cell_begin + tile * AT_C;
         // ---- the tile's cells: coordinates, unit gradient (:57-70), own projection
-        for (int e = tid; e < AT_C * GP; e += TT) {
+        for (int e = tid; e < AT_C * GP; e += T) {
             const int c = e / GP, x = e - c * GP;
             const bool in = c0 + c < n2 && x < g;
             cx[e] = in ? data2[(int64_t)(c0 + c) * g + x] : 0.0;
@@ -874,14 +911,13 @@ __global__ __launch_bounds__(TT) void asv_tile_kernel(int g, const double* __res
             sc_n[tid] = nn;
         }
         __syncthreads();
-        // ---- the workgroups start the stream of their round's tiles TOGETHER (round 6).  Every tile streams the same matrix
-        // S from its first row; workgroups that start at different times (their per-cell phases differ) each pull it from HBM
-        // on their own -- 32 TB of a config-5 step's 51 (pairs / 16 cells x 832 bytes a padded row; PMC: 41 TB read at
-        // 5.2 TB/s, the kernel sat on the HBM roof).  Started together they run in convoy: a step costs every workgroup the
-        // same 104 matrix instructions per wave, the first to ask for a row brings it into its XCD's L2 and the other 31
-        // workgroups of the XCD find it there (the leader waits for HBM, the followers do not: the convoy closes up by
-        // itself).  One arrival per TILE on a device word zeroed before the launch; the tiles of round r go on when all tiles
-        // of rounds <= r have arrived (or 50 ms have gone by).  gbar is null when the launch is wider than the device (host side).
+        // ---- testing hook "asv_sync" (OFF by default): the workgroups start the stream of their round's tiles TOGETHER and
+        // run in convoy, the first to ask for a row of S brings it into its XCD's L2 for the other 31.  That halves the kernel's
+        // HBM reads (PMC: 3.36 -> 1.56 TB on a mid-size call) and leaves its time where it was -- the stream's loads are
+        // prefetched a block ahead and hidden either way -- while the spread of the per-cell phases becomes idle time every
+        // round (config 5: 9.94 -> 10.78 s per step; rounds 4 and 6, EXPERIMENTS.md).  One arrival per TILE on a device word
+        // zeroed before the launch; the tiles of round r go on when all tiles of rounds <= r have arrived (or 50 ms have gone
+        // by).  gbar is null unless the hook is on and the launch is no wider than the device.
         tk0 = __builtin_amdgcn_s_memrealtime();
         if (gbar) {
             if (tid == 0) {
@@ -928,27 +964,6 @@ __global__ __launch_bounds__(TT) void asv_tile_kernel(int g, const double* __res
             for (int c = 0; c < AT_C; ++c) cmx = fmax(cmx, sc_n[c]);
             tol_tile = 1e-13 * (1.0 + cmx + snrm[Npad]);
         }
-        // the partial log-sum-exps of the 16 lanes that share a cell: to their common maximum, then added; parked per (wave,
-        // cell) in the block-reduction area (nobody else uses it during the stream) -- see the reduction behind the stream
-        auto own_done = [&]() __attribute__((always_inline)) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                for (int o = 1; o < 16; o <<= 1) {
-                    const double pm = __shfl_xor(om[i], o), pa = __shfl_xor(oa[i], o), pb = __shfl_xor(ob[i], o);
-                    const double mm = fmax(om[i], pm);
-                    const double f0 = om[i] == mm ? 1.0 : exp(om[i] - mm), f1 = pm == mm ? 1.0 : exp(pm - mm);
-                    oa[i] = oa[i] * f0 + pa * f1;
-                    ob[i] = ob[i] * f0 + pb * f1;
-                    om[i] = mm;
-                }
-                if ((lane & 15) == 0) {
-                    const int c = (lane >> 4) + 4 * i;
-                    sm[(w * AT_C + c) * 6 + 3] = om[i];
-                    sm[(w * AT_C + c) * 6 + 4] = oa[i];
-                    sm[(w * AT_C + c) * 6 + 5] = ob[i];
-                }
-            }
-        };
         if constexpr (NB8 > 0) {
             typedef double d2a __attribute__((ext_vector_type(2)));
             constexpr int GS = NB8 * 8;  // row stride of the stream (zero filled beyond g)
@@ -965,7 +980,7 @@ __global__ __launch_bounds__(TT) void asv_tile_kernel(int g, const double* __res
                     agr[st] = cg[(lane & 15) * GP + k];
                 }
             } else {
-                for (int e = tid; e < NST * 64; e += TT) {
+                for (int e = tid; e < NST * 64; e += T) {
                     const int st = e >> 6, ln = e & 63;
                     const int k = 8 * (st >> 1) + 2 * (ln >> 4) + (st & 1);
                     cxp[e] = cx[(ln & 15) * GP + k];
@@ -975,8 +990,7 @@ __global__ __launch_bounds__(TT) void asv_tile_kernel(int g, const double* __res
             }
             // this lane's streamed cell of step j0 is j0 + jl; rows, norms, ids and scratch are padded to whole pairs of
             // steps: no bounds checks (and no divergent branches) in the stream
-            // (wave w: rows 16 (w & 3) .. + 15 of the 64-row blocks w >> 2, w >> 2 + 2, ...: a SIMD's two waves alternate blocks)
-            const int jl = 16 * (w & 3) + (lane & 15);
+            const int jl = 16 * w + (lane & 15);
             const double* srow = S + (int64_t)jl * GS + 2 * kq;
             double* spo = SP + jl;
             double* swo = SW + jl;
@@ -990,21 +1004,12 @@ __global__ __launch_bounds__(TT) void asv_tile_kernel(int g, const double* __res
                     b[2 * q + 1] = v[1];
                 }
             };
-            // One 64-row block of the stream for this wave's 16 rows of it.  MODE (round 6: one loop per kind of block instead of
-            // per-element selects -- each loop keeps only its own running state in registers and its own half of the epilogue):
-            //   0 every row of the block belongs to the OWN batch: the online log-sum-exps (and the float codes of the re-run);
-            //   1 a block that holds the end of the own batch (or rows of both kinds, or padding): everything, by selects;
-            //   2 every row belongs to the REFERENCE batch: maxima, projection range, the scratch stores;
-            //   3 reference rows and the stream's zero padding behind them.
-            auto step = [&](auto mode_tag, double (&b)[NST], int64_t j0) __attribute__((always_inline)) {
-                constexpr int MODE = decltype(mode_tag)::value;
+            auto step = [&](const double (&b)[NST], double (&bn)[NST], int64_t j0) __attribute__((always_inline)) {
                 const int64_t jo = j0 + jl;
-                // this wave's next block is two blocks on (the last one asks for its own again); its rows are asked for piece by
-                // piece, each right behind the two MFMAs that consumed the registers it lands in: one row set, no second buffer
-                const double* nsrc = srow + (j0 + 2 * AT_R < Npad ? (j0 + 2 * AT_R) : j0) * GS;
+                // the next step's rows are on their way while this one multiplies (the last step asks for its own again)
+                load_rows(bn, srow + (j0 + AT_R < Npad ? (j0 + AT_R) : j0) * GS);
                 const double no = snrm[jo];
-                int rid = -1;
-                if constexpr (MODE <= 1) rid = sid[jo];
+                const int rid = sid[jo];
                 // two accumulator pairs (k-steps alternate): D and P chains are independent of each other as well
                 d4 Dq[2], Pq[2];
 #pragma unroll
@@ -1021,27 +1026,16 @@ __global__ __launch_bounds__(TT) void asv_tile_kernel(int g, const double* __res
                     }
                     Dq[st & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, b[st], Dq[st & 1], 0, 0, 0);
                     Pq[st & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ag, b[st], Pq[st & 1], 0, 0, 0);
-                    if (st & 1) {  // both values of this 8-dimension block are consumed: the next block's piece takes their place
-                        const d2a v = *reinterpret_cast<const d2a*>(nsrc + 8 * (st >> 1));
-                        b[st - 1] = v[0];
-                        b[st] = v[1];
-                    }
                     if constexpr (NB8 > 8)
                         if ((st & 7) == 7)
                             __builtin_amdgcn_sched_barrier(0);  // (keeps the A operands of 32 dimensions live at a time)
                 }
-                const bool own = MODE == 0 ? true : (MODE >= 2 ? false : jo < nr2);
-                const bool ref = MODE == 0 ? false : (MODE == 2 ? true : (!own && jo < N));
+                const bool own = jo < nr2, ref = !own && jo < N;
                 const int blk = (int)(j0 >> 6);
                 f4 oc = f4{0.f, 0.f, 0.f, 0.f};
                 (void)tol_tile;
                 double* sp_ = spo + (int64_t)blk * (AT_C * 64);
                 double* sw_ = swo + (int64_t)blk * (AT_C * 64);
-#ifdef BMX_ASV_X_BARE  // (timing build: the MFMA chains and the row loads only; the accumulators are kept alive by one max)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) mx1[i] = fmax(mx1[i], (Pq[0][i] + Pq[1][i]) + (Dq[0][i] + Dq[1][i]) + no);
-                if (MODE == 99)
-#endif
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {  // this lane: streamed cell jo, tile cells (lane >> 4) + 4 i
                     double pr = Pq[0][i] + Pq[1][i];
@@ -1050,36 +1044,25 @@ __global__ __launch_bounds__(TT) void asv_tile_kernel(int g, const double* __res
                     double d2 = (cn[i] + no) - 2.0 * dd - s_ * s_;
                     d2 = d2 > 0.0 ? d2 : 0.0;
                     double lw = -d2 / sigma2;
-                    bool self = false;
-                    if constexpr (MODE <= 1) {
-                        self = rid == c0 + kq + 4 * i;  // the cell itself: log-weight 0, always counted (:80-84)
-                        lw = self ? 0.0 : lw;
-                        pr = self ? NEG : pr;
-                    }
-                    if constexpr (MODE >= 1) {
-                        // (selects, not branches: the padding rows of the stream belong to neither batch)
-                        mx1[i] = fmax(mx1[i], ref ? lw : NEG);
-                        lo[i] = fmin(lo[i], ref ? pr : POS);
-                        hi[i] = fmax(hi[i], ref ? pr : NEG);
-                    }
-                    if constexpr (MODE <= 1) {
-                        if (own) {  // (whole waves but for the one block where the own batch ends)
-                            if (lw > om[i]) {  // a new maximum: rare once the cell itself (log-weight 0) has gone by
-                                const double f = exp(om[i] - lw);  // exp(-inf) = 0 the first time
-                                oa[i] *= f;
-                                ob[i] *= f;
-                                om[i] = lw;
-                            }
-                            const double e = exp(lw - om[i]);
-                            oa[i] += e;
-                            ob[i] += !(pr > cp[i]) ? e : 0.0;
+                    const bool self = rid == c0 + kq + 4 * i;  // the cell itself: log-weight 0, always counted (:80-84)
+                    lw = self ? 0.0 : lw;
+                    pr = self ? NEG : pr;
+                    // (selects, not branches: the padding rows of the stream belong to neither batch)
+                    mx1[i] = fmax(mx1[i], ref ? lw : NEG);
+                    lo[i] = fmin(lo[i], ref ? pr : POS);
+                    hi[i] = fmax(hi[i], ref ? pr : NEG);
+                    if (own) {  // (whole waves but for the one step where the own batch ends)
+                        if (lw > om[i]) {  // a new maximum: rare once the cell itself (log-weight 0) has gone by
+                            const double f = exp(om[i] - lw);  // exp(-inf) = 0 the first time
+                            oa[i] *= f;
+                            ob[i] *= f;
+                            om[i] = lw;
                         }
+                        const double e = exp(lw - om[i]);
+                        oa[i] += e;
+                        ob[i] += !(pr > cp[i]) ? e : 0.0;
                     }
-#ifdef BMX_ASV_X_NOSTORE  // (timing build: the scratch stores only when a value is NaN, i.e. never -- results are wrong)
-                    if (!own && pr != pr) {
-#else
                     if (!own) {
-#endif
                         const int slot = (kq + 4 * i + blk + rot0) & (AT_C - 1);  // == at(kq + 4 i, jo)
                         sp_[slot * 64] = pr;
                         sw_[slot * 64] = lw;
@@ -1090,25 +1073,16 @@ __global__ __launch_bounds__(TT) void asv_tile_kernel(int g, const double* __res
                     }
                 }
                 // (this lane's four cells kq, kq + 4, kq + 8, kq + 12 of one streamed cell: one 16-byte store, 16 lanes a 256-byte run)
-#ifdef BMX_ASV_X_NOSTORE
-                if (own && lit_on && oc[0] != oc[0]) so_[(int64_t)blk * (AT_C * 16)] = oc;
-#else
                 if (own && lit_on) so_[(int64_t)blk * (AT_C * 16)] = oc;
-#endif
             };
-            double ba[NST];
-            int64_t j0 = (int64_t)(w >> 2) * AT_R;
-            load_rows(ba, srow + j0 * GS);
-            for (; j0 + AT_R <= nr2; j0 += 2 * AT_R) step(std::integral_constant<int, 0>{}, ba, j0);
-            if (j0 < nr2) {
-                step(std::integral_constant<int, 1>{}, ba, j0);
-                j0 += 2 * AT_R;
+            double ba[NST], bb[NST];
+            load_rows(ba, srow);
+            for (int64_t j0 = 0; j0 < Npad; j0 += 2 * AT_R) {
+                step(ba, bb, j0);
+                step(bb, ba, j0 + AT_R);
             }
-            own_done();  // (the own batch's sums leave the registers: the reference loop runs without them)
-            for (; j0 + AT_R <= N; j0 += 2 * AT_R) step(std::integral_constant<int, 2>{}, ba, j0);
-            for (; j0 < Npad; j0 += 2 * AT_R) step(std::integral_constant<int, 3>{}, ba, j0);
         } else {
-        // staging: 128 rows x 4 segments of 8 doubles per step of 32 dimensions; the step after the one being multiplied is
+        // staging: 64 rows x 4 segments of 8 doubles per step of 32 dimensions; the step after the one being multiplied is
         // already on its way into registers (16-byte loads where the rows allow), the row pointers one streamed block ahead
         typedef double d2a __attribute__((ext_vector_type(2)));
         const int lr = tid >> 2, seg = (tid & 3) * 8;
@@ -1132,11 +1106,10 @@ __global__ __launch_bounds__(TT) void asv_tile_kernel(int g, const double* __res
                 }
             }
         };
-        constexpr int SR = 2 * AT_R;  // rows per step of the staged form: 16 per wave, eight waves
         const double* src = row_ptr(lr);
-        const double* src_next = row_ptr((int64_t)SR + lr);
+        const double* src_next = row_ptr((int64_t)AT_R + lr);
         fetch(src, 0);
-        for (int64_t j0 = 0; j0 < N; j0 += SR) {
+        for (int64_t j0 = 0; j0 < N; j0 += AT_R) {
             d4 D = d4{0.0, 0.0, 0.0, 0.0}, P = d4{0.0, 0.0, 0.0, 0.0};
             // this lane's streamed cell of the step: its norm and id are asked for now and used after the products
             const int64_t jo = j0 + 16 * w + (lane & 15);
@@ -1152,7 +1125,7 @@ __global__ __launch_bounds__(TT) void asv_tile_kernel(int g, const double* __res
                 } else {  // the next streamed block's first step; its successor's row pointer starts its own round trip
                     src = src_next;
                     fetch(src, 0);
-                    src_next = row_ptr(j0 + 2 * SR + lr);
+                    src_next = row_ptr(j0 + 2 * AT_R + lr);
                     (void)src_next;
                 }
 #pragma unroll
@@ -1207,15 +1180,22 @@ __global__ __launch_bounds__(TT) void asv_tile_kernel(int g, const double* __res
         }
         }
         // per-cell maxima and projection range: over the 16 lanes of a row group, then over the waves
-        if constexpr (NB8 == 0) own_done();  // (the register-streamed form has parked the own batch's sums already)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             for (int o = 1; o < 16; o <<= 1) {
                 mx1[i] = fmax(mx1[i], __shfl_xor(mx1[i], o));
                 lo[i] = fmin(lo[i], __shfl_xor(lo[i], o));
                 hi[i] = fmax(hi[i], __shfl_xor(hi[i], o));
+                // the partial log-sum-exps of the 16 lanes that share the cell: to their common maximum, then added
+                const double pm = __shfl_xor(om[i], o), pa = __shfl_xor(oa[i], o), pb = __shfl_xor(ob[i], o);
+                const double mm = fmax(om[i], pm);
+                const double f0 = om[i] == mm ? 1.0 : exp(om[i] - mm), f1 = pm == mm ? 1.0 : exp(pm - mm);
+                oa[i] = oa[i] * f0 + pa * f1;
+                ob[i] = ob[i] * f0 + pb * f1;
+                om[i] = mm;
             }
         }
+        __syncthreads();
         if ((lane & 15) == 0) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -1223,19 +1203,22 @@ __global__ __launch_bounds__(TT) void asv_tile_kernel(int g, const double* __res
                 sm[(w * AT_C + c) * 6 + 0] = mx1[i];
                 sm[(w * AT_C + c) * 6 + 1] = lo[i];
                 sm[(w * AT_C + c) * 6 + 2] = hi[i];
+                sm[(w * AT_C + c) * 6 + 3] = om[i];
+                sm[(w * AT_C + c) * 6 + 4] = oa[i];
+                sm[(w * AT_C + c) * 6 + 5] = ob[i];
             }
         }
         __syncthreads();
         if (tid < AT_C) {
             double a = NEG, l = POS, h = NEG, m2 = NEG;
-            for (int ww = 0; ww < AT_W; ++ww) {
+            for (int ww = 0; ww < 4; ++ww) {
                 a = fmax(a, sm[(ww * AT_C + tid) * 6 + 0]);
                 l = fmin(l, sm[(ww * AT_C + tid) * 6 + 1]);
                 h = fmax(h, sm[(ww * AT_C + tid) * 6 + 2]);
                 m2 = fmax(m2, sm[(ww * AT_C + tid) * 6 + 3]);
             }
-            double all = 0.0, below = 0.0;  // the waves' partial sums to the common maximum, in wave order
-            for (int ww = 0; ww < AT_W; ++ww) {
+            double all = 0.0, below = 0.0;  // the four waves' partial sums to the common maximum, in wave order
+            for (int ww = 0; ww < 4; ++ww) {
                 const double pm = sm[(ww * AT_C + tid) * 6 + 3];
                 const double f = pm == m2 ? 1.0 : exp(pm - m2);
                 all += sm[(ww * AT_C + tid) * 6 + 4] * f;
@@ -1290,7 +1273,7 @@ __global__ __launch_bounds__(TT) void asv_tile_kernel(int g, const double* __res
                 const unsigned long long NEGBITS = 0xFFF0000000000000ull;  // -inf
                 // ---- the first histogram of the walk; for a flagged cell also every bin's largest log-weight and the number
                 // of reference cells within 38.5 of the largest one (all of those are kept addends)
-                for (int b = tid; b < AT_NB; b += TT) {
+                for (int b = tid; b < AT_NB; b += T) {
                     hist[b] = 0ull;
                     binmax[b] = NEGBITS;
                 }
@@ -1324,7 +1307,7 @@ __global__ __launch_bounds__(TT) void asv_tile_kernel(int g, const double* __res
                     int* smi = reinterpret_cast<int*>(sm);
                     smi[tid] = cG;
                     __syncthreads();
-                    for (int o2 = TT / 2; o2 > 0; o2 >>= 1) {
+                    for (int o2 = T / 2; o2 > 0; o2 >>= 1) {
                         if (tid < o2) smi[tid] += smi[tid + o2];
                         __syncthreads();
                     }
@@ -1350,11 +1333,10 @@ __global__ __launch_bounds__(TT) void asv_tile_kernel(int g, const double* __res
                         double* binthr = reinterpret_cast<double*>(binmax);
                         {
                             const bool wide = (bhi - blo) > 16.0 * AT_NB * tolp;
-                            constexpr int BPT = AT_NB / TT;  // bins per thread
-                            double v[BPT], m8 = NEG;
+                            double v[8], m8 = NEG;
 #pragma unroll
-                            for (int k = 0; k < BPT; ++k) {
-                                v[k] = __longlong_as_double((long long)binmax[BPT * tid + k]);
+                            for (int k = 0; k < 8; ++k) {
+                                v[k] = __longlong_as_double((long long)binmax[8 * tid + k]);
                                 m8 = fmax(m8, v[k]);
                             }
                             double inc = m8;
@@ -1369,11 +1351,11 @@ __global__ __launch_bounds__(TT) void asv_tile_kernel(int g, const double* __res
                             if (lane == 0) run = NEG;
                             for (int ww = 0; ww < w; ++ww) run = fmax(run, sm[ww]);
 #pragma unroll
-                            for (int k = 0; k < BPT; ++k) {
-                                const double E = run;  // largest log-weight of the bins in front of bin BPT tid + k
+                            for (int k = 0; k < 8; ++k) {
+                                const double E = run;  // largest log-weight of the bins in front of bin 8 tid + k
                                 run = fmax(run, v[k]);
-                                if (BPT * tid + k + 1 < AT_NB)
-                                    binthr[BPT * tid + k + 1] = wide ? asv_thr_neg(E, mx, (double)nr1, mb) : NEG;
+                                if (8 * tid + k + 1 < AT_NB)
+                                    binthr[8 * tid + k + 1] = wide ? asv_thr_neg(E, mx, (double)nr1, mb) : NEG;
                             }
                             if (tid == 0) {
                                 binthr[0] = NEG;
@@ -1399,14 +1381,14 @@ __global__ __launch_bounds__(TT) void asv_tile_kernel(int g, const double* __res
                                     thrR = asv_thr_neg(Mr, mx, (double)nr1, mb);  // (from the pieces in front of this one)
                                     double r = mT;
                                     for (int o2 = 1; o2 < 64; o2 <<= 1) r = fmax(r, __shfl_xor(r, o2));
-                                    double* smx = sm + par * (AT_W + 2);
+                                    double* smx = sm + par * 8;
                                     if (lane == 0) smx[w] = r;
-                                    if (tid == 0) smx[AT_W] = (sh_sel[1] > lcap_c || sh_sel[2] > lcap_c) ? 1.0 : 0.0;
+                                    if (tid == 0) smx[4] = (sh_sel[1] > lcap_c || sh_sel[2] > lcap_c) ? 1.0 : 0.0;
                                     __syncthreads();
-                                    for (int ww = 0; ww < AT_W; ++ww) Mr = fmax(Mr, smx[ww]);
+                                    Mr = fmax(Mr, fmax(fmax(smx[0], smx[1]), fmax(smx[2], smx[3])));
                                     mT = NEG;
                                     par ^= 1;
-                                    return smx[AT_W] != 0.0;
+                                    return smx[4] != 0.0;
                                 },
                                 [&](double pr, double lw, int o) {
                                     const bool in = o < nr1;
@@ -1466,16 +1448,16 @@ __global__ __launch_bounds__(TT) void asv_tile_kernel(int g, const double* __res
                                         const int t2 = __shfl_xor(rs_, o2);
                                         rs_ = t2 < rs_ ? t2 : rs_;
                                     }
-                                    double* smx = sm + par * (4 * AT_W + 2);
+                                    double* smx = sm + par * 32;
                                     if (lane == 0) {
                                         smx[w * 4 + 0] = r1;
                                         smx[w * 4 + 1] = r3;
                                         smx[w * 4 + 2] = (double)rs_;
                                     }
-                                    if (tid == 0) smx[4 * AT_W] = sh_sel[0] > lcap_c ? 1.0 : 0.0;
+                                    if (tid == 0) smx[16] = sh_sel[0] > lcap_c ? 1.0 : 0.0;
                                     __syncthreads();
                                     double pTx = NEG, pPx = NEG, ps = 2147483647.0;
-                                    for (int ww = 0; ww < AT_W; ++ww) {
+                                    for (int ww = 0; ww < 4; ++ww) {
                                         pTx = fmax(pTx, smx[ww * 4 + 0]);
                                         pPx = fmax(pPx, smx[ww * 4 + 1]);
                                         ps = fmin(ps, smx[ww * 4 + 2]);
@@ -1494,7 +1476,7 @@ __global__ __launch_bounds__(TT) void asv_tile_kernel(int g, const double* __res
                                     Px = fmax(Px, pPx);
                                     mTx = mPx = NEG;
                                     par ^= 1;
-                                    return smx[4 * AT_W] != 0.0;
+                                    return smx[16] != 0.0;
                                 },
                                 [&](double code, double lw, int o) {
                                     const bool behind = o > spos;
@@ -1521,15 +1503,15 @@ __global__ __launch_bounds__(TT) void asv_tile_kernel(int g, const double* __res
                                 int np2 = 1;
                                 while (np2 < cnt) np2 <<= 1;
                                 if (np2 > 4 * lsort) {
-                                    for (int i = cnt + tid; i < np2; i += TT) gi[i] = 0x7fffffff;
+                                    for (int i = cnt + tid; i < np2; i += T) gi[i] = 0x7fffffff;
                                     asv_sort_global(gi, np2, ib, 4 * lsort, tid, [](int x, int y) { return x < y; });
                                     return gi;
                                 }
-                                for (int i = tid; i < np2; i += TT) ib[i] = i < cnt ? gi[i] : 0x7fffffff;
+                                for (int i = tid; i < np2; i += T) ib[i] = i < cnt ? gi[i] : 0x7fffffff;
                                 __syncthreads();
                                 for (int k = 2; k <= np2; k <<= 1)
                                     for (int j = k >> 1; j > 0; j >>= 1) {
-                                        for (int i = tid; i < np2; i += TT) {
+                                        for (int i = tid; i < np2; i += T) {
                                             const int ixj = i ^ j;
                                             if (ixj > i) {
                                                 const int x0 = ib[i], x1 = ib[ixj];
@@ -1545,7 +1527,7 @@ __global__ __launch_bounds__(TT) void asv_tile_kernel(int g, const double* __res
                             };
                             {
                                 const int32_t* ix = sorted_ints(giR, KR);  // totalprob1's chain runs in restrict order (:117-131)
-                                for (int i = tid; i < KR; i += TT) {
+                                for (int i = tid; i < KR; i += T) {
                                     double pr, lw;
                                     asv_pair_literal(cur, grd, S + ((int64_t)nr2 + ix[i]) * gs_rt, g, sigma2, pr, lw);
                                     LR[(int64_t)c * lcap + i] = lw;
@@ -1554,7 +1536,7 @@ __global__ __launch_bounds__(TT) void asv_tile_kernel(int g, const double* __res
                             }
                             {
                                 const int32_t* ix = sorted_ints(giO, KO);  // totalprob2's and prob2's likewise (:78-109)
-                                for (int i = tid; i < KO; i += TT) {
+                                for (int i = tid; i < KO; i += T) {
                                     const int j = ix[i];
                                     double pr = 0.0, lw = 0.0;
                                     bool add = true;
@@ -1573,7 +1555,7 @@ __global__ __launch_bounds__(TT) void asv_tile_kernel(int g, const double* __res
                             if (np2 <= lsort) {
                                 double* kp = ub;
                                 double* kw = ub + lsort;
-                                for (int i = tid; i < np2; i += TT) {
+                                for (int i = tid; i < np2; i += T) {
                                     double pr = POS, lw = POS;
                                     if (i < KS) asv_pair_literal(cur, grd, S + ((int64_t)nr2 + giS[i]) * gs_rt, g, sigma2, pr, lw);
                                     kp[i] = pr;
@@ -1582,7 +1564,7 @@ __global__ __launch_bounds__(TT) void asv_tile_kernel(int g, const double* __res
                                 __syncthreads();
                                 for (int k = 2; k <= np2; k <<= 1)
                                     for (int j = k >> 1; j > 0; j >>= 1) {
-                                        for (int i = tid; i < np2; i += TT) {
+                                        for (int i = tid; i < np2; i += T) {
                                             const int ixj = i ^ j;
                                             if (ixj > i) {
                                                 const double p0 = kp[i], w0 = kw[i], p1 = kp[ixj], w1_ = kw[ixj];
@@ -1597,14 +1579,14 @@ __global__ __launch_bounds__(TT) void asv_tile_kernel(int g, const double* __res
                                         }
                                         __syncthreads();
                                     }
-                                for (int i = tid; i < KS; i += TT) {
+                                for (int i = tid; i < KS; i += T) {
                                     LS[((int64_t)c * lcap + i) * 2] = kp[i];
                                     LS[((int64_t)c * lcap + i) * 2 + 1] = kw[i];
                                 }
                             } else {  // a long list: sorted where it lies, through an LDS window
                                 typedef double d2a __attribute__((ext_vector_type(2)));
                                 d2a* L2 = reinterpret_cast<d2a*>(LS + (int64_t)c * lcap * 2);
-                                for (int i = tid; i < np2; i += TT) {
+                                for (int i = tid; i < np2; i += T) {
                                     double pr = POS, lw = POS;
                                     if (i < KS) asv_pair_literal(cur, grd, S + ((int64_t)nr2 + giS[i]) * gs_rt, g, sigma2, pr, lw);
                                     L2[i] = d2a{pr, lw};
@@ -1628,7 +1610,7 @@ __global__ __launch_bounds__(TT) void asv_tile_kernel(int g, const double* __res
                 if (!literal)
                 for (int round = 0; round < 40; ++round) {
                     if (round > 0) {  // (round 0's histogram is the one taken above)
-                        for (int b = tid; b < AT_NB; b += TT) hist[b] = 0ull;
+                        for (int b = tid; b < AT_NB; b += T) hist[b] = 0ull;
                         if (tid == 0) sh_cnt = 0;
                         __syncthreads();
                     }
@@ -1671,14 +1653,14 @@ __global__ __launch_bounds__(TT) void asv_tile_kernel(int g, const double* __res
                         const int m = cnt < AT_CAP ? cnt : AT_CAP;
                         int npad = 1;
                         while (npad < m) npad <<= 1;
-                        for (int i = m + tid; i < npad; i += TT) {
+                        for (int i = m + tid; i < npad; i += T) {
                             lp[i] = POS;
                             lw_[i] = 0ull;
                         }
                         __syncthreads();
                         for (int k = 2; k <= npad; k <<= 1)
                             for (int j = k >> 1; j > 0; j >>= 1) {
-                                for (int i = tid; i < npad; i += TT) {
+                                for (int i = tid; i < npad; i += T) {
                                     const int ixj = i ^ j;
                                     if (ixj > i) {
                                         const double a = lp[i], b2 = lp[ixj];
@@ -1725,7 +1707,7 @@ __global__ __launch_bounds__(TT) void asv_tile_kernel(int g, const double* __res
                     unsigned long long* smu = reinterpret_cast<unsigned long long*>(sm);
                     smu[tid] = mine;
                     __syncthreads();
-                    for (int o2 = TT / 2; o2 > 0; o2 >>= 1) {
+                    for (int o2 = T / 2; o2 > 0; o2 >>= 1) {
                         if (tid < o2) smu[tid] += smu[tid + o2];
                         __syncthreads();
                     }
@@ -2015,7 +1997,7 @@ void adjust_shift_variance_device(hipStream_t stream, const double* data1, int g
 #define BMX_ASV_TILE(NB8)                                                                                                    \
     case NB8:                                                                                                                \
         ensure_dynamic_lds(reinterpret_cast<const void*>(&asv_tile_kernel<NB8>), lds);                                       \
-        hipLaunchKernelGGL(asv_tile_kernel<NB8>, dim3(blocks), dim3(TT), lds, stream, g, data2, n2, vrm, sigma2, nr1, nr2,     \
+        hipLaunchKernelGGL(asv_tile_kernel<NB8>, dim3(blocks), dim3(T), lds, stream, g, data2, n2, vrm, sigma2, nr1, nr2,     \
                            (const double*)S, (const double*)snrm, (const int32_t*)sid, out, ws_pairs, cell_begin, cell_end,  \
                            pl.lcap, tally, gbar);                                                                          \
         break

@@ -82,7 +82,7 @@ def measured_traffic(workload, kernel):
     last committed measurement -- and it is only reported when it was taken on the very kernel (template arguments
     included) this run has just launched; otherwise None plus the reason."""
     rec = None
-    for rnd in ("r05", "r04", "r03", "r02"):  # the latest committed measurement
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):  # the latest committed measurement
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_traffic_{workload}.json")))
             break
@@ -148,7 +148,8 @@ def cpu_baselines(batches, stats, d, k):
     pair evaluations to the whole job (oracle/cpu_baselines.py):
       A  one thread, pruned exact search in the manner of KmknnParam() / SerialParam(), fastMNN()'s defaults;
       B  all host threads, blocked brute force on the host BLAS with a fused running-threshold filter;
-      C  all host cores, the oracle's OpenMP brute force (no BLAS).
+      C  all host cores, the oracle's OpenMP brute force (no BLAS);
+      T  all physical cores, cache-blocked brute force with a hand-written AVX2 + FMA micro-kernel and the filter fused in.
     Returns (main, variants): main = the faster one in the contract's cpu_baseline form."""
     from oracle import cpu_baselines as cb
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -210,6 +211,30 @@ def cpu_baselines(batches, stats, d, k):
                 "sample": (f"oracle exact FP64 brute force (oracle/mnn_oracle.c, OpenMP, {cores} threads): {whole_c}, {nq_c} "
                            f"queries x {L.shape[0]} reference cells in {dt:.1f} s ({rate_c:.3g} pair evaluations/s = "
                            f"{rate_c * flop_per_pair / 1e9:.0f} GFLOP/s); scaled by pair evaluations to the whole job")}
+    # T: the same search the way a CPU wants it (oracle/tiled_knn_baseline.c): packed operands, a register-blocked AVX2 + FMA
+    # micro-kernel, the reference block in L2, the filter on the tile in registers; one thread per physical core; whole blocks
+    # of the job (every right cell against a batch) until ~10 s are spent
+    try:
+        nt = cb.physical_cores()
+        cb.tiled_knn(L[:4096], R[:512], k, nthreads=nt)
+        t0 = time.perf_counter()
+        pairs_t, nblk = 0.0, 0
+        while time.perf_counter() - t0 < 10.0 and nblk < 64:
+            cb.tiled_knn(L, R, k, nthreads=nt)
+            pairs_t += float(L.shape[0]) * R.shape[0]
+            nblk += 1
+        dt = time.perf_counter() - t0
+        rate_t = pairs_t / dt
+        out["T"] = {"value": n_cells / (total_pairs / rate_t), "unit": "cells/s", "cores": nt, "kind": "port",
+                    "gflops": rate_t * flop_per_pair / 1e9, "host_fp64_peak_gflops": peak_gf,
+                    "frac_of_host_fp64_peak": (rate_t * flop_per_pair / 1e9 / peak_gf) if peak_gf else None,
+                    "sample": (f"cache-blocked FP64 brute force with a 4 x 8 AVX2 + FMA micro-kernel and the threshold filter fused "
+                               f"into it (oracle/tiled_knn_baseline.c, OpenMP, {nt} threads = physical cores of {cores} host threads): "
+                               f"{nblk} whole block(s) of the job, {R.shape[0]} queries x {L.shape[0]} reference cells each, in {dt:.1f} s "
+                               f"({rate_t:.3g} pair evaluations/s = {rate_t * flop_per_pair / 1e9:.0f} GFLOP/s); scaled by pair "
+                               f"evaluations to the whole job")}
+    except Exception as exc:  # noqa: BLE001
+        out["T"] = {"value": 0.0, "unit": "cells/s", "cores": 0, "kind": "port", "sample": f"failed: {exc}"}
     main = dict(max(out.values(), key=lambda r: r["value"]))
     return main, out
 
@@ -760,14 +785,17 @@ def main():
             a_tf = 4.0 * d * asv["asv_pairs"] / (asv["asv_ms"] * 1e-3) / 1e12
             # HBM bytes per launch from the committed --pmc passes of this very command at sigma 1 (2 x FETCH_SIZE + WRITE_SIZE
             # over the 15 launches of a step); another bandwidth runs other code paths: no number then
-            asv_traffic, asv_traffic_note = None, "profiles/r05_asv_tile_pmc.json holds the counters of the sigma = 1 run only"
+            asv_traffic, asv_traffic_note = None, "profiles/r0N_asv_tile_pmc.json holds the counters of the sigma = 1 run only"
             if args.sigma == 1.0 and args.workload == "config5":
-                try:
-                    rec = json.load(open(os.path.join(ROOT, "profiles", "r05_asv_tile_pmc.json")))["all_launches_total"]
-                    asv_traffic = (rec["hbm_read_bytes"] + rec["hbm_write_bytes"]) / 15.0
-                    asv_traffic_note = "profiles/r05_asv_tile_pmc.json: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 over a step's 15 launches / 15"
-                except (OSError, ValueError, KeyError):
-                    pass
+                for rnd in ("r06", "r05"):
+                    try:
+                        rec = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_asv_tile_pmc.json")))["all_launches_total"]
+                        asv_traffic = (rec["hbm_read_bytes"] + rec["hbm_write_bytes"]) / 15.0
+                        asv_traffic_note = (f"profiles/{rnd}_asv_tile_pmc.json: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 over a step's 15 "
+                                            "launches / 15")
+                        break
+                    except (OSError, ValueError, KeyError):
+                        continue
             line["metric"] = "cells/sec corrected (reducedMNN engine + adjust_shift_variance, 100 PCs)"
             line["dtype"] = "f64 (FP64 MFMA) for adjust_shift_variance; " + kern["dtype"] + " for the searches"
             line["config"]["var_adj_sigma"] = args.sigma
@@ -785,6 +813,9 @@ def main():
                 "cells_tiled": _bl.dev_get("asv_tiled_cells") // max(1, args.steps + 0),
                 "cells_rerun_in_reference_order": _bl.dev_get("asv_literal_cells") // max(1, args.steps),
                 "cells_flagged_beyond_the_rerun": _bl.dev_get("asv_fallback_cells") // max(1, args.steps),
+                # 100 MHz ticks added up over the workgroups (256 per launch at this size) since the library was loaded
+                "phase_ms_per_workgroup": {ph: _bl.dev_get("asv_ticks_" + ph) / 256 / 1e5 / max(1, args.steps + args.warmup)
+                                           for ph in ("stream", "wait", "cells")},
             }
         if h2h is not None:
             line["value_host_to_host"] = n_cells / h2h

@@ -163,3 +163,41 @@ def blas_knn(X, Q, k, block=256, workers=None, chunk=4096):
         if limiter is not None:
             limiter.restore_original_limits()
     return idx + 1, dist, info
+
+
+def physical_cores():
+    """Host cores without their SMT siblings (FMA-bound code gains nothing from the second thread of a core)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/devices/system/cpu/smt/active") as f:
+            if f.read().strip() == "1":
+                n = max(1, n // 2)
+    except OSError:
+        pass
+    return n
+
+
+_TILED = None
+
+
+def tiled_knn(X, Q, k, nthreads=0):
+    """Exact kNN, all cores, the way a CPU wants it (oracle/tiled_knn_baseline.c: packed operands, a 4 x 8 AVX2 + FMA
+    micro-kernel, the reference block resident in L2, the threshold filter on the tile in registers, exact re-evaluation of
+    the kept).  Returns (idx 1-based [nq x k], dist [nq x k])."""
+    global _TILED
+    if _TILED is None:
+        path = os.path.join(_HERE, "libtiled_knn_baseline.so")
+        if not os.path.exists(path):
+            raise RuntimeError("baseline not built: run `make -C oracle`")
+        _TILED = ctypes.CDLL(path)
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    Q = np.ascontiguousarray(Q, dtype=np.float64)
+    nq, d = Q.shape
+    idx = np.zeros((nq, k), dtype=np.int32)
+    dist = np.zeros((nq, k), dtype=np.float64)
+    f64p, i32p = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)
+    rc = _TILED.tiled_knn(X.ctypes.data_as(f64p), X.shape[0], Q.ctypes.data_as(f64p), nq, d, int(k),
+                          idx.ctypes.data_as(i32p), dist.ctypes.data_as(f64p), int(nthreads))
+    if rc:
+        raise RuntimeError("tiled_knn: bad arguments or out of memory")
+    return idx + 1, dist

@@ -111,6 +111,27 @@ def test_full_size_knn_beyond_the_tiers_lists(oracle, data, k):
     assert np.all(np.diff(dist, axis=1) >= 0)
 
 
+def test_full_size_knn_k_5000(oracle, data):
+    """k = 5 000 = prop.k 0.05 of BASELINE config 2's 100 000 cells (R/MNN_tree.R:140-146), all 100 000 queries: the partitioned
+    search with the big merge (knn.hip: lk_merge_big) instead of seconds of FP64 scan; 200 sampled rows against the oracle's brute
+    force over the full reference, indices and distances bitwise.  The time is printed (< 1 s was the mark)."""
+    import time
+    import torch
+    from batchelor_amd import neighbors as nb
+    L, R = data
+    nb.query_knn(R, L[:2000], 5000)  # (workspaces)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    idx, dist = nb.query_knn(R, L, 5000)
+    dt = time.perf_counter() - t0
+    print(f"query_knn k = 5000, {N} x {N} cells, host to host ({idx.nbytes + dist.nbytes >> 20} MB of results): {dt:.2f} s; "
+          f"{nb.last_knn_exact_fallbacks()} queries through the FP64 scan")
+    rows = np.sort(np.random.default_rng(5000).choice(N, 200, replace=False))
+    oi, od = oracle.query_knn(R, L[rows], 5000)
+    assert np.array_equal(idx[rows], oi) and np.array_equal(dist[rows], od)
+    assert nb.last_knn_exact_fallbacks() <= 2000
+
+
 def test_full_size_prop_k_run(data):
     # reducedMNN(prop.k = 0.0005) on 2 x 100 000 cells: k = max(20, round(50)) = 50 for every search of the merge
     import batchelor_amd as bx

@@ -74,6 +74,28 @@ def test_query_knn_beyond_the_tiers_lists(oracle, nb, nx, nq, d, k):
         assert nb.last_knn_exact_fallbacks() <= nq // 20        # (queries that went to the FP64 scan)
 
 
+@pytest.mark.parametrize("nx,nq,d,k", [(40000, 600, 50, 1000), (60000, 400, 20, 2500), (100000, 300, 50, 5000)])
+def test_query_knn_k_beyond_900(oracle, nb, nx, nq, d, k):
+    """`prop.k` = 0.05 of 100 000 cells is k = 5 000 (R/MNN_tree.R:140-146): more candidates a query (P x 36, P = ceil(k / 14))
+    than the rank-counting merges take -- knn.hip: lk_merge_big, the k-th smallest by bisection on the distances' bit patterns,
+    only the selected sorted.  Same bar: indices equal, distances bitwise, none of it through the FP64 scan."""
+    X, Q = synth_batches(3, [nx, nq], d)
+    idx, dist = nb.query_knn(X, Q, k)
+    oi, od = oracle.query_knn(X, Q, k)
+    assert np.array_equal(idx, oi)
+    assert np.array_equal(dist, od)
+    assert nb.last_knn_exact_fallbacks() <= nq // 20
+
+
+def test_query_knn_k_beyond_900_with_exact_duplicates(oracle, nb):
+    # every reference cell twice: each distance occurs twice, the k-th place splits a pair of equal distances by position
+    X0, Q = synth_batches(4, [15000, 200], 30)
+    X = np.concatenate([X0, X0])
+    idx, dist = nb.query_knn(X, Q, 1001)
+    oi, od = oracle.query_knn(X, Q, 1001)
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+
+
 def test_query_knn_beyond_the_tiers_lists_clustered(oracle, nb):
     # a reference whose ORDER follows its geometry (cells sorted by cluster): the strided deal keeps every partition a fair
     # sample of every cluster; with contiguous partitions a query's neighbours would all sit in one

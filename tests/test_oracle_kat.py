@@ -549,3 +549,19 @@ def test_cpu_baseline_b_filtered_brute_force_is_an_exact_knn():
         assert np.array_equal(idx, oi)
         np.testing.assert_allclose(dist, od, rtol=1e-12)
         assert info["workers"] == 2
+
+
+@pytest.mark.parametrize("nx,nq,d,k", [(9000, 700, 30, 20), (5003, 257, 50, 20), (300, 131, 7, 36), (64, 10, 3, 5)])
+def test_cpu_baseline_t_tiled_brute_force_is_an_exact_knn(oracle, nx, nq, d, k):
+    """bench.py's CPU baseline T (oracle/tiled_knn_baseline.c: packed operands, a 4 x 8 AVX2 + FMA micro-kernel with the
+    threshold filter on the tile in registers, all cores) against the oracle's brute force: the same neighbours in the same
+    order, distances bitwise (the kept candidates are re-evaluated in the oracle's order of operations).  Ragged sizes: rows
+    that do not fill an octet, queries that do not fill a group of four."""
+    from oracle import cpu_baselines as cb
+    rng = np.random.default_rng(12)
+    X = rng.standard_normal((nx, d)) / np.sqrt(1.0 + np.arange(d) / 5.0)
+    Q = rng.standard_normal((nq, d)) / np.sqrt(1.0 + np.arange(d) / 5.0) + 0.2
+    idx, dist = cb.tiled_knn(X, Q, k, nthreads=3)
+    oi, od = oracle.query_knn(X, Q, k)
+    assert np.array_equal(idx, oi)
+    assert np.array_equal(dist, od)
