@@ -19,6 +19,7 @@
 #include "portable_math.hpp"
 
 #include <algorithm>
+#include <type_traits>
 #include <mutex>
 #include <cstdlib>
 
@@ -87,6 +88,28 @@ __global__ void row_norms2(const double* __restrict__ X, int64_t n, int gd, doub
     if (lane == 0) out[r] = s;
 }
 
+// exp(x) for x <= 0 in the stream's epilogue (the own batch's online log-sum-exp: one per pair, two when a new maximum arrives).
+// The library's exp costs the one wave of a SIMD ~1 000 cycles a call there -- a block of own-batch rows took 2.6 times a block
+// of reference rows (round 6, by phase ticks with and without the division: EXPERIMENTS.md).  Table-driven instead: x = (32 m + j)
+// ln 2 / 32 + r, |r| <= ln 2 / 64, exp(x) = 2^m 2^(j / 32) (1 + r + r^2 / 2 + ... + r^6 / 720); the 32 powers sit in the LDS (tab).
+// Below 2 ulp (checked against extended precision over [-700, 0]); -inf and anything below -800 give 0.
+__device__ __forceinline__ double asv_exp_neg(double x, const double* tab) {
+    x = fmax(x, -800.0);
+    const double nf = __builtin_rint(x * 46.16624130844683);     // 32 / ln 2
+    const int n = (int)nf;
+    double r = __builtin_fma(nf, -0x1.62e42fee00000p-6, x);      // ln 2 / 32, high part (n times it is exact)
+    r = __builtin_fma(nf, -0x1.a39ef35793c76p-38, r);            // ... low part
+    double p = 1.0 / 720.0;
+    p = __builtin_fma(p, r, 1.0 / 120.0);
+    p = __builtin_fma(p, r, 1.0 / 24.0);
+    p = __builtin_fma(p, r, 1.0 / 6.0);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = p * r;
+    const double t = tab[n & 31];
+    return ldexp(__builtin_fma(t, p, t), n >> 5);
+}
+
 constexpr int SG_KC = 32;    // distance genes staged per step
 // SG_GT: output genes per workgroup -- 64 where that covers all of them (the PC-space calls of the merge engine's world: half the
 // weighted-sum MFMAs of a 128-gene tile would multiply zeros, and two workgroups fit a CU: one's exp() under the other's
@@ -106,7 +129,9 @@ __global__ __launch_bounds__(256) void sgk_flash(const double* __restrict__ X, i
     __shared__ double xs[64 * P];
     __shared__ double as_[APPLY ? 64 * PA : 1];
     __shared__ double mi2[64], di[64], fac[64];
+    __shared__ double e2tab[32];  // 2^(j / 32) for asv_exp_neg: one FP64 exp per (MNN cell, cell) pair is what this kernel spends
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid < 32) e2tab[tid] = exp2((double)tid * 0.03125);  // (visible after the first barrier below, long before its first use)
     const int64_t c0 = (int64_t)blockIdx.x * 64;
     const int g0 = blockIdx.y * SG_GT;
     const int cl = 16 * w + (lane & 15);  // this lane's column (cell) of the score tile
@@ -252,13 +277,13 @@ __global__ __launch_bounds__(256) void sgk_flash(const double* __restrict__ X, i
         tmax = fmax(tmax, __shfl_xor(tmax, 16));
         tmax = fmax(tmax, __shfl_xor(tmax, 32));
         const double m_new = fmax(m_run, tmax);  // finite: the tile holds at least one MNN cell
-        const double scale = exp(m_run - m_new);  // exp(-inf) = 0 on the first tile
+        const double scale = asv_exp_neg(m_run - m_new, e2tab);  // exp(-inf) = 0 on the first tile
         double psum = 0.0;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const double pv = exp(S[t][reg] - m_new);
+                const double pv = asv_exp_neg(S[t][reg] - m_new, e2tab);
                 S[t][reg] = pv;
                 psum += pv;
             }
@@ -477,9 +502,11 @@ constexpr int AT_NP = 2 * AT_R; // the stream is padded to whole pairs of steps 
 constexpr int AT_SM = 4 * AT_C * 6;  // doubles of the block-reduction area: six values per (wave, cell) after the stream (>= T)
 
 __host__ __device__ inline int asv_tile_gp(int g) { return (g + AT_KC - 1) / AT_KC * AT_KC + 2; }
-__host__ __device__ inline int asv_tile_nb8(int g) { return g <= 128 ? (g + 7) / 8 : 0; }  // 8-dimension blocks of a row; 0: the staged form
+// 8-dimension blocks of a streamed row; 0: the staged form.  Round 6: a row carries two more columns behind its g coordinates
+// -- 1 and its squared norm -- so that the distance chain's MFMAs deliver -|x_c - x_o|^2 / sigma directly (asv_tile_kernel)
+__host__ __device__ inline int asv_tile_nb8(int g) { return g + 2 <= 128 ? (g + 2 + 7) / 8 : 0; }
 // row stride of the gathered stream: whole 8-dimension blocks (zero filled) for the register-streamed form
-inline int asv_tile_gs(int g) { return g <= 128 ? asv_tile_nb8(g) * 8 : g; }
+inline int asv_tile_gs(int g) { return asv_tile_nb8(g) > 0 ? asv_tile_nb8(g) * 8 : g; }
 __host__ __device__ inline size_t asv_tile_npad(size_t N) {
     const size_t p = (N + AT_NP - 1) / AT_NP * AT_NP;
     return p > (size_t)AT_NP ? p : (size_t)AT_NP;
@@ -506,7 +533,7 @@ __host__ __device__ inline int64_t asv_tile_list_doubles(int lcap) { return (int
 inline size_t asv_tile_lds_bytes(int g, int lcap) {
     const int nb8 = asv_tile_nb8(g);
     return ((size_t)2 * AT_C * asv_tile_gp(g) + (size_t)asv_tile_ub_doubles(g, lcap) +
-            (nb8 == 0 ? (size_t)AT_R * (AT_KC + 2) : 0) + 8 * AT_C + AT_SM) * sizeof(double) +
+            (nb8 == 0 ? (size_t)AT_R * (AT_KC + 2) : 0) + 8 * AT_C + 32 + AT_SM) * sizeof(double) +
            (size_t)2 * AT_NB * sizeof(unsigned long long);
 }
 
@@ -628,6 +655,7 @@ __device__ __forceinline__ void asv_row_scan(const double* __restrict__ P, const
 // way, which there resolves the quantile to 2^-40 of the total weight.
 // ---------------------------------------------------------------------------------------------------
 constexpr double AT_LN2 = 0.6931471805599453;
+
 
 // addends below the returned value cannot change a chain whose running value lies in [L, U] (the lemma above)
 __device__ __forceinline__ double asv_noop_below(double L, double U) {
@@ -787,15 +815,17 @@ __global__ __launch_bounds__(256) void asv_gather_stream(const double* __restric
     const int rid = !live ? -1 : (own ? r2[j] : r1[j - nr2]);
     const double* src = live ? (own ? data2 : data1) + (int64_t)rid * g : nullptr;
     double sq = 0.0;
+    const bool aug = gs >= g + 2;  // (the register-streamed form: column g holds 1, column g + 1 the squared norm)
     for (int k = lane; k < gs; k += 64) {  // (rows of gs >= g values and npad >= nr1 + nr2 rows: zeros beyond the data)
         const double v = live && k < g ? src[k] : 0.0;
-        S[j * gs + k] = v;
+        if (!(aug && k == g + 1)) S[j * gs + k] = (aug && k == g && live) ? 1.0 : v;
         sq += v * v;
     }
     for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
     if (lane == 0) {
         snrm[j] = sq;
         sid[j] = own ? rid : -1;
+        if (aug) S[j * gs + g + 1] = live ? sq : 0.0;
     }
 }
 
@@ -851,7 +881,8 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
     double* sc_lo = sc_mx2 + AT_C;
     double* sc_hi = sc_lo + AT_C;
     double* sc_tmp = sc_hi + AT_C;
-    double* sm = sc_tmp + AT_C;                         // [AT_SM] block reductions
+    double* etab = sc_tmp + AT_C;                       // [32] 2^(j / 32) for asv_exp_neg
+    double* sm = etab + 32;                             // [AT_SM] block reductions
     unsigned long long* hist = reinterpret_cast<unsigned long long*>(sm + AT_SM);  // [NB]
     unsigned long long* binmax = hist + AT_NB;  // [NB] per projection bin: the largest log-weight (bit pattern), then the bin's threshold
     double* cxp = ub;                                       // [2 NB8][64] the cells' coordinates as the lanes read them
@@ -918,6 +949,8 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
         // round (config 5: 9.94 -> 10.78 s per step; rounds 4 and 6, EXPERIMENTS.md).  One arrival per TILE on a device word
         // zeroed before the launch; the tiles of round r go on when all tiles of rounds <= r have arrived (or 50 ms have gone
         // by).  gbar is null unless the hook is on and the launch is no wider than the device.
+        if (tid < 32) etab[tid] = exp2((double)tid * 0.03125);  // (for asv_exp_neg)
+        __syncthreads();
         tk0 = __builtin_amdgcn_s_memrealtime();
         if (gbar) {
             if (tid == 0) {
@@ -964,6 +997,27 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
             for (int c = 0; c < AT_C; ++c) cmx = fmax(cmx, sc_n[c]);
             tol_tile = 1e-13 * (1.0 + cmx + snrm[Npad]);
         }
+        // the partial log-sum-exps of the 16 lanes that share a cell: to their common maximum, then added; parked per (wave,
+        // cell) in the block-reduction area (nobody else uses it during the stream) -- see the reduction behind the stream
+        auto own_done = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                for (int o = 1; o < 16; o <<= 1) {
+                    const double pm = __shfl_xor(om[i], o), pa = __shfl_xor(oa[i], o), pb = __shfl_xor(ob[i], o);
+                    const double mm = fmax(om[i], pm);
+                    const double f0 = om[i] == mm ? 1.0 : exp(om[i] - mm), f1 = pm == mm ? 1.0 : exp(pm - mm);
+                    oa[i] = oa[i] * f0 + pa * f1;
+                    ob[i] = ob[i] * f0 + pb * f1;
+                    om[i] = mm;
+                }
+                if ((lane & 15) == 0) {
+                    const int c = (lane >> 4) + 4 * i;
+                    sm[(w * AT_C + c) * 6 + 3] = om[i];
+                    sm[(w * AT_C + c) * 6 + 4] = oa[i];
+                    sm[(w * AT_C + c) * 6 + 5] = ob[i];
+                }
+            }
+        };
         if constexpr (NB8 > 0) {
             typedef double d2a __attribute__((ext_vector_type(2)));
             constexpr int GS = NB8 * 8;  // row stride of the stream (zero filled beyond g)
@@ -971,19 +1025,29 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
             const int kq = lane >> 4;
             // the A operands of MFMA step st = 2 q + t: lane l holds cell l & 15, dimension 8 q + 2 (l >> 4) + t.  Up to 64
             // dimensions they live in registers for the whole stream, beyond that in the LDS in lane order.
+            // Round 6: the distance chain's A operand is the cell SCALED and AUGMENTED -- (2 / sigma) x_c, then -|x_c|^2 / sigma
+            // against the row's column of ones and -1 / sigma against its squared norm -- so that the chain delivers
+            // -|x_c - x_o|^2 / sigma and the epilogue is left with one multiply, one fused multiply-add and a clamp per pair
+            // where it had an add, a multiply, two subtractions, a clamp and a division (FP64 vector work does not run under
+            // FP64 MFMAs on this part: EXPERIMENTS.md round 6).  The values differ from the division's by rounding of the order
+            // of 1e-14 (|x_c|^2 + |x_o|^2) / sigma, inside the margin `mb` every use of them carries.
+            const double isig = 1.0 / sigma2;
+            auto a_dist = [&](int cell, int k) -> double {
+                return k < g ? cx[cell * GP + k] * (2.0 * isig) : (k == g ? -sc_n[cell] * isig : (k == g + 1 ? -isig : 0.0));
+            };
             double axr[NB8 <= 8 ? NST : 1], agr[NB8 <= 8 ? NST : 1];
             if constexpr (NB8 <= 8) {
 #pragma unroll
                 for (int st = 0; st < NST; ++st) {
                     const int k = 8 * (st >> 1) + 2 * kq + (st & 1);
-                    axr[st] = cx[(lane & 15) * GP + k];
+                    axr[st] = a_dist(lane & 15, k);
                     agr[st] = cg[(lane & 15) * GP + k];
                 }
             } else {
                 for (int e = tid; e < NST * 64; e += T) {
                     const int st = e >> 6, ln = e & 63;
                     const int k = 8 * (st >> 1) + 2 * (ln >> 4) + (st & 1);
-                    cxp[e] = cx[(ln & 15) * GP + k];
+                    cxp[e] = a_dist(ln & 15, k);
                     cgp[e] = cg[(ln & 15) * GP + k];
                 }
                 __syncthreads();
@@ -1004,16 +1068,39 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                     b[2 * q + 1] = v[1];
                 }
             };
-            auto step = [&](const double (&b)[NST], double (&bn)[NST], int64_t j0) __attribute__((always_inline)) {
+            // One 64-row block of the stream for this wave's 16 rows of it.  Round 6: on this part NOTHING runs under an FP64 MFMA
+            // -- every vector instruction of a SIMD, whichever wave it comes from, adds its ~4 cycles to the 64 of each MFMA
+            // (scripts/microbench/mfma_f64_valu.hip) -- so what a block costs is its 52 MFMAs plus the COUNT of everything else,
+            // and rounds 3-5's single loop carried ~450 vector instructions a block (per-element selects between the two kinds
+            // of rows, SGPR spills, accumulator moves).  Hence one loop per KIND of block (MODE), each with only its own running
+            // state and its own half of the epilogue, and ONE row set per wave, each piece re-loaded right behind the two MFMAs
+            // that consumed it (the same prefetch distance as a second buffer, 52 registers less):
+            //   0 every row of the block belongs to the OWN batch: the online log-sum-exps (and the float codes of the re-run);
+            //   1 a block that holds the end of the own batch (or rows of both kinds, or padding): everything, by selects;
+            //   2 every row belongs to the REFERENCE batch: maxima, projection range, the scratch stores;
+            //   3 reference rows and the stream's zero padding behind them.
+            auto step = [&](auto mode_tag, double (&b)[NST], int64_t j0) __attribute__((always_inline)) {
+                constexpr int MODE = decltype(mode_tag)::value;
                 const int64_t jo = j0 + jl;
-                // the next step's rows are on their way while this one multiplies (the last step asks for its own again)
-                load_rows(bn, srow + (j0 + AT_R < Npad ? (j0 + AT_R) : j0) * GS);
-                const double no = snrm[jo];
-                const int rid = sid[jo];
+                const double* nsrc = srow + (j0 + AT_R < Npad ? (j0 + AT_R) : j0) * GS;  // (the last block asks for its own again)
+                int rid = -1;
+                if constexpr (MODE <= 1) rid = sid[jo];
                 // two accumulator pairs (k-steps alternate): D and P chains are independent of each other as well
                 d4 Dq[2], Pq[2];
 #pragma unroll
                 for (int a = 0; a < 2; ++a) Dq[a] = Pq[a] = d4{0.0, 0.0, 0.0, 0.0};
+                // (NB8 > 8: the A operands come from the LDS, asked for AHEAD k-steps before the MFMAs that take them -- read
+                // right in front of its MFMAs, as the compiler places them, every pair of k-steps waits out the LDS's latency:
+                // the bare chains ran at 0.79 of the matrix pipe's rate)
+                constexpr int AHEAD = 4;
+                double axq[NB8 > 8 ? AHEAD : 1], agq[NB8 > 8 ? AHEAD : 1];
+                if constexpr (NB8 > 8) {
+#pragma unroll
+                    for (int t = 0; t < AHEAD; ++t) {
+                        axq[t] = cxp[t * 64 + lane];
+                        agq[t] = cgp[t * 64 + lane];
+                    }
+                }
 #pragma unroll
                 for (int st = 0; st < NST; ++st) {
                     double ax, ag;
@@ -1021,16 +1108,24 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                         ax = axr[st];
                         ag = agr[st];
                     } else {
-                        ax = cxp[st * 64 + lane];
-                        ag = cgp[st * 64 + lane];
+                        ax = axq[st % AHEAD];
+                        ag = agq[st % AHEAD];
+                        if (st + AHEAD < NST) {
+                            axq[st % AHEAD] = cxp[(st + AHEAD) * 64 + lane];
+                            agq[st % AHEAD] = cgp[(st + AHEAD) * 64 + lane];
+                        }
                     }
                     Dq[st & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, b[st], Dq[st & 1], 0, 0, 0);
                     Pq[st & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ag, b[st], Pq[st & 1], 0, 0, 0);
-                    if constexpr (NB8 > 8)
-                        if ((st & 7) == 7)
-                            __builtin_amdgcn_sched_barrier(0);  // (keeps the A operands of 32 dimensions live at a time)
+                    if (st & 1) {  // both values of this 8-dimension block are consumed: the next block's piece takes their place
+                        const d2a v = *reinterpret_cast<const d2a*>(nsrc + 8 * (st >> 1));
+                        b[st - 1] = v[0];
+                        b[st] = v[1];
+                    }
+                    if constexpr (NB8 > 8) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // (two MFMAs, then what belongs behind them)
                 }
-                const bool own = jo < nr2, ref = !own && jo < N;
+                const bool own = MODE == 0 ? true : (MODE >= 2 ? false : jo < nr2);
+                const bool ref = MODE == 0 ? false : (MODE == 2 ? true : (!own && jo < N));
                 const int blk = (int)(j0 >> 6);
                 f4 oc = f4{0.f, 0.f, 0.f, 0.f};
                 (void)tol_tile;
@@ -1039,28 +1134,34 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {  // this lane: streamed cell jo, tile cells (lane >> 4) + 4 i
                     double pr = Pq[0][i] + Pq[1][i];
-                    const double dd = Dq[0][i] + Dq[1][i];
                     const double s_ = cp[i] - pr;
-                    double d2 = (cn[i] + no) - 2.0 * dd - s_ * s_;
-                    d2 = d2 > 0.0 ? d2 : 0.0;
-                    double lw = -d2 / sigma2;
-                    const bool self = rid == c0 + kq + 4 * i;  // the cell itself: log-weight 0, always counted (:80-84)
-                    lw = self ? 0.0 : lw;
-                    pr = self ? NEG : pr;
-                    // (selects, not branches: the padding rows of the stream belong to neither batch)
-                    mx1[i] = fmax(mx1[i], ref ? lw : NEG);
-                    lo[i] = fmin(lo[i], ref ? pr : POS);
-                    hi[i] = fmax(hi[i], ref ? pr : NEG);
-                    if (own) {  // (whole waves but for the one step where the own batch ends)
-                        if (lw > om[i]) {  // a new maximum: rare once the cell itself (log-weight 0) has gone by
-                            const double f = exp(om[i] - lw);  // exp(-inf) = 0 the first time
-                            oa[i] *= f;
-                            ob[i] *= f;
-                            om[i] = lw;
+                    // -(|x_c - x_o|^2 - s^2) / sigma: the chain's value plus s^2 / sigma, never above zero
+                    double lw = __builtin_fma(s_, s_ * isig, Dq[0][i] + Dq[1][i]);
+                    lw = lw < 0.0 ? lw : -0.0;  // (log-weights are <= -0, as -d2 / sigma was: the per-bin maxima order them by bit pattern)
+                    bool self = false;
+                    if constexpr (MODE <= 1) {
+                        self = rid == c0 + kq + 4 * i;  // the cell itself: log-weight 0, always counted (:80-84)
+                        lw = self ? 0.0 : lw;
+                        pr = self ? NEG : pr;
+                    }
+                    if constexpr (MODE >= 1) {
+                        // (selects, not branches: the padding rows of the stream belong to neither batch)
+                        mx1[i] = fmax(mx1[i], ref ? lw : NEG);
+                        lo[i] = fmin(lo[i], ref ? pr : POS);
+                        hi[i] = fmax(hi[i], ref ? pr : NEG);
+                    }
+                    if constexpr (MODE <= 1) {
+                        if (own) {  // (whole waves but for the one block where the own batch ends)
+                            if (lw > om[i]) {  // a new maximum: rare once the cell itself (log-weight 0) has gone by
+                                const double f = asv_exp_neg(om[i] - lw, etab);  // exp(-inf) = 0 the first time
+                                oa[i] *= f;
+                                ob[i] *= f;
+                                om[i] = lw;
+                            }
+                            const double e = asv_exp_neg(lw - om[i], etab);
+                            oa[i] += e;
+                            ob[i] += !(pr > cp[i]) ? e : 0.0;
                         }
-                        const double e = exp(lw - om[i]);
-                        oa[i] += e;
-                        ob[i] += !(pr > cp[i]) ? e : 0.0;
                     }
                     if (!own) {
                         const int slot = (kq + 4 * i + blk + rot0) & (AT_C - 1);  // == at(kq + 4 i, jo)
@@ -1075,12 +1176,17 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                 // (this lane's four cells kq, kq + 4, kq + 8, kq + 12 of one streamed cell: one 16-byte store, 16 lanes a 256-byte run)
                 if (own && lit_on) so_[(int64_t)blk * (AT_C * 16)] = oc;
             };
-            double ba[NST], bb[NST];
+            double ba[NST];
+            int64_t j0 = 0;
             load_rows(ba, srow);
-            for (int64_t j0 = 0; j0 < Npad; j0 += 2 * AT_R) {
-                step(ba, bb, j0);
-                step(bb, ba, j0 + AT_R);
+            for (; j0 + AT_R <= nr2; j0 += AT_R) step(std::integral_constant<int, 0>{}, ba, j0);
+            if (j0 < nr2) {
+                step(std::integral_constant<int, 1>{}, ba, j0);
+                j0 += AT_R;
             }
+            own_done();  // (the own batch's sums leave the registers: the reference loop runs without them; see below)
+            for (; j0 + AT_R <= N; j0 += AT_R) step(std::integral_constant<int, 2>{}, ba, j0);
+            for (; j0 < Npad; j0 += AT_R) step(std::integral_constant<int, 3>{}, ba, j0);
         } else {
         // staging: 64 rows x 4 segments of 8 doubles per step of 32 dimensions; the step after the one being multiplied is
         // already on its way into registers (16-byte loads where the rows allow), the row pointers one streamed block ahead
@@ -1180,22 +1286,15 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
         }
         }
         // per-cell maxima and projection range: over the 16 lanes of a row group, then over the waves
+        if constexpr (NB8 == 0) own_done();  // (the register-streamed form parked the own batch's sums when its last own block was through)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             for (int o = 1; o < 16; o <<= 1) {
                 mx1[i] = fmax(mx1[i], __shfl_xor(mx1[i], o));
                 lo[i] = fmin(lo[i], __shfl_xor(lo[i], o));
                 hi[i] = fmax(hi[i], __shfl_xor(hi[i], o));
-                // the partial log-sum-exps of the 16 lanes that share the cell: to their common maximum, then added
-                const double pm = __shfl_xor(om[i], o), pa = __shfl_xor(oa[i], o), pb = __shfl_xor(ob[i], o);
-                const double mm = fmax(om[i], pm);
-                const double f0 = om[i] == mm ? 1.0 : exp(om[i] - mm), f1 = pm == mm ? 1.0 : exp(pm - mm);
-                oa[i] = oa[i] * f0 + pa * f1;
-                ob[i] = ob[i] * f0 + pb * f1;
-                om[i] = mm;
             }
         }
-        __syncthreads();
         if ((lane & 15) == 0) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -1203,9 +1302,6 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                 sm[(w * AT_C + c) * 6 + 0] = mx1[i];
                 sm[(w * AT_C + c) * 6 + 1] = lo[i];
                 sm[(w * AT_C + c) * 6 + 2] = hi[i];
-                sm[(w * AT_C + c) * 6 + 3] = om[i];
-                sm[(w * AT_C + c) * 6 + 4] = oa[i];
-                sm[(w * AT_C + c) * 6 + 5] = ob[i];
             }
         }
         __syncthreads();

@@ -152,7 +152,13 @@ def cpu_baselines(batches, stats, d, k):
       T  all physical cores, cache-blocked brute force with a hand-written AVX2 + FMA micro-kernel and the filter fused in.
     Returns (main, variants): main = the faster one in the contract's cpu_baseline form."""
     from oracle import cpu_baselines as cb
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    hw_threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # (round 6: the GPU boxes of this pool show 256 hardware threads and grant the container 16 CPUs' worth of time
+    # (cgroup cpu.max): every "all cores" baseline of rounds 1-5 ran 256 threads on that quota.  The baselines now start as
+    # many threads as the quota and the physical cores allow, and say so.)
+    quota = cb.cpu_quota()
+    cores = cb.usable_cores() if quota else hw_threads
+    quota_note = (f"; the container's cgroup grants {quota:g} CPUs of the host's {hw_threads} hardware threads" if quota else "")
     L, R = batches[0], batches[1]
     rng = np.random.default_rng(0)
     total_pairs = sum(2.0 * m["nL"] * m["nR"] + m["nR_all"] * m["U"] for m in stats)  # two searches per block on a CPU
@@ -176,15 +182,19 @@ def cpu_baselines(batches, stats, d, k):
     flop_per_pair = 2.0 * d
     t0 = time.perf_counter()
     nq_b = min(R.shape[0], 8192)
-    _, _, info_b = cb.blas_knn(L, R[:nq_b], k)
+    _, _, info_b = cb.blas_knn(L, R[:nq_b], k, workers=cores)
     dt0 = time.perf_counter() - t0
     nq_b = int(min(R.shape[0], max(8192, 8192 * 25.0 / max(dt0, 1e-3))))
     t0 = time.perf_counter()
-    cb.blas_knn(L, R[:nq_b], k)
+    cb.blas_knn(L, R[:nq_b], k, workers=cores)
     dt = time.perf_counter() - t0
     rate_b = nq_b * L.shape[0] / dt
     whole_b = "one whole block of the job" if nq_b == R.shape[0] else "a sample of the block"
     peak_gf, peak_how = host_fp64_peak_gflops()
+    if quota and peak_gf:  # the peak this process can reach: its quota's share of the physical cores
+        phys = cb.physical_cores()
+        peak_gf = peak_gf * min(1.0, quota / max(phys, 1))
+        peak_how += f", of which the cgroup's quota of {quota:g} CPUs can reach {peak_gf:.0f} GFLOP/s"
     out["B"] = {"value": n_cells / (total_pairs / rate_b), "unit": "cells/s", "cores": info_b["workers"], "kind": "port",
                 "gflops": rate_b * flop_per_pair / 1e9,
                 "host_fp64_peak_gflops": peak_gf, "host_fp64_peak_how": peak_how,
@@ -192,7 +202,7 @@ def cpu_baselines(batches, stats, d, k):
                 "sample": (f"blocked brute force on the host BLAS ({info_b['blas']}; FP64 DGEMM tiles of 256 queries x 4096 "
                            f"reference cells with a fused running-threshold filter + exact "
                            f"re-evaluation of the kept), {info_b['workers']} worker threads x {info_b['blas_threads_per_worker']} "
-                           f"BLAS thread(s) of {cores} host threads: {whole_b}, {nq_b} queries x {L.shape[0]} reference cells in "
+                           f"BLAS thread(s){quota_note}: {whole_b}, {nq_b} queries x {L.shape[0]} reference cells in "
                            f"{dt:.1f} s ({rate_b:.3g} pair evaluations/s = {rate_b * flop_per_pair / 1e9:.0f} GFLOP/s); scaled by "
                            f"pair evaluations to the whole job")}
     # C: the oracle's own OpenMP brute force (FP64, no BLAS), all cores -- round 1's baseline, kept for continuity
@@ -208,14 +218,14 @@ def cpu_baselines(batches, stats, d, k):
     whole_c = "one whole block of the job" if nq_c == R.shape[0] else "a sample of the block"
     out["C"] = {"value": n_cells / (total_pairs / rate_c), "unit": "cells/s", "cores": cores, "kind": "port",
                 "gflops": rate_c * flop_per_pair / 1e9,
-                "sample": (f"oracle exact FP64 brute force (oracle/mnn_oracle.c, OpenMP, {cores} threads): {whole_c}, {nq_c} "
+                "sample": (f"oracle exact FP64 brute force (oracle/mnn_oracle.c, OpenMP, {cores} threads{quota_note}): {whole_c}, {nq_c} "
                            f"queries x {L.shape[0]} reference cells in {dt:.1f} s ({rate_c:.3g} pair evaluations/s = "
                            f"{rate_c * flop_per_pair / 1e9:.0f} GFLOP/s); scaled by pair evaluations to the whole job")}
     # T: the same search the way a CPU wants it (oracle/tiled_knn_baseline.c): packed operands, a register-blocked AVX2 + FMA
     # micro-kernel, the reference block in L2, the filter on the tile in registers; one thread per physical core; whole blocks
     # of the job (every right cell against a batch) until ~10 s are spent
     try:
-        nt = cb.physical_cores()
+        nt = cb.usable_cores()
         cb.tiled_knn(L[:4096], R[:512], k, nthreads=nt)
         t0 = time.perf_counter()
         pairs_t, nblk = 0.0, 0
@@ -229,7 +239,7 @@ def cpu_baselines(batches, stats, d, k):
                     "gflops": rate_t * flop_per_pair / 1e9, "host_fp64_peak_gflops": peak_gf,
                     "frac_of_host_fp64_peak": (rate_t * flop_per_pair / 1e9 / peak_gf) if peak_gf else None,
                     "sample": (f"cache-blocked FP64 brute force with a 4 x 8 AVX2 + FMA micro-kernel and the threshold filter fused "
-                               f"into it (oracle/tiled_knn_baseline.c, OpenMP, {nt} threads = physical cores of {cores} host threads): "
+                               f"into it (oracle/tiled_knn_baseline.c, OpenMP, {nt} threads{quota_note}): "
                                f"{nblk} whole block(s) of the job, {R.shape[0]} queries x {L.shape[0]} reference cells each, in {dt:.1f} s "
                                f"({rate_t:.3g} pair evaluations/s = {rate_t * flop_per_pair / 1e9:.0f} GFLOP/s); scaled by pair "
                                f"evaluations to the whole job")}
@@ -244,7 +254,9 @@ def cpu_baseline_var_adj(batches, d, sigma, asv_pairs_per_step):
     the cells, which the reference's loop treats independently) on a bounded sample -- 8 cells per host thread of one batch against
     ~200 000 reference cells + its own batch -- scaled by (cell, restricted cell) pairs to the step's calls."""
     from oracle import fastmnn_oracle as orc
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    from oracle import cpu_baselines as cb
+    cores = cb.usable_cores()
+    os.environ["OMP_NUM_THREADS"] = str(cores)  # (the oracle's loop takes OpenMP's default: set before its first parallel region)
     order = np.argsort([-b.shape[0] for b in batches])
     ref = batches[order[0]][:200000]
     own = batches[order[1]][:60000]

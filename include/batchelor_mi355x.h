@@ -101,8 +101,10 @@ void bmx_set_force_exact_knn(int32_t on);
  * adjust_shift_variance: addends a chain of the literal re-run of an ill-conditioned cell may keep; -1 = default, 0 = no
  * re-run), "asv_modes" (n: the tiled form records which way each of the first n cells of a call went, see
  * bmx_dev_get_bytes), "asv_sync" (0: the tiled form's workgroups do not wait for each other at the start of a round of
- * tiles -- round 5's free-running streams; default 1), "sample_split" (ranges the threshold sample of a search with few
- * query blocks is split into; 0 = never, the default; -1 = automatic), "reset" (all back to their defaults).
+ * tiles -- the default; 1 = they do, measured slower), "sample_split" (ranges the threshold sample of a search with few
+ * query blocks is split into; -1 = automatic, the default; 0 = never), "tau_replay" (developer experiment: 1 = every search of
+ * a run records its queries' final thresholds, 2 = the same sequence of searches starts its full passes from them), "reset"
+ * (all back to their defaults).
  * Unknown name: BMX_ERR_ARG. */
 int32_t bmx_dev_set(const char* name, int32_t value);
 /* Counters for tests and bench.py, current device: "asv_tiled_cells" (cells the tiled form of adjust_shift_variance has

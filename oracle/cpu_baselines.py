@@ -177,6 +177,33 @@ def physical_cores():
     return n
 
 
+def cpu_quota():
+    """CPUs' worth of time the container's cgroup grants this process (cpu.max; None: unlimited / unknown).  A box may show
+    256 hardware threads and grant 16: more threads than that only add throttling."""
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            q, per = open(path).read().split()[:2]
+            if q != "max":
+                return float(q) / float(per)
+        except (OSError, ValueError):
+            pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return q / per
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+def usable_cores():
+    """Threads worth starting: the physical cores of the affinity mask, capped by the cgroup's CPU quota."""
+    n = physical_cores()
+    q = cpu_quota()
+    return max(1, min(n, int(q + 0.5))) if q else n
+
+
 _TILED = None
 
 
