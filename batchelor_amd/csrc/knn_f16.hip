@@ -1249,7 +1249,7 @@ namespace {
 // The split sample's thresholds (see the SAMPLE epilogue of knn_topk_f16): one wave per query, n = nranges x KS values of
 // distinct references; the k-th smallest of them -- every value's rank by counting, ties by position -- plus twice the pass's
 // error bound is a valid starting threshold (the margin form of the unsplit sample), taken if tighter than what stands there.
-__global__ __launch_bounds__(256) void sample_merge_kernel(const float* __restrict__ lists, int n, int nq, int k,
+__global__ __launch_bounds__(256) void sample_merge_kernel(const float* __restrict__ lists, int n, int len, int nq, int k,
                                                            const float* __restrict__ margin_g, uint32_t* __restrict__ tau_g) {
     __shared__ float sv[4][512];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1260,11 +1260,26 @@ __global__ __launch_bounds__(256) void sample_merge_kernel(const float* __restri
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // the n values are n / len ascending lists of len (a range's two lanes each kept their len smallest, sorted): an entry's
+    // rank in the union = its place in its own list + a binary search in every other list (ties: the earlier list first)
+    const int nl = n / len;
     float uk = __builtin_inff();
     for (int i = lane; i < n; i += 64) {
         const float x = v[i];
-        int r = 0;
-        for (int j = 0; j < n; ++j) r += (v[j] < x || (v[j] == x && j < i)) ? 1 : 0;
+        const int li = i / len;
+        int r = i - li * len;
+        for (int m = 0; m < nl; ++m) {
+            if (m == li) continue;
+            const float* lm = v + m * len;
+            int lo = 0, hi = len;  // entries of list m in front of x
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                const float y = lm[mid];
+                if (y < x || (y == x && m < li)) lo = mid + 1;
+                else hi = mid;
+            }
+            r += lo;
+        }
         uk = r == k - 1 ? x : uk;
     }
     for (int o = 32; o > 0; o >>= 1) uk = fminf(uk, __shfl_xor(uk, o));
@@ -1279,7 +1294,7 @@ void f16_sample_merge(hipStream_t stream, const float* lists, int nranges, int K
                       uint32_t* tau_g) {
     const int n = nranges * KS;
     if (n > 512 || nq <= 0 || k < 1 || k > n || !margin) return;  // (the ranges' own thresholds stand)
-    hipLaunchKernelGGL(sample_merge_kernel, dim3(cdiv(nq, 4)), dim3(256), 0, stream, lists, n, nq, k, margin, tau_g);
+    hipLaunchKernelGGL(sample_merge_kernel, dim3(cdiv(nq, 4)), dim3(256), 0, stream, lists, n, KS / 2, nq, k, margin, tau_g);
     BMX_LAUNCH_CHECK();
 }
 
