@@ -306,8 +306,8 @@ def test_full_size_config5_with_variance_adjustment(oracle, full5, sigma):
     assert (modes == 2).mean() < 0.01
 
 
-@pytest.mark.parametrize("sigma", [1.0, 0.3])
-def test_full_size_config5_cells_beyond_the_rerun_by_mode(oracle, full5, sigma):
+@pytest.mark.parametrize("sigma,known_worst", [(1.0, None), (0.3, 13)])
+def test_full_size_config5_cells_beyond_the_rerun_by_mode(oracle, full5, sigma, known_worst):
     """the cells the tiled adjust_shift_variance FLAGS but does not re-run (mode 2: ill-conditioned, more
     significant pairs than the re-run's lists hold -- 2.5 % of config 5's cells at sigma 1, next to none of them in the root
     merge) sampled where they ARE: a first full-size run records every merge's tallies (testing hook "asv_modes"), the merge
@@ -326,11 +326,18 @@ def test_full_size_config5_cells_beyond_the_rerun_by_mode(oracle, full5, sigma):
     eng.upload(B)
     _lib.dev_set("asv_modes", 600000)
     try:
+        # (sigma 0.3 re-runs 58 % of the cells with long lists: 100 s a run -- the merge that holds the most flagged cells is
+        # known from a recorded run and checked against this run's tallies, so that one run serves)
+        if known_worst is not None:
+            eng.set_snapshot(known_worst)
         eng.run(k=k, merge_tree=code, var_adj=True, sigma=sigma)
         tallies = eng.var_adj_tally()
         worst = int(np.argmax([t["beyond"] for t in tallies]))
-        eng.set_snapshot(worst)
-        eng.run(k=k, merge_tree=code, var_adj=True, sigma=sigma)
+        if known_worst is None:
+            eng.set_snapshot(worst)
+            eng.run(k=k, merge_tree=code, var_adj=True, sigma=sigma)
+        else:
+            assert worst == known_worst, (worst, [t["beyond"] for t in tallies])
         snap = eng.snapshot_var_adj()
         modes = eng.snapshot_var_adj_modes(snap["right"].shape[0])
     finally:
