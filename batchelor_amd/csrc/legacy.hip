@@ -830,9 +830,11 @@ __global__ __launch_bounds__(256) void asv_gather_stream(const double* __restric
 }
 
 // snrm[n] = max of snrm[0, n): non-negative doubles order like their bit patterns (one workgroup's maximum per atomic)
-__global__ __launch_bounds__(256) void asv_max_norm(double* __restrict__ snrm, int64_t n, unsigned int* __restrict__ gbar) {
+__global__ __launch_bounds__(256) void asv_max_norm(double* __restrict__ snrm, int64_t n, unsigned int* __restrict__ gbar,
+                                                    unsigned int* __restrict__ tile_ctr) {
     __shared__ double sm[256];
     if (gbar && blockIdx.x == 0 && threadIdx.x == 0) *gbar = 0u;  // (the tile kernel's round barrier starts from zero)
+    if (tile_ctr && blockIdx.x == 0 && threadIdx.x == 0) *tile_ctr = 0u;  // (... and so does its tile counter)
     double m = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmax(m, snrm[i]);
     sm[threadIdx.x] = m;
@@ -861,7 +863,8 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                                                      const double* __restrict__ S, const double* __restrict__ snrm,
                                                      const int32_t* __restrict__ sid, double* __restrict__ out,
                                                      double* __restrict__ scratch, int cell_begin, int cell_end, int lcap,
-                                                     unsigned long long* __restrict__ tally, unsigned int* __restrict__ gbar) {
+                                                     unsigned long long* __restrict__ tally, unsigned int* __restrict__ gbar,
+                                                     unsigned int* __restrict__ tile_ctr) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int GP = asv_tile_gp(g);
     double* cx = reinterpret_cast<double*>(smem_raw);  // [16][GP] the tile's cells
@@ -887,7 +890,7 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
     unsigned long long* binmax = hist + AT_NB;  // [NB] per projection bin: the largest log-weight (bit pattern), then the bin's threshold
     double* cxp = ub;                                       // [2 NB8][64] the cells' coordinates as the lanes read them
     double* cgp = cxp + (NB8 > 8 ? NB8 * 2 * 64 : 0);       // [2 NB8][64] the unit gradients likewise (NB8 > 8)
-    __shared__ int sh_cnt, sh_bin;
+    __shared__ int sh_cnt, sh_bin, sh_tile;
     __shared__ unsigned long long sh_before;
     __shared__ int sh_sel[4];        // literal re-run: kept addends (own batch, reference in restrict order, in projection order), abort flag
     __shared__ int sh_K[AT_C][3];    // per cell of the tile: the lengths of its three lists (-1: the cell went the histogram way)
@@ -916,7 +919,18 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
     const double NEG = -__builtin_inf(), POS = __builtin_inf();
     unsigned long long tk_stream = 0, tk_wait = 0, tk_cells = 0, tk0 = 0, tk1 = 0;  // (thread 0's)
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // Tiles are handed out as workgroups come free (round 6: a counter on the device): a tile with flagged cells takes several
+    // times a plain one -- with tiles dealt in a fixed stride the workgroups of a launch ended 11 % apart on config 5 at
+    // sigma 1 (5.7 % without the re-run).  Every cell's value is independent of which workgroup computes it and when.  (With the
+    // testing hook "asv_sync" the rounds need the fixed deal.)
+    for (int tile = blockIdx.x;; ) {
+        if (tile_ctr && !gbar) {
+            __syncthreads();  // (sh_tile of the previous turn has been read by everybody)
+            if (tid == 0) sh_tile = (int)atomicAdd(tile_ctr, 1u);
+            __syncthreads();
+            tile = sh_tile;
+        }
+        if (tile >= ntiles) break;
         const int c0 = cell_begin + tile * AT_C;
         // ---- the tile's cells: coordinates, unit gradient (:57-70), own projection
         for (int e = tid; e < AT_C * GP; e += T) {
@@ -1873,6 +1887,7 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
             __syncthreads();
         }
         tk_cells += __builtin_amdgcn_s_memrealtime() - tk0;
+        if (!(tile_ctr && !gbar)) tile += gridDim.x;  // (the fixed deal)
     }
     if (tid == 0) {
         atomicAdd(&g_asv_ticks[0], tk_stream);
@@ -2087,7 +2102,8 @@ void adjust_shift_variance_device(hipStream_t stream, const double* data1, int g
         unsigned int* gbar = nullptr;
         if (dev_knobs().asv_sync != 0 && blocks <= device_cu_count())
             gbar = reinterpret_cast<unsigned int*>(extra + pl.extra_doubles - 2);
-        hipLaunchKernelGGL(asv_max_norm, dim3(256), dim3(256), 0, stream, snrm, N, gbar);
+        unsigned int* tile_ctr = reinterpret_cast<unsigned int*>(extra + pl.extra_doubles - 4);
+        hipLaunchKernelGGL(asv_max_norm, dim3(256), dim3(256), 0, stream, snrm, N, gbar, tile_ctr);
         const size_t lds = asv_tile_lds_bytes(g, pl.lcap);
         unsigned long long* tally = asv_tally_device();
 #define BMX_ASV_TILE(NB8)                                                                                                    \
@@ -2095,7 +2111,7 @@ void adjust_shift_variance_device(hipStream_t stream, const double* data1, int g
         ensure_dynamic_lds(reinterpret_cast<const void*>(&asv_tile_kernel<NB8>), lds);                                       \
         hipLaunchKernelGGL(asv_tile_kernel<NB8>, dim3(blocks), dim3(T), lds, stream, g, data2, n2, vrm, sigma2, nr1, nr2,     \
                            (const double*)S, (const double*)snrm, (const int32_t*)sid, out, ws_pairs, cell_begin, cell_end,  \
-                           pl.lcap, tally, gbar);                                                                          \
+                           pl.lcap, tally, gbar, tile_ctr);                                                                \
         break
         switch (asv_tile_nb8(g)) {
 #ifdef BMX_ASV_AB_ONLY13
