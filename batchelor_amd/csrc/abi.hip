@@ -67,6 +67,21 @@ T* upload(bmx::DevBuf<T>& buf, const T* host, size_t n, hipStream_t s) {
     return p;
 }
 
+// neighbour lists [nq][k] (0-based, row-major) -> R's layout [k][nq] (1-based, column-major), on the device
+__global__ void idx_to_r_layout(const int32_t* __restrict__ in, int nq, int k, int32_t* __restrict__ out) {
+    __shared__ int32_t tile[32][33];
+    const int q0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+    for (int qq = threadIdx.y; qq < 32; qq += 8) {
+        const int q = q0 + qq, j = j0 + threadIdx.x;
+        if (q < nq && j < k) tile[qq][threadIdx.x] = in[(int64_t)q * k + j] + 1;
+    }
+    __syncthreads();
+    for (int jj = threadIdx.y; jj < 32; jj += 8) {
+        const int j = j0 + jj, q = q0 + threadIdx.x;
+        if (q < nq && j < k) out[(int64_t)j * nq + q] = tile[threadIdx.x][jj];
+    }
+}
+
 // host column-major [n x d] -> device row-major
 double* upload_rm(bmx::DevBuf<double>& tmp, bmx::DevBuf<double>& out, const double* cm, int n, int d, hipStream_t s) {
     const double* dcm = upload(tmp, cm, (size_t)n * d, s);
@@ -244,6 +259,28 @@ int32_t bmx_query_knn(const double* X, int32_t nx, const double* query, int32_t 
         // (k = 5 000 on 100 000 queries is 6 GB of results: no value-initialised vectors, the copies through the pinned staging
         // ring, the transposition into R's column-major layout by the pool of host threads, 512 queries a piece)
         const size_t nres = (size_t)nq * k;
+        if (nres >= ((size_t)1 << 22)) {
+            // large results: transposed into R's layout ON THE DEVICE and sent straight into the caller's arrays through the
+            // staging ring (k = 5 000 on 100 000 queries: 6 GB that the host threads -- 16 CPUs of quota on this pool's boxes --
+            // would otherwise read and write once more)
+            g_last_fallbacks = e.knn_ws_.last_exact;
+            if (index) {
+                int32_t* pc = dIc.reserve(nres);
+                hipLaunchKernelGGL(idx_to_r_layout, dim3((unsigned)((nq + 31) / 32), (unsigned)((k + 31) / 32)), dim3(32, 8), 0, s,
+                                   (const int32_t*)pi, nq, k, pc);
+                BMX_LAUNCH_CHECK();
+                bmx::download_pageable(index, pc, nres * sizeof(int32_t), s);
+            }
+            if (distance) {
+                bmx::DevBuf<double> dDc;
+                double* pc = dDc.reserve(nres);
+                bmx::transpose_rm_to_cm(s, pd, nq, k, pc, nq, 0);
+                bmx::download_pageable(distance, pc, nres * sizeof(double), s);
+                BMX_HIP(hipStreamSynchronize(s));
+            }
+            BMX_HIP(hipStreamSynchronize(s));
+            return;
+        }
         std::unique_ptr<int32_t[]> hi(index ? new int32_t[nres] : nullptr);
         std::unique_ptr<double[]> hd(distance ? new double[nres] : nullptr);
         if (index) bmx::download_pageable(hi.get(), pi, nres * sizeof(int32_t), s);
