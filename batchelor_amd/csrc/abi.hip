@@ -327,14 +327,16 @@ int32_t bmx_find_mutual_nns(const int32_t* left, int32_t nL, int32_t k2, const i
         offL.reserve((size_t)nL + 1);
         partR.reserve(std::max<size_t>(1, (size_t)nR * k1));
         cntR.reserve(std::max(1, nR));
-        bmx::mutual_counts(s, pl, nL, k2, pr, nR, k1, cntL.p, partR.p, cntR.p);
+        bmx::SortedRows sorted;
+        bmx::mutual_counts(s, pl, nL, k2, pr, nR, k1, cntL.p, partR.p, cntR.p, nullptr, nullptr, nullptr, false, nullptr,
+                           nullptr, &sorted);
         bmx::exclusive_scan_i32(s, e.scan_ws_, cntL.p, offL.p, nL);
         int32_t P = 0;
         BMX_HIP(hipMemcpyAsync(&P, offL.p + nL, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         BMX_HIP(hipStreamSynchronize(s));
         f.reserve(std::max(1, P));
         sc.reserve(std::max(1, P));
-        bmx::emit_pairs(s, pl, nL, k2, pr, k1, offL.p, nullptr, nullptr, f.p, sc.p);
+        bmx::emit_pairs(s, pl, nL, k2, pr, k1, offL.p, nullptr, nullptr, f.p, sc.p, nullptr, nullptr, &sorted);
         *out_left = download_malloc(f.p, (size_t)P, s);
         *out_right = download_malloc(sc.p, (size_t)P, s);
         *npairs = P;
@@ -362,14 +364,16 @@ int32_t bmx_find_mutual_nn(const double* data1, int32_t n1, const double* data2,
         offL.reserve((size_t)n1 + 1);
         partR.reserve((size_t)n2 * k1);
         cntR.reserve(n2);
-        bmx::mutual_counts(s, idxLR.p, n1, k2, idxRL.p, n2, k1, cntL.p, partR.p, cntR.p);
+        bmx::SortedRows sorted;
+        bmx::mutual_counts(s, idxLR.p, n1, k2, idxRL.p, n2, k1, cntL.p, partR.p, cntR.p, nullptr, nullptr, nullptr, false,
+                           nullptr, nullptr, &sorted);
         bmx::exclusive_scan_i32(s, e.scan_ws_, cntL.p, offL.p, n1);
         int32_t P = 0;
         BMX_HIP(hipMemcpyAsync(&P, offL.p + n1, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         BMX_HIP(hipStreamSynchronize(s));
         f.reserve(std::max(1, P));
         sc.reserve(std::max(1, P));
-        bmx::emit_pairs(s, idxLR.p, n1, k2, idxRL.p, k1, offL.p, nullptr, nullptr, f.p, sc.p);
+        bmx::emit_pairs(s, idxLR.p, n1, k2, idxRL.p, k1, offL.p, nullptr, nullptr, f.p, sc.p, nullptr, nullptr, &sorted);
         *first = download_malloc(f.p, (size_t)P, s);
         *second = download_malloc(sc.p, (size_t)P, s);
         *npairs = P;
@@ -398,7 +402,7 @@ int32_t bmx_mnn_average_correction(const double* refdata, int32_t n1, const doub
         f.reserve(std::max<int64_t>(1, mo.P));
         sc.reserve(std::max<int64_t>(1, mo.P));
         bmx::emit_pairs(s, e.idxLR_.p, mo.nsel, mo.k2, e.idxRL_.p, mo.k1, e.offL_.p, nullptr, nullptr, f.p, sc.p,
-                        e.lsel_.p, e.maskL_.p);
+                        e.lsel_.p, e.maskL_.p, &e.sorted_);
         double* avg = e.averaged_.reserve(std::max<size_t>(1, (size_t)mo.U * d));
         bmx::average_correction(s, e.red_ws_, L.data.p, nullptr, R.data.p, nullptr, d, e.second_u_.p, mo.U, e.partR_.p,
                                 e.cntR_.p, mo.k1, avg);

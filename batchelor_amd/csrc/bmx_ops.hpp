@@ -30,10 +30,17 @@ void exclusive_scan_i32(hipStream_t stream, ScanWorkspace& ws, const int32_t* in
 // it is clear); without it (k2 > 64) cntL[c] = number of mutual partners of row c.
 // idxLR may cover a SUBSET of the left cells: row c belongs to left cell lsel[c] (ascending) and lpos2c[l] is the row
 // of a selected left cell l (both nullptr: one row per left cell).  nL = number of rows of idxLR.
+// SortedRows (nullable; used where sorted_rows_apply(k1, k2): 64 < k2 <= 8192, k1 <= 8192): mutual_counts sorts each row of
+// both lists into it and answers every "does row x list y" by binary search instead of reading the row -- k1 * k2 words a
+// cell otherwise; emit_pairs handed the same object reuses the sorted right rows.  Results are identical.
+struct SortedRows {
+    DevBuf<int32_t> lr, rl;
+};
+bool sorted_rows_apply(int k1, int k2);
 void mutual_counts(hipStream_t stream, const int32_t* idxLR, int nL, int k2, const int32_t* idxRL, int nR, int k1,
                    int32_t* cntL, int32_t* partR, int32_t* cntR, const int32_t* lsel = nullptr,
                    const int32_t* lpos2c = nullptr, unsigned long long* maskL = nullptr, bool mask_is_clear = false,
-                   const double* distRL = nullptr, const double* kthL = nullptr);
+                   const double* distRL = nullptr, const double* kthL = nullptr, SortedRows* sorted = nullptr);
 // (distRL [nR][k1] + kthL [nL], both or neither: the right cells' exact distances to their listed left cells and each
 // left row's largest distance, +inf where unknown -- the probe then rejects without reading the row where it can)
 // ONE launch behind mutual_counts: offL [nsel + 1] = exclusive scan of the pairs per row of idxLR (popcount of maskL, or
@@ -46,7 +53,8 @@ void pair_scans(hipStream_t stream, ScanWorkspace& ws, const unsigned long long*
 // identity if null).  maskL (nullable): emit_pairs then skips the lookups.
 void emit_pairs(hipStream_t stream, const int32_t* idxLR, int nL, int k2, const int32_t* idxRL, int k1,
                 const int32_t* offL, const int32_t* lrows, const int32_t* rrows, int32_t* first, int32_t* second,
-                const int32_t* lsel = nullptr, const unsigned long long* maskL = nullptr);
+                const int32_t* lsel = nullptr, const unsigned long long* maskL = nullptr,
+                const SortedRows* sorted = nullptr);
 // Rows (of n_rows) that occur in idx[0, n_entries): they are stamped with `gen` in stamp [n_rows] (a buffer that is zero
 // when first used and never cleared: every call brings a larger gen), off = exclusive scan of "row is listed" (n_rows + 1
 // entries: off[r] = position of a listed row in sel, off[n_rows] = their number, also written to the device word

@@ -596,7 +596,7 @@ Engine::MnnOut Engine::find_mnn(const Node& left, const Node& right, int k, doub
     int32_t* offR = offR_.reserve((size_t)nR + 1);
     int32_t* second_u = second_u_.reserve(nR);
     mutual_counts(stream_, idxLR, nsel, o.k2, idxRL, nR, o.k1, cntL, partR, cntR, lsel, offSel, maskL, /* mask_is_clear */ true,
-                  distRL, kthL);
+                  distRL, kthL, &sorted_);
     const int32_t* cntR_cells = cntR;
     if (right.restrict_dups) {
         int32_t* fold = cntFold_.reserve(nR);
@@ -825,7 +825,7 @@ void Engine::merge_step(int mdx, Node& left, Node& right, const bmx_params_t& p,
     int32_t* first = rec.first.reserve((size_t)mo.P);
     int32_t* second = rec.second.reserve((size_t)mo.P);
     emit_pairs(stream_, idxLR_.p, mo.nsel, mo.k2, idxRL_.p, mo.k1, offL_.p, lrows, rrows, first, second, lsel_.p,
-               maskL_.p);
+               maskL_.p, &sorted_);
 
     // .average_correction + overall.batch (R/fastMNN.R:480-481); the column means of the averaged vectors, the mean squares
     // .get_batch_magnitude wants (R/fastMNN.R:582-595) and the magnitude itself come out of the same pass where its fused

@@ -140,6 +140,7 @@ class Engine {
     int state_seq_ = 0;  // sequence number of the last publish_state (read_state)
     int stamp_gen_ = 0;  // number of the last search whose listed rows were stamped (stampL_ is never cleared)
     DevBuf<unsigned long long> maskL_;
+    SortedRows sorted_;  // k2 > 64: both neighbour lists, each row sorted (pairs.hip)
     DevBuf<double> kthL_;  // per selected left cell: the largest distance of its row of idxLR_ (+inf where unknown)
     DevBuf<double> distT_, distRL_, averaged_, loc_, vecs_, scal_, means_pool_;
     DevBuf<float> seedL_;

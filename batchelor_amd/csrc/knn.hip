@@ -582,6 +582,96 @@ __global__ __launch_bounds__(256) void knn_exact_select(const double* __restrict
     }
 }
 
+// The same selection for k > 64 (prop.k runs; the k rounds above are 69 ms a query at k = 1 000 over 100 000 references,
+// however few queries there are -- a query is one workgroup).  Squared distances are >= 0, so they order like their bit
+// patterns: a bisection over the patterns finds the k-th smallest value T (<= 63 counting sweeps of the row, which stays in
+// L2), a bisection over the positions finds how far into the references equal to T the list reaches (ties rank by position,
+// as above), the k chosen entries are compacted into LDS and sorted by (distance, position).
+constexpr int XSB_T = 1024;
+constexpr int XSB_MAXK = 8192;
+
+__device__ __forceinline__ int xsb_block_sum(int v, int* sh_part) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();  // (sh_part is read by everyone at the end of the previous call)
+    if ((threadIdx.x & 63) == 0) sh_part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    int s = 0;
+    for (int w = 0; w < XSB_T / 64; ++w) s += sh_part[w];
+    return s;
+}
+
+__global__ __launch_bounds__(XSB_T) void knn_exact_select_big(const double* __restrict__ drow, int nr, int k, int np2,
+                                                              const int32_t* __restrict__ flagged, int f0,
+                                                              int32_t* __restrict__ idx_out, double* __restrict__ dist_out) {
+    extern __shared__ double xsb_d[];       // [np2] distances, then [np2] positions
+    int* xsb_i = reinterpret_cast<int*>(xsb_d + np2);
+    __shared__ int sh_part[XSB_T / 64];
+    __shared__ int sh_fill;
+    const int tid = threadIdx.x;
+    const int f = f0 + blockIdx.x;
+    const int q = flagged ? flagged[1 + f] : f;
+    const double* row = drow + (int64_t)blockIdx.x * nr;
+    // the k-th smallest pattern (NaN patterns lie above +inf's and are never counted; the caller has k <= nr finite rows)
+    unsigned long long lo = 0, hi = 0x7FF0000000000000ull;
+    while (lo < hi) {
+        const unsigned long long mid = lo + ((hi - lo) >> 1);
+        int c = 0;
+        for (int r = tid; r < nr; r += XSB_T) c += (unsigned long long)__double_as_longlong(row[r]) <= mid ? 1 : 0;
+        if (xsb_block_sum(c, sh_part) >= k) hi = mid;
+        else lo = mid + 1;
+    }
+    const unsigned long long T = lo;
+    int c = 0;
+    for (int r = tid; r < nr; r += XSB_T) c += (unsigned long long)__double_as_longlong(row[r]) < T ? 1 : 0;
+    const int need = k - xsb_block_sum(c, sh_part);  // >= 1 entries equal to T, the first in position order
+    int plo = 0, phi = nr - 1;  // smallest position P with `need` entries equal to T at or before it
+    while (plo < phi) {
+        const int mid = plo + ((phi - plo) >> 1);
+        int e = 0;
+        for (int r = tid; r <= mid; r += XSB_T) e += (unsigned long long)__double_as_longlong(row[r]) == T ? 1 : 0;
+        if (xsb_block_sum(e, sh_part) >= need) phi = mid;
+        else plo = mid + 1;
+    }
+    const int P = plo;
+    if (tid == 0) sh_fill = 0;
+    for (int i = tid; i < np2; i += XSB_T) {
+        xsb_d[i] = __builtin_inf();
+        xsb_i[i] = 0x7FFFFFFF;
+    }
+    __syncthreads();
+    for (int r = tid; r < nr; r += XSB_T) {
+        const double v = row[r];
+        const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+        if (b < T || (b == T && r <= P)) {
+            const int at = atomicAdd(&sh_fill, 1);
+            if (at < np2) {
+                xsb_d[at] = v;
+                xsb_i[at] = r;
+            }
+        }
+    }
+    __syncthreads();
+    for (int size = 2; size <= np2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < (np2 >> 1); t += XSB_T) {
+                const int i = 2 * t - (t & (stride - 1)), j = i + stride;
+                const double a = xsb_d[i], b = xsb_d[j];
+                const int ai = xsb_i[i], bi = xsb_i[j];
+                if (key_less(b, bi, a, ai) == ((i & size) == 0)) {
+                    xsb_d[i] = b;
+                    xsb_d[j] = a;
+                    xsb_i[i] = bi;
+                    xsb_i[j] = ai;
+                }
+            }
+            __syncthreads();
+        }
+    for (int j = tid; j < k; j += XSB_T) {
+        idx_out[(int64_t)q * k + j] = xsb_i[j];
+        if (dist_out) dist_out[(int64_t)q * k + j] = sqrt(xsb_d[j]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // 4b. fast exact path for a FEW flagged queries: the k-th candidate distance bounds the true k-th neighbour from
 //     above, so one pass that stages each reference tile once in LDS, evaluates it against every flagged query in
@@ -1166,7 +1256,16 @@ void exact_search(hipStream_t stream, KnnWorkspace& ws, const double* X, const i
             hipLaunchKernelGGL(knn_exact_dist, dim3(cdiv(nr, 256), nb), dim3(256), 0, stream, X, ref_rows, nr, Qs, qrs, d,
                                scan_list, f0, drow);
             BMX_LAUNCH_CHECK();
-            hipLaunchKernelGGL(knn_exact_select, dim3(nb), dim3(256), 0, stream, drow, nr, k, scan_list, f0, io, dout);
+            if (k > 64 && k <= XSB_MAXK) {
+                int np2 = 128;
+                while (np2 < k) np2 <<= 1;
+                const size_t lds = (size_t)np2 * (sizeof(double) + sizeof(int));
+                ensure_dynamic_lds(reinterpret_cast<const void*>(&knn_exact_select_big), lds);
+                hipLaunchKernelGGL(knn_exact_select_big, dim3(nb), dim3(XSB_T), lds, stream, drow, nr, k, np2, scan_list, f0, io,
+                                   dout);
+            } else {
+                hipLaunchKernelGGL(knn_exact_select, dim3(nb), dim3(256), 0, stream, drow, nr, k, scan_list, f0, io, dout);
+            }
             BMX_LAUNCH_CHECK();
         }
     }

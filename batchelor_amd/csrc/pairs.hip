@@ -209,6 +209,108 @@ __global__ void emit_pairs_kernel(const int32_t* __restrict__ idxLR, int nL, int
     }
 }
 
+// ---- k2 > 64 (prop.k runs: k = 1 000 at 100 000 cells) -------------------------------------------------------------
+// The probes above read a whole row per question: nL * k2 * k1 words, 0.83 s of a 1.7 s step at k = 1 000.  The reference
+// sorts nothing either but asks a per-cell set (src/find_mutual_nns.cpp:23-36); here every row is sorted once
+// (sort_rows_kernel) and a question is a binary search.  One wave per row; the hits of 64 entries are ranked by a ballot,
+// so a right cell's partners come out ascending (its sorted row is walked in order) and a left cell's pairs in neighbour
+// rank order (its row is walked as the search wrote it) -- the orders the linear kernels produce.
+__global__ __launch_bounds__(256) void sort_rows_kernel(const int32_t* __restrict__ in, int n_rows, int k, int np2,
+                                                        int32_t* __restrict__ out) {
+    extern __shared__ int32_t sh_row[];
+    for (int row = blockIdx.x; row < n_rows; row += gridDim.x) {
+        for (int i = threadIdx.x; i < np2; i += 256) sh_row[i] = i < k ? in[(int64_t)row * k + i] : INT32_MAX;
+        __syncthreads();
+        for (int size = 2; size <= np2; size <<= 1)
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int t = threadIdx.x; t < (np2 >> 1); t += 256) {
+                    const int i = 2 * t - (t & (stride - 1)), j = i + stride;
+                    const int32_t a = sh_row[i], b = sh_row[j];
+                    if ((a > b) == ((i & size) == 0)) {
+                        sh_row[i] = b;
+                        sh_row[j] = a;
+                    }
+                }
+                __syncthreads();
+            }
+        for (int i = threadIdx.x; i < k; i += 256) out[(int64_t)row * k + i] = sh_row[i];
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ bool sorted_contains(const int32_t* __restrict__ row, int k, int32_t want) {
+    int lo = 0, hi = k;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (row[mid] < want) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo < k && row[lo] == want;
+}
+
+__global__ __launch_bounds__(256) void mutual_left_sorted(const int32_t* __restrict__ idxLR, int nL, int k2,
+                                                          const int32_t* __restrict__ sortedRL, int k1,
+                                                          const int32_t* __restrict__ lsel, int32_t* __restrict__ cntL) {
+    const int c0 = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c0 >= nL) return;
+    const int l = lsel ? lsel[c0] : c0;
+    int c = 0;
+    for (int base = 0; base < k2; base += 64) {
+        const int j = base + lane;
+        const int32_t r = j < k2 ? idxLR[(int64_t)c0 * k2 + j] : -1;
+        const bool hit = r >= 0 && sorted_contains(sortedRL + (int64_t)r * k1, k1, l);
+        c += __popcll(__ballot(hit));
+    }
+    if (lane == 0) cntL[c0] = c;
+}
+
+__global__ __launch_bounds__(256) void mutual_right_sorted(const int32_t* __restrict__ sortedLR, int k2,
+                                                           const int32_t* __restrict__ sortedRL, int nR, int k1,
+                                                           const int32_t* __restrict__ lpos2c, int32_t* __restrict__ partR,
+                                                           int32_t* __restrict__ cntR) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= nR) return;
+    int m = 0;
+    for (int base = 0; base < k1; base += 64) {
+        const int j = base + lane;
+        const int32_t l = j < k1 ? sortedRL[(int64_t)r * k1 + j] : -1;
+        bool hit = false;
+        if (l >= 0) {
+            const int64_t c = lpos2c ? lpos2c[l] : l;
+            hit = sorted_contains(sortedLR + c * k2, k2, r);
+        }
+        const unsigned long long b = __ballot(hit);
+        if (hit) partR[(int64_t)r * k1 + m + __popcll(b & ((1ull << lane) - 1ull))] = l;  // ascending left cells
+        m += __popcll(b);
+    }
+    if (lane == 0) cntR[r] = m;
+}
+
+__global__ __launch_bounds__(256) void emit_pairs_sorted(const int32_t* __restrict__ idxLR, int nL, int k2,
+                                                         const int32_t* __restrict__ sortedRL, int k1,
+                                                         const int32_t* __restrict__ offL, const int32_t* __restrict__ lsel,
+                                                         const int32_t* __restrict__ lrows, const int32_t* __restrict__ rrows,
+                                                         int32_t* __restrict__ first, int32_t* __restrict__ second) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= nL) return;
+    int o = offL[c];
+    if (o == offL[c + 1]) return;  // no pair starts at this left cell (uniform over the wave)
+    const int l = lsel ? lsel[c] : c;
+    const int32_t lid = (lrows ? lrows[l] : l) + 1;
+    for (int base = 0; base < k2; base += 64) {
+        const int j = base + lane;
+        const int32_t r = j < k2 ? idxLR[(int64_t)c * k2 + j] : -1;
+        const bool hit = r >= 0 && sorted_contains(sortedRL + (int64_t)r * k1, k1, l);
+        const unsigned long long b = __ballot(hit);
+        if (hit) {
+            const int at = o + __popcll(b & ((1ull << lane) - 1ull));
+            first[at] = lid;
+            second[at] = (rrows ? rrows[r] : r) + 1;
+        }
+        o += __popcll(b);
+    }
+}
+
 // stamp[row] = gen for every row some list names (the stamps are never cleared: each search brings its own number)
 __global__ void mark_listed(const int32_t* __restrict__ idx, int64_t n, int32_t* __restrict__ stamp, int gen) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -268,12 +370,41 @@ void exclusive_scan_i32(hipStream_t stream, ScanWorkspace& ws, const int32_t* in
     BMX_LAUNCH_CHECK();
 }
 
+bool sorted_rows_apply(int k1, int k2) { return k2 > 64 && k2 <= 8192 && k1 <= 8192; }
+
+// rows of `in` [n_rows][k], each sorted ascending (-1 = "no neighbour" first), into buf
+static const int32_t* sort_rows(hipStream_t stream, const int32_t* in, int n_rows, int k, DevBuf<int32_t>& buf) {
+    int32_t* out = buf.reserve(std::max<size_t>(1, (size_t)n_rows * k));
+    if (n_rows <= 0) return out;
+    int np2 = 2;
+    while (np2 < k) np2 <<= 1;
+    hipLaunchKernelGGL(sort_rows_kernel, dim3(std::min(n_rows, 1 << 16)), dim3(256), (size_t)np2 * sizeof(int32_t), stream, in,
+                       n_rows, k, np2, out);
+    BMX_LAUNCH_CHECK();
+    return out;
+}
+
 void mutual_counts(hipStream_t stream, const int32_t* idxLR, int nL, int k2, const int32_t* idxRL, int nR, int k1,
                    int32_t* cntL, int32_t* partR, int32_t* cntR, const int32_t* lsel, const int32_t* lpos2c,
-                   unsigned long long* maskL, bool mask_is_clear, const double* distRL, const double* kthL) {
+                   unsigned long long* maskL, bool mask_is_clear, const double* distRL, const double* kthL,
+                   SortedRows* sorted) {
     // k2 <= 64 (and a mask buffer): the right cells' probe finds every mutual pair once and marks it on both sides (the
     // pairs of a left cell are then the popcount of its mask); otherwise the left side is probed separately into cntL
     const bool fused = maskL != nullptr && k2 <= 64;
+    if (sorted && sorted_rows_apply(k1, k2)) {
+        const int32_t* sLR = sort_rows(stream, idxLR, nL, k2, sorted->lr);
+        const int32_t* sRL = sort_rows(stream, idxRL, nR, k1, sorted->rl);
+        if (nL > 0) {
+            hipLaunchKernelGGL(mutual_left_sorted, dim3(cdiv(nL, 4)), dim3(256), 0, stream, idxLR, nL, k2, sRL, k1, lsel, cntL);
+            BMX_LAUNCH_CHECK();
+        }
+        if (nR > 0) {
+            hipLaunchKernelGGL(mutual_right_sorted, dim3(cdiv(nR, 4)), dim3(256), 0, stream, sLR, k2, sRL, nR, k1, lpos2c,
+                               partR, cntR);
+            BMX_LAUNCH_CHECK();
+        }
+        return;
+    }
     if (fused && nL > 0 && !mask_is_clear) BMX_HIP(hipMemsetAsync(maskL, 0, (size_t)nL * sizeof(unsigned long long), stream));
     if (!fused && nL > 0) {
         hipLaunchKernelGGL(mutual_left, dim3(cdiv(nL, 256)), dim3(256), 0, stream, idxLR, nL, k2, idxRL, k1, lsel,
@@ -304,8 +435,14 @@ void pair_scans(hipStream_t stream, ScanWorkspace& ws, const unsigned long long*
 
 void emit_pairs(hipStream_t stream, const int32_t* idxLR, int nL, int k2, const int32_t* idxRL, int k1,
                 const int32_t* offL, const int32_t* lrows, const int32_t* rrows, int32_t* first, int32_t* second,
-                const int32_t* lsel, const unsigned long long* maskL) {
+                const int32_t* lsel, const unsigned long long* maskL, const SortedRows* sorted) {
     if (nL <= 0) return;
+    if (sorted && sorted_rows_apply(k1, k2)) {  // (sorted->rl: the rows mutual_counts sorted for this idxRL)
+        hipLaunchKernelGGL(emit_pairs_sorted, dim3(cdiv(nL, 4)), dim3(256), 0, stream, idxLR, nL, k2,
+                           (const int32_t*)sorted->rl.p, k1, offL, lsel, lrows, rrows, first, second);
+        BMX_LAUNCH_CHECK();
+        return;
+    }
     hipLaunchKernelGGL(emit_pairs_kernel, dim3(cdiv(nL, 256)), dim3(256), 0, stream, idxLR, nL, k2, idxRL, k1, offL,
                        lsel, lrows, rrows, k2 <= 64 ? maskL : nullptr, first, second);
     BMX_LAUNCH_CHECK();

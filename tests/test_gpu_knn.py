@@ -96,6 +96,20 @@ def test_query_knn_k_beyond_900_with_exact_duplicates(oracle, nb):
     assert np.array_equal(idx, oi) and np.array_equal(dist, od)
 
 
+@pytest.mark.parametrize("nx,nq,d,k,dup", [(3000, 150, 130, 100, 1), (2500, 60, 140, 65, 4), (9000, 40, 128, 2049, 3),
+                                           (700, 30, 200, 700, 2), (8192, 20, 129, 8192, 1)])
+def test_full_scan_selection_beyond_64_neighbours(oracle, nb, nx, nq, d, k, dup):
+    """d > 127: every query takes the FP64 scan; k > 64: its selection is the bisection on the distances' bit patterns
+    (knn.hip: knn_exact_select_big).  Each reference cell `dup` times: the k-th place falls among equal distances and is
+    decided by position, as the reference's search order decides it."""
+    X0, Q = synth_batches(11, [nx // dup, nq], d)
+    X = np.concatenate([X0] * dup)
+    idx, dist = nb.query_knn(X, Q, k)
+    oi, od = oracle.query_knn(X, Q, k)
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+    assert nb.last_knn_exact_fallbacks() == nq
+
+
 def test_query_knn_beyond_the_tiers_lists_clustered(oracle, nb):
     # a reference whose ORDER follows its geometry (cells sorted by cluster): the strided deal keeps every partition a fair
     # sample of every cluster; with contiguous partitions a query's neighbours would all sit in one

@@ -26,6 +26,29 @@ def test_find_mutual_nns(oracle, nat):
     assert np.array_equal(f, of) and np.array_equal(s, os_)
 
 
+@pytest.mark.parametrize("nL,nR,k1,k2", [(1500, 1200, 300, 200), (900, 1100, 20, 65), (1200, 700, 1000, 70),
+                                         (300, 400, 33, 257), (64, 9000, 64, 8192)])
+def test_find_mutual_nns_beyond_64_neighbours(oracle, nat, nL, nR, k1, k2):
+    """k2 > 64: the lists are sorted row by row and probed by binary search (pairs.hip, SortedRows) -- same pairs, same
+    order (src/find_mutual_nns.cpp:23-36) as the set lookups of the reference."""
+    rng = np.random.default_rng(nL + k2)
+    L = np.vstack([rng.permutation(nR)[:k2] + 1 for _ in range(nL)])
+    R = np.vstack([rng.permutation(nL)[:k1] + 1 for _ in range(nR)])
+    f, s = nat.find_mutual_nns(L, R)
+    of, os_ = oracle.find_mutual_nns(L, R)
+    assert len(of) > 0
+    assert np.array_equal(f, of) and np.array_equal(s, os_)
+
+
+def test_find_mutual_nn_k_100(oracle, nat):
+    rng = np.random.default_rng(1200011)
+    t1 = rng.standard_normal((800, 6))
+    t2 = rng.standard_normal((1500, 6)) + 0.3
+    f, s = nat.find_mutual_nn(t1, t2, 100, 130)
+    of, os_ = oracle.find_mutual_nn(t1, t2, 100, 130)
+    assert np.array_equal(f, of) and np.array_equal(s, os_)
+
+
 def test_find_mutual_nn_and_average_correction(oracle, nat):
     rng = np.random.default_rng(1200001)
     t1 = rng.standard_normal((1000, 10))
