@@ -185,6 +185,7 @@ int32_t bmx_dev_set(const char* name, int32_t value) {
     else if (n == "asv_fast") k.asv_fast = value;
     else if (n == "asv_cap") k.asv_cap = value;
     else if (n == "sample_split") k.sample_split = value;
+    else if (n == "lk_seed") k.lk_seed = value;
     else if (n == "asv_modes") k.asv_modes = value;
     else if (n == "asv_sync") k.asv_sync = value;
     else if (n == "tau_replay") k.tau_replay = value;

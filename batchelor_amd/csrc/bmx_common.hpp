@@ -59,6 +59,7 @@ struct DevKnobs {
     int asv_modes = 0;        // tiled form: record which way each of the first n cells of a call went (bmx_dev_get_bytes)
     int asv_sync = 0;         // tiled form: 1 = the workgroups start each round of tiles together (measured slower twice: rounds 4 and 6)
     int tau_replay = 0;       // developer experiment: 1 record every search's final thresholds, 2 start the full passes from them
+    int lk_seed = 1;          // k beyond the tiers' lists: partitions after the first searched within the first's kp-th distance (0: plainly)
     int sample_split = -1;    // ranges of the threshold sample of a search with few query blocks (-1: automatic, 0: never, n: that many)
     int exchange_always = 0;  // a single rank goes through its exchange transport too (an all-gather of one)
     int refine_wave = 0;      // the exact re-rank takes a whole wave for every query (no half-wave form)
@@ -342,6 +343,8 @@ struct KnnWorkspace {
     // k-th candidate distances, and the scratch of the sub-search the next tier runs on them
     DevBuf<int32_t> flagged_t[2], sub_rows[2], sub_idx[2];
     DevBuf<int32_t> lk_rows, lk_idx;  // k > 36: the partitions' row lists, their neighbour lists [P][nq][36]
+    DevBuf<double> lk_kth;            // ... the first partition's kp-th distances
+    DevBuf<float> lk_seed;            // ... and the seeds of the other partitions' searches made of them
     DevBuf<double> flag_bound_t[2], sub_dist[2];
     DevBuf<double> drow;           // exact-path distance rows
     DevBuf<double> xd;             // short exact lists

@@ -1346,6 +1346,17 @@ void search_tiers(hipStream_t stream, KnnWorkspace& ws, const Tier* tiers, int n
 // ---------------------------------------------------------------------------------------------------
 constexpr int LK_MAXE = 2048;  // candidates merged per query
 
+// seed[q] = the first partition's kp-th distance squared, rounded up to f32 (+inf where that row was not certified): sqrt,
+// then squared again -- never below the true value
+__global__ void lk_seed_kernel(const double* __restrict__ kth, int nq, float* __restrict__ seed) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const double dd = kth[q] * kth[q] * (1.0 + 1e-15);
+    float f = (float)dd;
+    if ((double)f < dd) f = __uint_as_float(__float_as_uint(f) + 1u);  // dd >= 0: the next float up
+    seed[q] = dd < __builtin_inf() ? f : __builtin_inff();
+}
+
 // rows[off_p + j] = the (p + j P)-th row of the caller's reference list, partition-major
 __global__ void lk_partition_rows(const int32_t* __restrict__ ref_rows, int nr, int P, int32_t* __restrict__ rows) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1361,7 +1372,8 @@ __global__ __launch_bounds__(256) void lk_merge(const double* __restrict__ X, co
                                                 int kp, const double* __restrict__ Q, const int32_t* __restrict__ qrs, int nq,
                                                 int d, int k, const int32_t* __restrict__ sub_idx, int32_t* __restrict__ idx_out,
                                                 double* __restrict__ dist_out, int32_t* __restrict__ flagged,
-                                                int32_t* __restrict__ opt, double* __restrict__ kth_out) {
+                                                int32_t* __restrict__ opt, double* __restrict__ kth_out,
+                                                const float* __restrict__ seed_d2) {
     __shared__ double kd[LK_MAXE];
     __shared__ int32_t ki[LK_MAXE];
     __shared__ int sh_fail;
@@ -1421,6 +1433,8 @@ __global__ __launch_bounds__(256) void lk_merge(const double* __restrict__ X, co
         const int g = ki[r], p = g % P, l = g / P;
         if (sub_idx[((int64_t)p * nq + q) * kp + kp - 1] == l) sh_fail = 1;
     }
+    // partitions searched within the seed distance (large_k_search) are complete up to it only: the k-th must lie inside
+    if (tid == 0 && seed_d2 && !(kd[k - 1] < (double)seed_d2[q])) sh_fail = 1;
     __syncthreads();
     // (the intersection's probe skips a row whose k-th distance it knows to be too small: exact here when the merge stands)
     if (tid == 0 && kth_out) kth_out[q] = sh_fail ? __builtin_inf() : sqrt(kd[k - 1]);
@@ -1439,7 +1453,7 @@ __global__ __launch_bounds__(256) void lk_merge_wave(const double* __restrict__ 
                                                      int nq, int d, int k, const int32_t* __restrict__ sub_idx,
                                                      int32_t* __restrict__ idx_out, double* __restrict__ dist_out,
                                                      int32_t* __restrict__ flagged, int32_t* __restrict__ opt,
-                                                     double* __restrict__ kth_out) {
+                                                     double* __restrict__ kth_out, const float* __restrict__ seed_d2) {
     __shared__ double kd_[4][512];
     __shared__ int32_t ki_[4][512];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1503,11 +1517,11 @@ __global__ __launch_bounds__(256) void lk_merge_wave(const double* __restrict__ 
             if (rank == k - 1) kthv = de;
         }
     }
-    const bool any_fail = __builtin_amdgcn_ballot_w64(fail) != 0;
-    if (kth_out) {
-        for (int o = 32; o > 0; o >>= 1) kthv = fmax(kthv, __shfl_xor(kthv, o));
-        if (lane == 0) kth_out[q] = any_fail || kthv < 0.0 ? __builtin_inf() : sqrt(kthv);
-    }
+    bool any_fail = __builtin_amdgcn_ballot_w64(fail) != 0;
+    for (int o = 32; o > 0; o >>= 1) kthv = fmax(kthv, __shfl_xor(kthv, o));
+    // partitions searched within the seed distance (large_k_search) are complete up to it only: the k-th must lie inside
+    if (seed_d2 && !(kthv >= 0.0 && kthv < (double)seed_d2[q])) any_fail = true;
+    if (kth_out && lane == 0) kth_out[q] = any_fail || kthv < 0.0 ? __builtin_inf() : sqrt(kthv);
     if (any_fail && lane == 0) {
         if (opt) atomicOr(opt, 1);
         else flagged[1 + atomicAdd(&flagged[0], 1)] = q;
@@ -1531,7 +1545,7 @@ __global__ __launch_bounds__(LKB_T) void lk_merge_big(const double* __restrict__
                                                       int nq, int d, int k, const int32_t* __restrict__ sub_idx,
                                                       int32_t* __restrict__ idx_out, double* __restrict__ dist_out,
                                                       int32_t* __restrict__ flagged, int32_t* __restrict__ opt,
-                                                      double* __restrict__ kth_out) {
+                                                      double* __restrict__ kth_out, const float* __restrict__ seed_d2) {
     extern __shared__ __attribute__((aligned(16))) char lkb_smem[];
     __shared__ int sh_cnt[LKB_T / 64];
     __shared__ int sh_fail, sh_base;
@@ -1597,6 +1611,17 @@ __global__ __launch_bounds__(LKB_T) void lk_merge_big(const double* __restrict__
         const unsigned long long trial = vk | ((1ull << b) - 1ull);  // the largest value with the bits decided so far and this bit clear
         const int c = count_block([&](unsigned long long v, int) { return v <= trial; });
         if (c < k) vk |= 1ull << b;
+    }
+    // partitions searched within the seed distance (large_k_search) are complete up to it only: the k-th must lie inside.
+    // (Fewer than k candidates in all -- seeded lists may be short -- leaves vk beyond +inf: nothing to select, the query goes
+    // to the exact scan.)  vk is the same on every thread.
+    if (vk >= 0x7FF0000000000000ull || (seed_d2 && !(__longlong_as_double((long long)vk) < (double)seed_d2[q]))) {
+        if (tid == 0) {
+            if (kth_out) kth_out[q] = __builtin_inf();
+            if (opt) atomicOr(opt, 1);
+            else flagged[1 + atomicAdd(&flagged[0], 1)] = q;
+        }
+        return;
     }
     // ... and among the candidates AT that distance the m with the smallest positions (exact duplicates: rare)
     const int below = count_block([&](unsigned long long v, int) { return v < vk; });
@@ -1701,11 +1726,23 @@ bool large_k_search(hipStream_t stream, KnnWorkspace& ws, const double* X, const
     hipLaunchKernelGGL(lk_partition_rows, dim3(cdiv(nr, 256)), dim3(256), 0, stream, ref_rows, nr, P, rows);
     BMX_LAUNCH_CHECK();
     const int base = nr / P, rem = nr % P;
+    // The partitions are strided samples of one reference: a query's kp-th distance in the first is about its kp-th distance in
+    // every other.  So the first is searched plainly and its (certified) kp-th distance seeds the rest: their thresholds start
+    // there instead of at +inf -- a partition of ~1 400 cells is otherwise one long warm-up, every early value a survivor for the
+    // service waves (1.34 ms a launch at k = 1 000 against 13 us of matrix work).  A seeded list is complete up to the seed only;
+    // the merges' certificate asks the k-th merged distance to lie inside it.
+    const bool seeded = dev_knobs().lk_seed != 0 && P >= 3;
+    double* kth0 = seeded ? ws.lk_kth.reserve((size_t)nq) : nullptr;
+    float* seed = seeded ? ws.lk_seed.reserve((size_t)nq) : nullptr;
     for (int p = 0; p < P; ++p) {
         const int n_p = base + (p < rem ? 1 : 0);
         const int nt = candidate_tiers(d, kp, n_p, tiers);
         search_tiers(stream, ws, tiers, nt, 0, X, rows + (int64_t)p * base + std::min(p, rem), n_p, Qs, qrs, nq, d, kp,
-                     sub + (int64_t)p * nq * kp, nullptr, nullptr, centre, nullptr);
+                     sub + (int64_t)p * nq * kp, nullptr, p > 0 ? seed : nullptr, centre, p == 0 ? kth0 : nullptr);
+        if (p == 0 && seeded) {
+            hipLaunchKernelGGL(lk_seed_kernel, dim3(cdiv(nq, 256)), dim3(256), 0, stream, (const double*)kth0, nq, seed);
+            BMX_LAUNCH_CHECK();
+        }
     }
     int32_t* flagged = ws.flagged_t[0].reserve((size_t)nq + 1);
     int32_t* opt = ws.optimistic ? ws.opt_state_ptr(stream) : nullptr;
@@ -1716,13 +1753,13 @@ bool large_k_search(hipStream_t stream, KnnWorkspace& ws, const double* X, const
         const size_t lds = np2 * 12;
         ensure_dynamic_lds(reinterpret_cast<const void*>(&lk_merge_big), lds);
         hipLaunchKernelGGL(lk_merge_big, dim3(nq), dim3(LKB_T), lds, stream, X, (const int32_t*)rows, nr, P, kp, Qs, qrs, nq, d, k,
-                           (const int32_t*)sub, io, dout, flagged, opt, kth_out);
+                           (const int32_t*)sub, io, dout, flagged, opt, kth_out, (const float*)seed);
     } else if (P * kp <= 512)
         hipLaunchKernelGGL(lk_merge_wave, dim3(cdiv(nq, 4)), dim3(256), 0, stream, X, (const int32_t*)rows, nr, P, kp, Qs, qrs, nq,
-                           d, k, (const int32_t*)sub, io, dout, flagged, opt, kth_out);
+                           d, k, (const int32_t*)sub, io, dout, flagged, opt, kth_out, (const float*)seed);
     else
         hipLaunchKernelGGL(lk_merge, dim3(nq), dim3(256), 0, stream, X, (const int32_t*)rows, nr, P, kp, Qs, qrs, nq, d, k,
-                           (const int32_t*)sub, io, dout, flagged, opt, kth_out);
+                           (const int32_t*)sub, io, dout, flagged, opt, kth_out, (const float*)seed);
     BMX_LAUNCH_CHECK();
     if (!opt) {
         const int count = read_count(stream, ws, flagged);

@@ -102,7 +102,8 @@ void bmx_set_force_exact_knn(int32_t on);
  * re-run), "asv_modes" (n: the tiled form records which way each of the first n cells of a call went, see
  * bmx_dev_get_bytes), "asv_sync" (0: the tiled form's workgroups do not wait for each other at the start of a round of
  * tiles -- the default; 1 = they do, measured slower), "sample_split" (ranges the threshold sample of a search with few
- * query blocks is split into; -1 = automatic, the default; 0 = never), "tau_replay" (developer experiment: 1 = every search of
+ * query blocks is split into; -1 = automatic, the default; 0 = never), "lk_seed" (searches with k beyond the tiers' lists: 1 = the
+ * reference's partitions after the first are searched within the first's 36th distance, the default; 0 = all plainly), "tau_replay" (developer experiment: 1 = every search of
  * a run records its queries' final thresholds, 2 = the same sequence of searches starts its full passes from them), "reset"
  * (all back to their defaults).
  * Unknown name: BMX_ERR_ARG. */

@@ -110,6 +110,29 @@ def test_full_scan_selection_beyond_64_neighbours(oracle, nb, nx, nq, d, k, dup)
     assert nb.last_knn_exact_fallbacks() == nq
 
 
+@pytest.mark.parametrize("k", [100, 300, 1000])
+def test_large_k_partitions_seeded_by_the_first(oracle, nb, dev, k):
+    """knn.hip, large_k_search: the partitions (reference rows g with the same g % P) after the first are searched within the
+    first's 36th distance.  Same answers with and without; and the case the seed is worthless for: 40 exact copies of a query,
+    all in the first partition -- its 36th distance is 0, the other partitions' lists come back empty, fewer than k candidates in
+    all: the certificate must send those queries to the exact scan."""
+    P = max(2, -(-k // 16))
+    if P * 36 > 2048:
+        P = -(-k // 14)
+    X, Q = synth_batches(21, [30000, 300], 40)
+    for j in range(6):
+        X[(np.arange(40) + 40 * j) * P] = Q[j]       # rows that are multiples of P: the first partition
+    oi, od = oracle.query_knn(X, Q, k)
+    for seeded in (1, 0):
+        dev("lk_seed", seeded)
+        idx, dist = nb.query_knn(X, Q, k)
+        assert np.array_equal(idx, oi) and np.array_equal(dist, od), seeded
+        if seeded:
+            # (the six, and their rows in the other partitions: a seed of 0 certifies nothing, the bounded FP64 sweep finds
+            # the empty answer; plain queries: none -- scripts/lk_seed_probe.py)
+            assert 6 <= nb.last_knn_exact_fallbacks() <= 6 * P
+
+
 def test_query_knn_beyond_the_tiers_lists_clustered(oracle, nb):
     # a reference whose ORDER follows its geometry (cells sorted by cluster): the strided deal keeps every partition a fair
     # sample of every cluster; with contiguous partitions a query's neighbours would all sit in one
