@@ -24,7 +24,7 @@ for case in range(cases):
     if mode == 1:
         # (k <= 2 with more than two batches is degenerate -- a cell with one pair lands on its partner up to an ulp and
         # the next merge has to tell the two apart: checked up to such twins, tests/test_gpu_degenerate_k.py)
-        kw["k"] = int(rng.choice([1, 2, 5, 10, 25, 30, 40]))
+        kw["k"] = int(rng.choice([1, 2, 5, 10, 25, 30, 40, 70, 120]))
     elif mode == 2:
         kw["prop_k"] = float(rng.choice([0.01, 0.05, 0.1]))
     elif mode == 3:
