@@ -993,6 +993,11 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
 #else
         const bool lit_on = lcap > 0;
 #endif
+#ifdef BMX_ASV_AB_NOSO  // timing build: the literal re-run without the own batch's packed pairs (its results are then wrong)
+        const bool so_on = false;
+#else
+        const bool so_on = true;
+#endif
         double om[4], oa[4], ob[4];
         double mx1[4], mx2[4], lo[4], hi[4], cp[4], cn[4];
 #pragma unroll
@@ -1181,14 +1186,14 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                         const int slot = (kq + 4 * i + blk + rot0) & (AT_C - 1);  // == at(kq + 4 i, jo)
                         sp_[slot * 64] = pr;
                         sw_[slot * 64] = lw;
-                    } else if (lit_on) {
+                    } else if (lit_on && so_on) {
                         // (s_ = the cell's projection minus this one's; tol_tile >= the rounding of the two, for every cell of the tile)
                         const unsigned code = self ? 3u : (s_ >= tol_tile ? 2u : (s_ >= -tol_tile ? 1u : 0u));
                         oc[i] = __uint_as_float((__float_as_uint((float)fmax(lw, -3.0e38)) & ~3u) | code);
                     }
                 }
                 // (this lane's four cells kq, kq + 4, kq + 8, kq + 12 of one streamed cell: one 16-byte store, 16 lanes a 256-byte run)
-                if (own && lit_on) so_[(int64_t)blk * (AT_C * 16)] = oc;
+                if (own && lit_on && so_on) so_[(int64_t)blk * (AT_C * 16)] = oc;
             };
             double ba[NST];
             int64_t j0 = 0;
