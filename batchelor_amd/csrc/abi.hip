@@ -203,13 +203,16 @@ int32_t bmx_dev_get(const char* name, int64_t* value) {
     if (!name || !value) return BMX_ERR_ARG;
     return guarded([&] {
         const std::string n(name);
-        unsigned long long t[3];
+        unsigned long long t[8];
         if (n == "asv_literal_cells" || n == "asv_fallback_cells" || n == "asv_tiled_cells") {
             bmx::asv_tally_read(t, false);
             *value = (int64_t)t[n == "asv_literal_cells" ? 0 : (n == "asv_fallback_cells" ? 1 : 2)];
         } else if (n == "asv_ticks_stream" || n == "asv_ticks_wait" || n == "asv_ticks_cells") {
             bmx::asv_ticks_read(t);
             *value = (int64_t)t[n == "asv_ticks_stream" ? 0 : (n == "asv_ticks_wait" ? 1 : 2)];
+        } else if (n == "asv_ticks_literal" || n == "asv_ticks_chains" || n == "asv_literal_addends" || n == "asv_chain_tiles") {
+            bmx::asv_ticks_read(t);
+            *value = (int64_t)t[n == "asv_ticks_literal" ? 4 : (n == "asv_ticks_chains" ? 5 : (n == "asv_literal_addends" ? 6 : 7))];
         } else if (n == "asv_tally_reset") {
             bmx::asv_tally_read(t, true);
             *value = 0;

@@ -186,7 +186,7 @@ struct AsvPlan {
 AsvPlan adjust_shift_variance_plan(int g, int n2, int nr1, int nr2, int vect_row_major);
 // counters of the tiled form on the current device: {cells re-run literally, flagged cells beyond lcap, all cells}
 void asv_tally_read(unsigned long long out[3], bool reset);
-void asv_ticks_read(unsigned long long out[3]);  // diagnostics: 100 MHz ticks in the stream / at the round barrier / per-cell phase
+void asv_ticks_read(unsigned long long out[8]);  // diagnostics: 100 MHz ticks in the stream / at the round barrier / per-cell phase / -; literal cells: selection + re-evaluation, chains, kept addends, tiles
 void asv_modes_read(unsigned char* dst, size_t n);  // testing hook "asv_modes": the way each cell of the last call went
 // out[c] for the cells c in [cell_begin, cell_end) only (cell_end < 0: n2) -- the unit a multi-GPU run shards by
 void adjust_shift_variance_device(hipStream_t stream, const double* data1, int g, int n1, const double* data2, int n2,

@@ -855,7 +855,7 @@ __global__ __launch_bounds__(256) void asv_max_norm(double* __restrict__ snrm, i
 // current ones multiply.  NB8 = 0: the staged form (any g <= 256).
 // diagnostics (bmx_dev_get "asv_ticks_stream" / "_wait" / "_cells"): 100 MHz ticks the workgroups of the tiled form spent in the
 // stream, at the round barrier and in the per-cell phase, added up over all workgroups since the last "asv_tally_reset"
-__device__ unsigned long long g_asv_ticks[4];
+__device__ unsigned long long g_asv_ticks[8];  // stream, barrier wait, per-cell phase, (spare); literal cells: selection + re-evaluation + sort, chains + walk, kept addends, tiles with chains
 
 template <int NB8>
 __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __restrict__ data2, int n2,
@@ -918,6 +918,7 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
     const int ntiles = (cell_end - cell_begin + AT_C - 1) / AT_C;
     const double NEG = -__builtin_inf(), POS = __builtin_inf();
     unsigned long long tk_stream = 0, tk_wait = 0, tk_cells = 0, tk0 = 0, tk1 = 0;  // (thread 0's)
+    unsigned long long tk_lit = 0, tk_chain = 0, tk_lit_n = 0, tk_chain_tiles = 0;   // (the literal re-run's share of tk_cells)
 
     // Tiles are handed out as workgroups come free (round 6: a counter on the device): a tile with flagged cells takes several
     // times a plain one -- with tiles dealt in a fixed stride the workgroups of a launch ended 11 % apart on config 5 at
@@ -1429,6 +1430,7 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                     const int cGtot = smi[0];
                     __syncthreads();
                     if (cGtot <= lcap_c) {
+                        const unsigned long long tkl0 = __builtin_amdgcn_s_memrealtime();
                         // ================= the literal re-run (see the comment in front of asv_noop_below) =================
                         const double cn_c = sc_n[c];
                         const double mb = 1e-3 + 1e-13 * (cn_c + nmax_s) / sigma2;      // >= the rounding of a GEMM-form log-weight
@@ -1716,8 +1718,10 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
                             }
                             literal = true;
                             ++n_lit;
+                            tk_lit_n += (unsigned long long)KO + KR + KS;
                             __syncthreads();
                         }
+                        tk_lit += __builtin_amdgcn_s_memrealtime() - tkl0;
                     }
                     if (!literal) ++n_back;
                     cell_mode = literal ? 1 : 2;
@@ -1839,50 +1843,115 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
         // ---- the literal re-run's chains: one lane per chain, the reference's sequential sums (:96-109, :127-131), then
         // one lane per cell for the walk (:137-157)
         if (lit_on) {
+            const unsigned long long tkc0 = __builtin_amdgcn_s_memrealtime();
+            const bool any_lit = n_lit > 0;  // (thread 0's count is the tile's)
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");  // (the lists were written by other threads of the block)
             const double* LO = SW + (int64_t)AT_C * Npad;
             const double* LR = LO + (int64_t)AT_C * lcap * 2;
             const double* LS = LR + (int64_t)AT_C * lcap;
-            if (tid < 3 * AT_C) {
-                const int c = tid & (AT_C - 1), which = tid >> 4;
+            // (one WAVE per kind of sum -- total, counted, reference, walk --, a lane per cell: lanes of one wave on different
+            // kinds would take their loops one after the other)
+            static_assert(T == 256, "the chains take the block's four waves");
+            if (lane < AT_C) {
+                const int c = lane, which = w;
                 const int KO = sh_K[c][0];
                 if (KO >= 0) {
                     double acc = 0.0;
                     bool first = true;
+                    // (a chain is ONE lane's sequential sum: its addends are asked for eight at a time, ahead of the adds that use
+                    // them -- one by one, a step of the chain was a global load's round trip plus the add: 0.95 us, 59 ms for a
+                    // cell of config 5 at sigma 1 with 94 000 kept addends, the launch waiting for it)
                     if (which < 2) {
                         const double* L = LO + (int64_t)c * lcap * 2;
-                        for (int i = 0; i < KO; ++i) {
+                        int i = 0;
+                        for (; i + 8 <= KO; i += 8) {
+                            double lw[8], fl[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                lw[u] = L[2 * (i + u)];
+                                fl[u] = L[2 * (i + u) + 1];
+                            }
+#pragma unroll
+                            for (int u = 0; u < 8; ++u)
+                                if (which == 0 || fl[u] != 0.0) {
+                                    acc = first ? lw[u] : bmx_pm_logspace_add(acc, lw[u]);
+                                    first = false;
+                                }
+                        }
+                        for (; i < KO; ++i) {
                             const double lw = L[2 * i];
                             if (which == 0 || L[2 * i + 1] != 0.0) {
                                 acc = first ? lw : bmx_pm_logspace_add(acc, lw);
                                 first = false;
                             }
                         }
+                    } else if (which == 3) {
+                        // the walk's running sums (:147-151) do not depend on where the walk stops: a fourth lane takes them
+                        // WHILE the three chains run (the walk used to start when they were through: twice the sequential
+                        // length) and leaves sum i in the place of log-weight i; they never decrease (a log-sum is at least its
+                        // larger term), so the walk's stop is then a binary search for the target
+                        double* L = const_cast<double*>(LS) + (int64_t)c * lcap * 2;
+                        const int KS = sh_K[c][2];
+                        double cum = 0.0;
+                        int i = 0;
+                        for (; i + 8 <= KS; i += 8) {
+                            double lw[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) lw[u] = L[2 * (i + u) + 1];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                cum = i + u == 0 ? lw[u] : bmx_pm_logspace_add(cum, lw[u]);
+                                lw[u] = cum;
+                            }
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) L[2 * (i + u) + 1] = lw[u];
+                        }
+                        for (; i < KS; ++i) {
+                            cum = i == 0 ? L[1] : bmx_pm_logspace_add(cum, L[2 * i + 1]);
+                            L[2 * i + 1] = cum;
+                        }
                     } else {
                         const double* L = LR + (int64_t)c * lcap;
                         const int KR = sh_K[c][1];
-                        for (int i = 0; i < KR; ++i) {
+                        int i = 0;
+                        for (; i + 8 <= KR; i += 8) {
+                            double lw[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) lw[u] = L[i + u];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                acc = first ? lw[u] : bmx_pm_logspace_add(acc, lw[u]);
+                                first = false;
+                            }
+                        }
+                        for (; i < KR; ++i) {
                             acc = first ? L[i] : bmx_pm_logspace_add(acc, L[i]);
                             first = false;
                         }
                     }
-                    sh_chain[c][which] = acc;
+                    if (which < 3) sh_chain[c][which] = acc;
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");  // (the walk's sums, written by one wave, read by another)
             __syncthreads();
             if (tid < AT_C && c0 + tid < n2 && sh_K[tid][0] >= 0) {
                 const int c = tid, KS = sh_K[c][2];
                 const double* L = LS + (int64_t)c * lcap * 2;
                 const double tgt = (sh_chain[c][1] - sh_chain[c][0]) + sh_chain[c][2];  // :111, :138
-                double cum = 0.0, rq = L[2 * (KS - 1)];  // :141
-                for (int i = 0; i < KS; ++i) {
-                    cum = i == 0 ? L[1] : bmx_pm_logspace_add(cum, L[2 * i + 1]);
-                    if (cum >= tgt) {
-                        rq = L[2 * i];
-                        break;
-                    }
+                // the first place whose running sum reaches the target (:147-151; the sums stand where the log-weights stood and
+                // never decrease), the last projection if none does (:141; a NaN target: none)
+                int lo_ = 0, hi_ = KS;
+                while (lo_ < hi_) {
+                    const int mid = (lo_ + hi_) >> 1;
+                    if (L[2 * mid + 1] >= tgt) hi_ = mid;
+                    else lo_ = mid + 1;
                 }
+                const double rq = L[2 * (lo_ < KS ? lo_ : KS - 1)];
                 out[c0 + c] = (rq - sc_proj[c]) / sc_l2[c];  // :160
+            }
+            if (any_lit) {
+                tk_chain += __builtin_amdgcn_s_memrealtime() - tkc0;
+                ++tk_chain_tiles;
             }
             if (tid == 0 && tally) {
                 atomicAdd(&tally[0], (unsigned long long)n_lit);
@@ -1898,6 +1967,12 @@ __global__ __launch_bounds__(T) void asv_tile_kernel(int g, const double* __rest
         atomicAdd(&g_asv_ticks[0], tk_stream);
         atomicAdd(&g_asv_ticks[1], tk_wait);
         atomicAdd(&g_asv_ticks[2], tk_cells);
+        if (tk_lit | tk_chain) {
+            atomicAdd(&g_asv_ticks[4], tk_lit);
+            atomicAdd(&g_asv_ticks[5], tk_chain);
+            atomicAdd(&g_asv_ticks[6], tk_lit_n);
+            atomicAdd(&g_asv_ticks[7], tk_chain_tiles);
+        }
     }
 }
 
@@ -2003,17 +2078,15 @@ void asv_tally_read(unsigned long long out[3], bool reset) {
     BMX_HIP(hipMemcpy(out, t, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     if (reset) {
         BMX_HIP(hipMemset(t, 0, 3 * sizeof(unsigned long long)));
-        const unsigned long long z[4] = {0, 0, 0, 0};
+        const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         BMX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_asv_ticks), z, sizeof(z)));
     }
 }
-void asv_ticks_read(unsigned long long out[3]) {
-    unsigned long long v[4] = {0, 0, 0, 0};
+void asv_ticks_read(unsigned long long out[8]) {
+    unsigned long long v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     BMX_HIP(hipDeviceSynchronize());
     BMX_HIP(hipMemcpyFromSymbol(v, HIP_SYMBOL(g_asv_ticks), sizeof(v)));
-    out[0] = v[0];
-    out[1] = v[1];
-    out[2] = v[2];
+    for (int i = 0; i < 8; ++i) out[i] = v[i];
 }
 
 static int device_cu_count() {

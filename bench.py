@@ -831,6 +831,12 @@ def main():
                 # and ticks are reset when the timed region starts)
                 "phase_ms_per_workgroup_per_step": {ph: _bl.dev_get("asv_ticks_" + ph) / 256 / 1e5 / max(1, args.steps)
                                                     for ph in ("stream", "wait", "cells")},
+                # the re-run cells' share of the per-cell phase, added up over their workgroups (NOT divided by 256: a re-run
+                # cell holds ONE workgroup, and the launch waits for it)
+                "rerun_ms_per_step": {"selection_reevaluation_sort": _bl.dev_get("asv_ticks_literal") / 1e5 / max(1, args.steps),
+                                      "chains_and_walk": _bl.dev_get("asv_ticks_chains") / 1e5 / max(1, args.steps),
+                                      "kept_addends": _bl.dev_get("asv_literal_addends") // max(1, args.steps),
+                                      "tiles_with_chains": _bl.dev_get("asv_chain_tiles") // max(1, args.steps)},
             }
         if h2h is not None:
             line["value_host_to_host"] = n_cells / h2h

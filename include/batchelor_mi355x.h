@@ -111,7 +111,10 @@ int32_t bmx_dev_set(const char* name, int32_t value);
 /* Counters for tests and bench.py, current device: "asv_tiled_cells" (cells the tiled form of adjust_shift_variance has
  * handled), "asv_literal_cells" (of those, re-run in the reference's order of operations: bit-equal to the exact form),
  * "asv_fallback_cells" (ill-conditioned cells with too many significant pairs for the re-run: histogram quantile, may pick a
- * neighbouring quantile), "asv_tally_reset" (zeroes them).  Waits for the device. */
+ * neighbouring quantile), "asv_tally_reset" (zeroes them and the ticks); 100 MHz device ticks of the tiled form added up over its
+ * workgroups: "asv_ticks_stream", "asv_ticks_wait", "asv_ticks_cells" (the stream, the testing hook's round barrier, the per-cell
+ * phase), "asv_ticks_literal" / "asv_ticks_chains" (the re-run cells' selection + re-evaluation + sort, their chains and walks),
+ * "asv_literal_addends" (addends the re-run cells kept), "asv_chain_tiles" (tiles with a re-run cell).  Waits for the device. */
 int32_t bmx_dev_get(const char* name, int64_t* value);
 /* "asv_modes" (after bmx_dev_set "asv_modes" = n): which way each of the first n cells of the LAST tiled adjust_shift_variance
  * call went -- 0 the histogram quantile (a well-conditioned cell), 1 re-run in the reference's order of operations, 2
