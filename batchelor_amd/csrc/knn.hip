@@ -533,7 +533,10 @@ __global__ __launch_bounds__(256) void knn_exact_dist(const double* __restrict__
                                                       int nr, const double* __restrict__ Q,
                                                       const int32_t* __restrict__ q_rows, int d,
                                                       const int32_t* __restrict__ flagged, int f0,
-                                                      double* __restrict__ drow) {
+                                                      double* __restrict__ drow, int dev_cap = 0) {
+    // (dev_cap > 0: the number of listed queries is on the device -- flagged[0], at most dev_cap of them are taken --, the grid
+    // is dev_cap wide and the rows beyond the count end here)
+    if (dev_cap > 0 && (int)blockIdx.y >= min(flagged[0], dev_cap)) return;
     const int f = f0 + blockIdx.y;
     const int q = flagged ? flagged[1 + f] : f;
     const double* qv = Q + (int64_t)(q_rows ? q_rows[q] : q) * d;
@@ -543,9 +546,11 @@ __global__ __launch_bounds__(256) void knn_exact_dist(const double* __restrict__
 
 __global__ __launch_bounds__(256) void knn_exact_select(const double* __restrict__ drow, int nr, int k,
                                                         const int32_t* __restrict__ flagged, int f0,
-                                                        int32_t* __restrict__ idx_out, double* __restrict__ dist_out) {
+                                                        int32_t* __restrict__ idx_out, double* __restrict__ dist_out,
+                                                        int dev_cap = 0) {
     __shared__ double rd[256];
     __shared__ int ri[256];
+    if (dev_cap > 0 && (int)blockIdx.x >= min(flagged[0], dev_cap)) return;  // (see knn_exact_dist)
     const int tid = threadIdx.x;
     const int f = f0 + blockIdx.x;
     const int q = flagged ? flagged[1 + f] : f;
@@ -602,8 +607,10 @@ __device__ __forceinline__ int xsb_block_sum(int v, int* sh_part) {
 
 __global__ __launch_bounds__(XSB_T) void knn_exact_select_big(const double* __restrict__ drow, int nr, int k, int np2,
                                                               const int32_t* __restrict__ flagged, int f0,
-                                                              int32_t* __restrict__ idx_out, double* __restrict__ dist_out) {
+                                                              int32_t* __restrict__ idx_out, double* __restrict__ dist_out,
+                                                              int dev_cap = 0) {
     extern __shared__ double xsb_d[];       // [np2] distances, then [np2] positions
+    if (dev_cap > 0 && (int)blockIdx.x >= min(flagged[0], dev_cap)) return;  // (see knn_exact_dist)
     int* xsb_i = reinterpret_cast<int*>(xsb_d + np2);
     __shared__ int sh_part[XSB_T / 64];
     __shared__ int sh_fill;
@@ -794,7 +801,13 @@ __global__ __launch_bounds__(256) void knn_exact_pick(const int32_t* __restrict_
             atomicAdd(&opt[1], nflag);
             if (nflag > dev_cap) opt[0] = 1;
         }
-        if (nflag > dev_cap) return;
+        if (nflag > dev_cap) {
+            // (the run is given up -- but the searches queued behind this one still run, and their sweeps count into these
+            // slots: left as they are, a later row would hold a reference twice, its merge (lk_merge_wave) two candidates of one
+            // rank and an entry nobody wrote)
+            if (f < dev_cap && lane == 0) xcnt[f] = 0;
+            return;
+        }
     }
     if (f >= nflag) return;
     const int q = flagged[1 + f];
@@ -1436,6 +1449,11 @@ __global__ __launch_bounds__(256) void lk_merge(const double* __restrict__ X, co
     // partitions searched within the seed distance (large_k_search) are complete up to it only: the k-th must lie inside
     if (tid == 0 && seed_d2 && !(kd[k - 1] < (double)seed_d2[q])) sh_fail = 1;
     __syncthreads();
+    // (a row that fails is rewritten by an exact path -- unless an optimistic run has more of them than it takes on the device,
+    // and then the kernels queued behind this search still read the row before the engine starts over: every entry a valid
+    // position.  Seeded partitions can leave fewer than k candidates, i.e. empty places among the first k.)
+    if (sh_fail)
+        for (int r = tid; r < k; r += 256) idx_out[(int64_t)q * k + r] = 0;
     // (the intersection's probe skips a row whose k-th distance it knows to be too small: exact here when the merge stands)
     if (tid == 0 && kth_out) kth_out[q] = sh_fail ? __builtin_inf() : sqrt(kd[k - 1]);
     if (tid == 0 && sh_fail) {
@@ -1491,6 +1509,10 @@ __global__ __launch_bounds__(256) void lk_merge_wave(const double* __restrict__ 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // (every entry of the row a valid position whatever the lists hold: lists spoilt by a search that an optimistic run has
+    // already given up on must not leave an entry unwritten for the kernels queued behind it)
+    for (int r = lane; r < k; r += 64) idx_out[(int64_t)q * k + r] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     bool fail = false;
     double kthv = -1.0;  // the k-th merged candidate's squared distance, on the lane that ranks it
     for (int e = lane; e < E; e += 64) {
@@ -1521,6 +1543,8 @@ __global__ __launch_bounds__(256) void lk_merge_wave(const double* __restrict__ 
     for (int o = 32; o > 0; o >>= 1) kthv = fmax(kthv, __shfl_xor(kthv, o));
     // partitions searched within the seed distance (large_k_search) are complete up to it only: the k-th must lie inside
     if (seed_d2 && !(kthv >= 0.0 && kthv < (double)seed_d2[q])) any_fail = true;
+    if (any_fail)  // (see lk_merge: every entry of a failed row a valid position; later in the wave's program order than the ranks' stores)
+        for (int r = lane; r < k; r += 64) idx_out[(int64_t)q * k + r] = 0;
     if (kth_out && lane == 0) kth_out[q] = any_fail || kthv < 0.0 ? __builtin_inf() : sqrt(kthv);
     if (any_fail && lane == 0) {
         if (opt) atomicOr(opt, 1);
@@ -1616,6 +1640,7 @@ __global__ __launch_bounds__(LKB_T) void lk_merge_big(const double* __restrict__
     // (Fewer than k candidates in all -- seeded lists may be short -- leaves vk beyond +inf: nothing to select, the query goes
     // to the exact scan.)  vk is the same on every thread.
     if (vk >= 0x7FF0000000000000ull || (seed_d2 && !(__longlong_as_double((long long)vk) < (double)seed_d2[q]))) {
+        for (int r = tid; r < k; r += LKB_T) idx_out[(int64_t)q * k + r] = 0;  // (see lk_merge: every entry a valid position)
         if (tid == 0) {
             if (kth_out) kth_out[q] = __builtin_inf();
             if (opt) atomicOr(opt, 1);
@@ -1705,6 +1730,16 @@ __global__ __launch_bounds__(LKB_T) void lk_merge_big(const double* __restrict__
     }
 }
 
+// optimistic run: the queries a merge could not certify are on the device (flagged[0] of them).  Up to LK_OPT_CAP take the full
+// FP64 scan there and then (launched whatever the count: with none flagged its workgroups end at once); more raise the run's
+// flag (opt[0]) and the engine repeats the run with host-checked searches.  opt[1] counts the queries that took an exact path.
+constexpr int LK_OPT_CAP = 32;
+__global__ void lk_opt_overflow(const int32_t* __restrict__ flagged, int32_t* __restrict__ opt) {
+    const int c = flagged[0];
+    if (c > LK_OPT_CAP) atomicOr(&opt[0], 1);
+    if (c > 0) atomicAdd(&opt[1], c < LK_OPT_CAP ? c : LK_OPT_CAP);
+}
+
 // false: the shape does not suit the partitioned search (too few reference cells a partition, too many candidates)
 bool large_k_search(hipStream_t stream, KnnWorkspace& ws, const double* X, const int32_t* ref_rows, int nr, const double* Qs,
                     const int32_t* qrs, int nq, int d, int k, int32_t* io, double* dout, const double* centre,
@@ -1746,24 +1781,46 @@ bool large_k_search(hipStream_t stream, KnnWorkspace& ws, const double* X, const
     }
     int32_t* flagged = ws.flagged_t[0].reserve((size_t)nq + 1);
     int32_t* opt = ws.optimistic ? ws.opt_state_ptr(stream) : nullptr;
-    if (!opt) BMX_HIP(hipMemsetAsync(flagged, 0, sizeof(int32_t), stream));
+    BMX_HIP(hipMemsetAsync(flagged, 0, sizeof(int32_t), stream));
+    int32_t* const no_opt = nullptr;  // (the merges list what they cannot certify in either kind of run)
     if (P * kp > LK_MAXE) {
         size_t np2 = 1;
         while (np2 < (size_t)k) np2 <<= 1;
         const size_t lds = np2 * 12;
         ensure_dynamic_lds(reinterpret_cast<const void*>(&lk_merge_big), lds);
         hipLaunchKernelGGL(lk_merge_big, dim3(nq), dim3(LKB_T), lds, stream, X, (const int32_t*)rows, nr, P, kp, Qs, qrs, nq, d, k,
-                           (const int32_t*)sub, io, dout, flagged, opt, kth_out, (const float*)seed);
+                           (const int32_t*)sub, io, dout, flagged, no_opt, kth_out, (const float*)seed);
     } else if (P * kp <= 512)
         hipLaunchKernelGGL(lk_merge_wave, dim3(cdiv(nq, 4)), dim3(256), 0, stream, X, (const int32_t*)rows, nr, P, kp, Qs, qrs, nq,
-                           d, k, (const int32_t*)sub, io, dout, flagged, opt, kth_out, (const float*)seed);
+                           d, k, (const int32_t*)sub, io, dout, flagged, no_opt, kth_out, (const float*)seed);
     else
         hipLaunchKernelGGL(lk_merge, dim3(nq), dim3(256), 0, stream, X, (const int32_t*)rows, nr, P, kp, Qs, qrs, nq, d, k,
-                           (const int32_t*)sub, io, dout, flagged, opt, kth_out, (const float*)seed);
+                           (const int32_t*)sub, io, dout, flagged, no_opt, kth_out, (const float*)seed);
     BMX_LAUNCH_CHECK();
     if (!opt) {
         const int count = read_count(stream, ws, flagged);
         if (count > 0) exact_search(stream, ws, X, ref_rows, nr, Qs, qrs, d, k, io, dout, flagged, nullptr, count);
+    } else {
+        // (one query whose first partition holds 36 of its k used to send the whole run back to its start: 7 of 300 000 queries a
+        // step did at k = 1 000, every step ran twice)
+        hipLaunchKernelGGL(lk_opt_overflow, dim3(1), dim3(1), 0, stream, (const int32_t*)flagged, opt);
+        BMX_LAUNCH_CHECK();
+        double* drow = ws.drow.reserve((size_t)LK_OPT_CAP * nr);
+        hipLaunchKernelGGL(knn_exact_dist, dim3(cdiv(nr, 256), LK_OPT_CAP), dim3(256), 0, stream, X, ref_rows, nr, Qs, qrs, d,
+                           (const int32_t*)flagged, 0, drow, LK_OPT_CAP);
+        BMX_LAUNCH_CHECK();
+        if (k > 64 && k <= XSB_MAXK) {
+            int np2 = 128;
+            while (np2 < k) np2 <<= 1;
+            const size_t lds = (size_t)np2 * (sizeof(double) + sizeof(int));
+            ensure_dynamic_lds(reinterpret_cast<const void*>(&knn_exact_select_big), lds);
+            hipLaunchKernelGGL(knn_exact_select_big, dim3(LK_OPT_CAP), dim3(XSB_T), lds, stream, (const double*)drow, nr, k, np2,
+                               (const int32_t*)flagged, 0, io, dout, LK_OPT_CAP);
+        } else {
+            hipLaunchKernelGGL(knn_exact_select, dim3(LK_OPT_CAP), dim3(256), 0, stream, (const double*)drow, nr, k,
+                               (const int32_t*)flagged, 0, io, dout, LK_OPT_CAP);
+        }
+        BMX_LAUNCH_CHECK();
     }
     return true;
 }

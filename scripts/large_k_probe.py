@@ -21,5 +21,7 @@ for k in ks:
     eng.run(k=k)
     dt = time.perf_counter() - t
     st = eng.merge_stats()[0]
-    print(f"n={n} k={k}: {1e3 * dt:.1f} ms per step, {st['P']} pairs, kernel {eng.profile_detail()['kernel']}", flush=True)
+    pd = eng.profile_detail()
+    print(f"n={n} k={k}: {1e3 * dt:.1f} ms per step, {st['P']} pairs, kernel {pd['kernel']}, "
+          f"{pd['exact_fallbacks']} queries to the FP64 paths, optimistic runs given up so far: {pd['optimistic_retries']}", flush=True)
 eng.close()

@@ -213,3 +213,29 @@ def test_large_k_with_restriction_and_three_batches(oracle, bx):
     keep = [np.arange(1, 4001), None, np.arange(300, 3500)]
     assert_same_result(bx.reducedMNN(*B, k=50, restrict=keep), oracle.reduced_mnn(*B, k=50, restrict=keep))
     assert_same_result(bx.reducedMNN(*B, k=20, prop_k=0.02, restrict=keep), oracle.reduced_mnn(*B, k=20, prop_k=0.02, restrict=keep))
+
+
+@pytest.mark.parametrize("outliers,retries", [(True, 0), (False, 1)])
+def test_large_k_queries_the_merge_cannot_certify(oracle, bx, outliers, retries):
+    """k = 100: the searches are partitioned (knn.hip, large_k_search: reference rows g with the same g % 7).  Six cells of the
+    first batch each have 40 exact copies in the second, all in its first partition: the merge of the partitions' lists cannot
+    certify a query that has them among its 100 nearest.  With the six far from everything else only they themselves do: in the
+    engine's optimistic run (no host read-back inside a search) those queries take the FP64 scan on the device -- one such query
+    used to send the whole run back to its start.  With the six in the crowd hundreds of queries do, more than the device-side
+    path takes: the run starts over with host-checked searches -- and what is queued behind the search that gave up must
+    survive its spoilt lists (every index in range).  Either way the result is the oracle's, pairs bit for bit."""
+    B1, B2 = synth_batches(31, [3000, 30000], 20)
+    if outliers:
+        B1[:6] = 12.0 * np.eye(20)[:6]
+    for j in range(6):
+        B2[(np.arange(40) + 40 * j) * 7] = B1[j]
+    eng = bx.MnnEngine()
+    try:
+        eng.upload([B1, B2])
+        eng.run(k=100)
+        pd = eng.profile_detail()
+        assert pd["optimistic_retries"] == retries
+        assert pd["exact_fallbacks"] >= 6
+    finally:
+        eng.close()
+    assert_same_result(bx.reducedMNN(B1, B2, k=100), oracle.reduced_mnn(B1, B2, k=100))
