@@ -343,6 +343,8 @@ struct KnnWorkspace {
     // k-th candidate distances, and the scratch of the sub-search the next tier runs on them
     DevBuf<int32_t> flagged_t[2], sub_rows[2], sub_idx[2];
     DevBuf<int32_t> lk_rows, lk_idx;  // k > 36: the partitions' row lists, their neighbour lists [P][nq][36]
+    DevBuf<double> lk_d2;             // ... their exact SQUARED distances [P][nq][36] (the merge then gathers no rows)
+    bool dist_squared = false;        // set around the partitions' searches: every writer of a search's distances leaves them squared
     DevBuf<double> lk_kth;            // ... the first partition's kp-th distances
     DevBuf<float> lk_seed;            // ... and the seeds of the other partitions' searches made of them
     DevBuf<double> flag_bound_t[2], sub_dist[2];

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void knn_refine(const double* __restrict__ X, 
                                                   double* __restrict__ dist_out, int32_t* __restrict__ flagged,
                                                   double* __restrict__ flag_bound,
                                                   unsigned long long* __restrict__ zero_slots, int q0,
-                                                  double* __restrict__ kth_out) {
+                                                  double* __restrict__ kth_out, int sq = 0) {
     __shared__ __attribute__((aligned(16))) double sd[4][REFINE_MAXM];
     __shared__ int si[4][REFINE_MAXM];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void knn_refine(const double* __restrict__ X, 
         for (int f = 0; f < M; ++f) rank += key_less(sd[w][f], si[w][f], dm, im) ? 1 : 0;
         if (rank < k) {
             idx_out[(int64_t)q * k + rank] = im;
-            if (dist_out) dist_out[(int64_t)q * k + rank] = sqrt(dm);
+            if (dist_out) dist_out[(int64_t)q * k + rank] = sq ? dm : sqrt(dm);  // (sq: squared, for the partitioned search's merge)
         }
         if (rank == k - 1) kth = dm;
     }
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void knn_refine_half(const double* __restrict_
                                                        double* __restrict__ dist_out, int32_t* __restrict__ flagged,
                                                        double* __restrict__ flag_bound,
                                                        unsigned long long* __restrict__ zero_slots,
-                                                       double* __restrict__ kth_out) {
+                                                       double* __restrict__ kth_out, int sq = 0) {
     constexpr int KS = 32;
     __shared__ __attribute__((aligned(16))) double sd[8][KS];
     __shared__ int si[8][KS];
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(256) void knn_refine_half(const double* __restrict_
         }
         if (hl < M && rank < k && live) {
             idx_out[(int64_t)q * k + rank] = im;
-            if (dist_out) dist_out[(int64_t)q * k + rank] = sqrt(dm);
+            if (dist_out) dist_out[(int64_t)q * k + rank] = sq ? dm : sqrt(dm);  // (sq: squared, for the partitioned search's merge)
         }
         if (hl < M && rank == k - 1) kth = dm;
     }
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(256) void knn_exact_dist(const double* __restrict__
 __global__ __launch_bounds__(256) void knn_exact_select(const double* __restrict__ drow, int nr, int k,
                                                         const int32_t* __restrict__ flagged, int f0,
                                                         int32_t* __restrict__ idx_out, double* __restrict__ dist_out,
-                                                        int dev_cap = 0) {
+                                                        int dev_cap = 0, int sq = 0) {
     __shared__ double rd[256];
     __shared__ int ri[256];
     if (dev_cap > 0 && (int)blockIdx.x >= min(flagged[0], dev_cap)) return;  // (see knn_exact_dist)
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256) void knn_exact_select(const double* __restrict
         last_i = ri[0];
         if (tid == 0) {
             idx_out[(int64_t)q * k + jdx] = last_i;
-            if (dist_out) dist_out[(int64_t)q * k + jdx] = sqrt(last_d);
+            if (dist_out) dist_out[(int64_t)q * k + jdx] = sq ? last_d : sqrt(last_d);
         }
         __syncthreads();
     }
@@ -608,7 +608,7 @@ __device__ __forceinline__ int xsb_block_sum(int v, int* sh_part) {
 __global__ __launch_bounds__(XSB_T) void knn_exact_select_big(const double* __restrict__ drow, int nr, int k, int np2,
                                                               const int32_t* __restrict__ flagged, int f0,
                                                               int32_t* __restrict__ idx_out, double* __restrict__ dist_out,
-                                                              int dev_cap = 0) {
+                                                              int dev_cap = 0, int sq = 0) {
     extern __shared__ double xsb_d[];       // [np2] distances, then [np2] positions
     if (dev_cap > 0 && (int)blockIdx.x >= min(flagged[0], dev_cap)) return;  // (see knn_exact_dist)
     int* xsb_i = reinterpret_cast<int*>(xsb_d + np2);
@@ -675,7 +675,7 @@ __global__ __launch_bounds__(XSB_T) void knn_exact_select_big(const double* __re
         }
     for (int j = tid; j < k; j += XSB_T) {
         idx_out[(int64_t)q * k + j] = xsb_i[j];
-        if (dist_out) dist_out[(int64_t)q * k + j] = sqrt(xsb_d[j]);
+        if (dist_out) dist_out[(int64_t)q * k + j] = sq ? xsb_d[j] : sqrt(xsb_d[j]);
     }
 }
 
@@ -792,7 +792,7 @@ __global__ __launch_bounds__(256) void knn_exact_pick(const int32_t* __restrict_
                                                       int seeded, int32_t* __restrict__ xcnt, const double* __restrict__ xd,
                                                       const int32_t* __restrict__ xi, int32_t* __restrict__ idx_out,
                                                       double* __restrict__ dist_out, int32_t* __restrict__ slow,
-                                                      int32_t* __restrict__ opt) {
+                                                      int32_t* __restrict__ opt, int sq = 0) {
     const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (dev_cap > 0) {
@@ -836,7 +836,7 @@ __global__ __launch_bounds__(256) void knn_exact_pick(const int32_t* __restrict_
         for (int t = 0; t < n; ++t) rank += key_less(dd[t], ii[t], dm, im) ? 1 : 0;
         if (rank < k) {
             idx_out[(int64_t)q * k + rank] = im;
-            if (dist_out) dist_out[(int64_t)q * k + rank] = sqrt(dm);
+            if (dist_out) dist_out[(int64_t)q * k + rank] = sq ? dm : sqrt(dm);
         }
     }
     if (short_ok)
@@ -1114,16 +1114,17 @@ void candidate_pass(hipStream_t stream, KnnWorkspace& ws, const Tier& T, const d
         const int need = (d & 1) ? 0 : cdiv(d, 8);
         const int unit_q = T.id == 1 ? 256 : 32 * bf16_ncons(NS, KS);
         const int nq_half = KS == 32 && !dev_knobs().refine_wave ? (C > 1 ? std::min(nq, n_full * unit_q) : nq) : 0;
+        const int sq = ws.dist_squared ? 1 : 0;
 #define BMX_REFINE(NC)                                                                                                              \
     do {                                                                                                                            \
         if (nq_half > 0)                                                                                                            \
             hipLaunchKernelGGL(knn_refine_half<NC>, dim3(cdiv(nq_half, 8)), dim3(256), 0, stream, X, ref_rows, Qs, qrs, nq_half, d, k, \
                                nchunks, eps_k, eps_qr, eps_split, eps_den, T.id == 1 ? 1 : 0, cand, cand_v, tau, qn2, maxbits,       \
-                               seed_d2, io, dout, flagged, flag_bound, zero_slots, kth_out);                                        \
+                               seed_d2, io, dout, flagged, flag_bound, zero_slots, kth_out, sq);                                    \
         if (nq > nq_half)                                                                                                           \
             hipLaunchKernelGGL(knn_refine<NC>, dim3(cdiv(nq - nq_half, 4)), dim3(256), 0, stream, X, ref_rows, Qs, qrs, nq, d, k, KS,  \
                                nchunks, eps_k, eps_qr, eps_split, eps_den, T.id == 1 ? 1 : 0, cand, cand_v, tau, qn2, maxbits,       \
-                               seed_d2, io, dout, flagged, flag_bound, nq_half > 0 ? nullptr : zero_slots, nq_half, kth_out);       \
+                               seed_d2, io, dout, flagged, flag_bound, nq_half > 0 ? nullptr : zero_slots, nq_half, kth_out, sq);   \
     } while (0)
         if (need == 0 || need > 16) BMX_REFINE(0);
         else if (need <= 2) BMX_REFINE(2);
@@ -1253,7 +1254,7 @@ void exact_search(hipStream_t stream, KnnWorkspace& ws, const double* X, const i
                            d, list, bounds, count, 0, xcnt, xd, xi);
         BMX_LAUNCH_CHECK();
         hipLaunchKernelGGL(knn_exact_pick, dim3(cdiv(count, 4)), dim3(256), 0, stream, list, count, 0, k, seeded ? 1 : 0, xcnt,
-                           xd, xi, io, dout, slow, (int32_t*)nullptr);
+                           xd, xi, io, dout, slow, (int32_t*)nullptr, ws.dist_squared ? 1 : 0);
         BMX_LAUNCH_CHECK();
         count = read_count(stream, ws, slow);
         scan_list = slow;
@@ -1275,9 +1276,10 @@ void exact_search(hipStream_t stream, KnnWorkspace& ws, const double* X, const i
                 const size_t lds = (size_t)np2 * (sizeof(double) + sizeof(int));
                 ensure_dynamic_lds(reinterpret_cast<const void*>(&knn_exact_select_big), lds);
                 hipLaunchKernelGGL(knn_exact_select_big, dim3(nb), dim3(XSB_T), lds, stream, drow, nr, k, np2, scan_list, f0, io,
-                                   dout);
+                                   dout, 0, ws.dist_squared ? 1 : 0);
             } else {
-                hipLaunchKernelGGL(knn_exact_select, dim3(nb), dim3(256), 0, stream, drow, nr, k, scan_list, f0, io, dout);
+                hipLaunchKernelGGL(knn_exact_select, dim3(nb), dim3(256), 0, stream, drow, nr, k, scan_list, f0, io, dout, 0,
+                                   ws.dist_squared ? 1 : 0);
             }
             BMX_LAUNCH_CHECK();
         }
@@ -1319,7 +1321,8 @@ void search_tiers(hipStream_t stream, KnnWorkspace& ws, const Tier* tiers, int n
                            d, flagged, bound, 0, KnnWorkspace::OPT_CAP, xcnt, xd, xi);
         BMX_LAUNCH_CHECK();
         hipLaunchKernelGGL(knn_exact_pick, dim3(KnnWorkspace::OPT_CAP / 4), dim3(256), 0, stream, flagged, 0,
-                           KnnWorkspace::OPT_CAP, k, seed_d2 ? 1 : 0, xcnt, xd, xi, io, dout, (int32_t*)nullptr, opt);
+                           KnnWorkspace::OPT_CAP, k, seed_d2 ? 1 : 0, xcnt, xd, xi, io, dout, (int32_t*)nullptr, opt,
+                           ws.dist_squared ? 1 : 0);
         BMX_LAUNCH_CHECK();
         return;
     }
@@ -1386,7 +1389,7 @@ __global__ __launch_bounds__(256) void lk_merge(const double* __restrict__ X, co
                                                 int d, int k, const int32_t* __restrict__ sub_idx, int32_t* __restrict__ idx_out,
                                                 double* __restrict__ dist_out, int32_t* __restrict__ flagged,
                                                 int32_t* __restrict__ opt, double* __restrict__ kth_out,
-                                                const float* __restrict__ seed_d2) {
+                                                const float* __restrict__ seed_d2, const double* __restrict__ sub_d2) {
     __shared__ double kd[LK_MAXE];
     __shared__ int32_t ki[LK_MAXE];
     __shared__ int sh_fail;
@@ -1403,13 +1406,17 @@ __global__ __launch_bounds__(256) void lk_merge(const double* __restrict__ X, co
             const int p = e / kp, j = e - p * kp;
             const int l = sub_idx[((int64_t)p * nq + q) * kp + j];  // position inside partition p
             if (l >= 0) {
-                const double* x = X + (int64_t)rows[(int64_t)p * base + (p < rem ? p : rem) + l] * d;
-                double s = 0.0;
-                for (int c = 0; c < d; ++c) {
-                    const double t = qv[c] - x[c];
-                    s += t * t;
+                if (sub_d2) {  // (the partition's search left the very sum below, squared: nothing to gather)
+                    d2 = sub_d2[((int64_t)p * nq + q) * kp + j];
+                } else {
+                    const double* x = X + (int64_t)rows[(int64_t)p * base + (p < rem ? p : rem) + l] * d;
+                    double s = 0.0;
+                    for (int c = 0; c < d; ++c) {
+                        const double t = qv[c] - x[c];
+                        s += t * t;
+                    }
+                    d2 = s;
                 }
-                d2 = s;
                 g = l * P + p;  // its position in the caller's reference list
             }
         }
@@ -1471,7 +1478,8 @@ __global__ __launch_bounds__(256) void lk_merge_wave(const double* __restrict__ 
                                                      int nq, int d, int k, const int32_t* __restrict__ sub_idx,
                                                      int32_t* __restrict__ idx_out, double* __restrict__ dist_out,
                                                      int32_t* __restrict__ flagged, int32_t* __restrict__ opt,
-                                                     double* __restrict__ kth_out, const float* __restrict__ seed_d2) {
+                                                     double* __restrict__ kth_out, const float* __restrict__ seed_d2,
+                                                     const double* __restrict__ sub_d2) {
     __shared__ double kd_[4][512];
     __shared__ int32_t ki_[4][512];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1485,6 +1493,11 @@ __global__ __launch_bounds__(256) void lk_merge_wave(const double* __restrict__ 
     for (int e = lane; e < E; e += 64) {
         const int p = e / kp, j = e - p * kp;
         const int l = sub_idx[((int64_t)p * nq + q) * kp + j];
+        if (sub_d2) {  // (the partition's search left the very sum below, squared: nothing to gather)
+            kd[e] = l >= 0 ? sub_d2[((int64_t)p * nq + q) * kp + j] : __builtin_inf();
+            ki[e] = l >= 0 ? l * P + p : 0x7fffffff;
+            continue;
+        }
         const double* x = X + (int64_t)rows[(int64_t)p * base + (p < rem ? p : rem) + (l >= 0 ? l : 0)] * d;
         // (eight coordinates asked for at a time -- a random row: the round trips are what this costs --, summed in order)
         double s = 0.0;
@@ -1569,7 +1582,8 @@ __global__ __launch_bounds__(LKB_T) void lk_merge_big(const double* __restrict__
                                                       int nq, int d, int k, const int32_t* __restrict__ sub_idx,
                                                       int32_t* __restrict__ idx_out, double* __restrict__ dist_out,
                                                       int32_t* __restrict__ flagged, int32_t* __restrict__ opt,
-                                                      double* __restrict__ kth_out, const float* __restrict__ seed_d2) {
+                                                      double* __restrict__ kth_out, const float* __restrict__ seed_d2,
+                                                      const double* __restrict__ sub_d2) {
     extern __shared__ __attribute__((aligned(16))) char lkb_smem[];
     __shared__ int sh_cnt[LKB_T / 64];
     __shared__ int sh_fail, sh_base;
@@ -1591,7 +1605,10 @@ __global__ __launch_bounds__(LKB_T) void lk_merge_big(const double* __restrict__
         if (e < E) {
             const int p = e / kp, j = e - p * kp;
             const int l = sub_idx[((int64_t)p * nq + q) * kp + j];
-            if (l >= 0) {
+            if (l >= 0 && sub_d2) {  // (the partition's search left the very sum below, squared: nothing to gather)
+                bits = (unsigned long long)__double_as_longlong(sub_d2[((int64_t)p * nq + q) * kp + j]);
+                g = l * P + p;
+            } else if (l >= 0) {
                 const double* x = X + (int64_t)rows[(int64_t)p * base + (p < rem ? p : rem) + l] * d;
                 double s_ = 0.0;
                 int c = 0;
@@ -1766,6 +1783,15 @@ bool large_k_search(hipStream_t stream, KnnWorkspace& ws, const double* X, const
     // there instead of at +inf -- a partition of ~1 400 cells is otherwise one long warm-up, every early value a survivor for the
     // service waves (1.34 ms a launch at k = 1 000 against 13 us of matrix work).  A seeded list is complete up to the seed only;
     // the merges' certificate asks the k-th merged distance to lie inside it.
+    // The partitions' searches leave their exact SQUARED distances (the reference's sum, left to right -- what the merges used to
+    // gather every candidate's row for: 2 592 rows of 400 bytes a query at k = 1 000, 49 ms of a 100 ms search).
+    const size_t n_sub = (size_t)P * nq * kp;
+    double* sub_d2 = n_sub * sizeof(double) <= ((size_t)16 << 30) ? ws.lk_d2.reserve(n_sub) : nullptr;
+    struct SquaredScope {
+        KnnWorkspace& w;
+        ~SquaredScope() { w.dist_squared = false; }
+    } squared_scope{ws};
+    ws.dist_squared = sub_d2 != nullptr;
     const bool seeded = dev_knobs().lk_seed != 0 && P >= 3;
     double* kth0 = seeded ? ws.lk_kth.reserve((size_t)nq) : nullptr;
     float* seed = seeded ? ws.lk_seed.reserve((size_t)nq) : nullptr;
@@ -1773,12 +1799,14 @@ bool large_k_search(hipStream_t stream, KnnWorkspace& ws, const double* X, const
         const int n_p = base + (p < rem ? 1 : 0);
         const int nt = candidate_tiers(d, kp, n_p, tiers);
         search_tiers(stream, ws, tiers, nt, 0, X, rows + (int64_t)p * base + std::min(p, rem), n_p, Qs, qrs, nq, d, kp,
-                     sub + (int64_t)p * nq * kp, nullptr, p > 0 ? seed : nullptr, centre, p == 0 ? kth0 : nullptr);
+                     sub + (int64_t)p * nq * kp, sub_d2 ? sub_d2 + (int64_t)p * nq * kp : nullptr, p > 0 ? seed : nullptr, centre,
+                     p == 0 ? kth0 : nullptr);
         if (p == 0 && seeded) {
             hipLaunchKernelGGL(lk_seed_kernel, dim3(cdiv(nq, 256)), dim3(256), 0, stream, (const double*)kth0, nq, seed);
             BMX_LAUNCH_CHECK();
         }
     }
+    ws.dist_squared = false;  // (what follows writes the caller's distances)
     int32_t* flagged = ws.flagged_t[0].reserve((size_t)nq + 1);
     int32_t* opt = ws.optimistic ? ws.opt_state_ptr(stream) : nullptr;
     BMX_HIP(hipMemsetAsync(flagged, 0, sizeof(int32_t), stream));
@@ -1789,13 +1817,13 @@ bool large_k_search(hipStream_t stream, KnnWorkspace& ws, const double* X, const
         const size_t lds = np2 * 12;
         ensure_dynamic_lds(reinterpret_cast<const void*>(&lk_merge_big), lds);
         hipLaunchKernelGGL(lk_merge_big, dim3(nq), dim3(LKB_T), lds, stream, X, (const int32_t*)rows, nr, P, kp, Qs, qrs, nq, d, k,
-                           (const int32_t*)sub, io, dout, flagged, no_opt, kth_out, (const float*)seed);
+                           (const int32_t*)sub, io, dout, flagged, no_opt, kth_out, (const float*)seed, (const double*)sub_d2);
     } else if (P * kp <= 512)
         hipLaunchKernelGGL(lk_merge_wave, dim3(cdiv(nq, 4)), dim3(256), 0, stream, X, (const int32_t*)rows, nr, P, kp, Qs, qrs, nq,
-                           d, k, (const int32_t*)sub, io, dout, flagged, no_opt, kth_out, (const float*)seed);
+                           d, k, (const int32_t*)sub, io, dout, flagged, no_opt, kth_out, (const float*)seed, (const double*)sub_d2);
     else
         hipLaunchKernelGGL(lk_merge, dim3(nq), dim3(256), 0, stream, X, (const int32_t*)rows, nr, P, kp, Qs, qrs, nq, d, k,
-                           (const int32_t*)sub, io, dout, flagged, no_opt, kth_out, (const float*)seed);
+                           (const int32_t*)sub, io, dout, flagged, no_opt, kth_out, (const float*)seed, (const double*)sub_d2);
     BMX_LAUNCH_CHECK();
     if (!opt) {
         const int count = read_count(stream, ws, flagged);
