@@ -1585,7 +1585,7 @@ __global__ __launch_bounds__(LKB_T) void lk_merge_big(const double* __restrict__
                                                       double* __restrict__ kth_out, const float* __restrict__ seed_d2,
                                                       const double* __restrict__ sub_d2) {
     extern __shared__ __attribute__((aligned(16))) char lkb_smem[];
-    __shared__ int sh_cnt[LKB_T / 64];
+    __shared__ int sh_cnt[LKB_T / 64], sh_cb[2][LKB_T / 64];
     __shared__ int sh_fail, sh_base;
     const int E = P * kp, q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     int np2 = 1;
@@ -1634,16 +1634,18 @@ __global__ __launch_bounds__(LKB_T) void lk_merge_big(const double* __restrict__
         gmine[u] = g;
     }
     // block-wide count of this thread's candidates that satisfy pred
+    // (a wave's count: one ballot per candidate place, counted on the scalar side; the waves' counts meet in one of two LDS rows
+    // in turn -- one barrier a round: a row is written again two rounds later, behind the barrier of the round in between)
+    int cb_par = 0;
     auto count_block = [&](auto pred) -> int {
         int c = 0;
 #pragma unroll
-        for (int u = 0; u < LKB_PER; ++u) c += pred(mine[u], gmine[u]) ? 1 : 0;
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-        __syncthreads();
-        if (lane == 0) sh_cnt[w] = c;
+        for (int u = 0; u < LKB_PER; ++u) c += __popcll(__builtin_amdgcn_ballot_w64(pred(mine[u], gmine[u])));
+        if (lane == 0) sh_cb[cb_par][w] = c;
         __syncthreads();
         int t = 0;
-        for (int ww = 0; ww < LKB_T / 64; ++ww) t += sh_cnt[ww];
+        for (int ww = 0; ww < LKB_T / 64; ++ww) t += sh_cb[cb_par][ww];
+        cb_par ^= 1;
         return t;
     };
     // ---- the k-th smallest distance: the smallest bit pattern with at least k candidates at or below it
