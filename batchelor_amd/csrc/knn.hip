@@ -525,36 +525,163 @@ __global__ __launch_bounds__(256) void knn_refine_half(const double* __restrict_
 
 // ---------------------------------------------------------------------------------------------------
 // 4. exact FP64 scan for flagged queries (or every query when the MFMA path does not apply), in batches:
-//    knn_exact_dist   -- grid (reference blocks, queries of the batch): all exact squared distances, spread over the
-//                        whole chip even when only a handful of queries are flagged;
+//    knn_exact_dist   -- grid (tiles of 64 references, tiles of 64 queries of the batch): all exact squared distances, spread
+//                        over the whole chip even when only a handful of queries are flagged;
 //    knn_exact_select -- one workgroup per query: k rounds of block-wide (distance, index) minimum.
 // ---------------------------------------------------------------------------------------------------
+// A tile of 64 references x 64 queries of the batch per workgroup, the rows staged through the LDS 32 columns at a time; a thread
+// holds 4 x 4 pairs.  Every pair's sum runs over the columns left to right, one subtraction, one product, one addition each
+// (compiled with -ffp-contract=off): exact_d2's value bit for bit.  (Until late in round 6 a thread took ONE pair and read both
+// its rows itself: 1.2 KB of L2 traffic a pair at 150 columns, 555 ms for 20 000 queries against 100 000 cells.)
+constexpr int XDT = 64;   // rows of a tile, both ways
+constexpr int XDC = 32;   // columns staged at a time
 __global__ __launch_bounds__(256) void knn_exact_dist(const double* __restrict__ X, const int32_t* __restrict__ ref_rows,
                                                       int nr, const double* __restrict__ Q,
                                                       const int32_t* __restrict__ q_rows, int d,
-                                                      const int32_t* __restrict__ flagged, int f0,
+                                                      const int32_t* __restrict__ flagged, int f0, int nb,
                                                       double* __restrict__ drow, int dev_cap = 0) {
     // (dev_cap > 0: the number of listed queries is on the device -- flagged[0], at most dev_cap of them are taken --, the grid
-    // is dev_cap wide and the rows beyond the count end here)
-    if (dev_cap > 0 && (int)blockIdx.y >= min(flagged[0], dev_cap)) return;
-    const int f = f0 + blockIdx.y;
-    const int q = flagged ? flagged[1 + f] : f;
-    const double* qv = Q + (int64_t)(q_rows ? q_rows[q] : q) * d;
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r < nr) drow[(int64_t)blockIdx.y * nr + r] = exact_d2(qv, X + (int64_t)(ref_rows ? ref_rows[r] : r) * d, d);
+    // is made for dev_cap and the tiles beyond the count end here)
+    if (dev_cap > 0) nb = min(flagged[0], dev_cap);
+    const int q0 = blockIdx.y * XDT, r0 = blockIdx.x * XDT;
+    if (q0 >= nb) return;
+    __shared__ double Qs_[XDT][XDC + 1], Xs_[XDT][XDC + 1];
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    const int lr = tid >> 2, lc = (tid & 3) * 8;  // this thread stages 8 columns of row lr of either tile
+    const double* qp = nullptr;
+    const double* xp = nullptr;
+    if (q0 + lr < nb) {
+        const int f = f0 + q0 + lr;
+        const int q = flagged ? flagged[1 + f] : f;
+        qp = Q + (int64_t)(q_rows ? q_rows[q] : q) * d;
+    }
+    if (r0 + lr < nr) xp = X + (int64_t)(ref_rows ? ref_rows[r0 + lr] : r0 + lr) * d;
+    double s[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j2 = 0; j2 < 4; ++j2) s[i][j2] = 0.0;
+    for (int c0 = 0; c0 < d; c0 += XDC) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = c0 + lc + e;
+            Qs_[lr][lc + e] = (qp && c < d) ? qp[c] : 0.0;
+            Xs_[lr][lc + e] = (xp && c < d) ? xp[c] : 0.0;
+        }
+        __syncthreads();
+        const int cmax = d - c0 < XDC ? d - c0 : XDC;
+        for (int c = 0; c < cmax; ++c) {
+            double qv[4], xv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) qv[i] = Qs_[ty * 4 + i][c];
+#pragma unroll
+            for (int j2 = 0; j2 < 4; ++j2) xv[j2] = Xs_[tx * 4 + j2][c];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j2 = 0; j2 < 4; ++j2) {
+                    const double t = qv[i] - xv[j2];
+                    s[i][j2] += t * t;
+                }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int qi = q0 + ty * 4 + i;
+        if (qi >= nb) continue;
+#pragma unroll
+        for (int j2 = 0; j2 < 4; ++j2) {
+            const int r = r0 + tx * 4 + j2;
+            if (r < nr) drow[(int64_t)qi * nr + r] = s[i][j2];
+        }
+    }
 }
+
+// k <= 256: TWO sweeps of the row instead of k.  The k-th smallest of the 256 threads' own minima bounds the k-th smallest of the
+// row from above (k different entries lie at or below it); the entries at or below that bound -- about k (1 + k / 256) of them --
+// are collected in the LDS and sorted by (distance, position).  More than XS2_CAP of them (a row of equal distances): the k
+// rounds below.
+constexpr int XS2_CAP = 2048;
+__device__ __forceinline__ void knn_exact_select_rounds(const double* __restrict__ row, int nr, int k, int q,
+                                                        int32_t* __restrict__ idx_out, double* __restrict__ dist_out, int sq,
+                                                        double* rd, int* ri);
 
 __global__ __launch_bounds__(256) void knn_exact_select(const double* __restrict__ drow, int nr, int k,
                                                         const int32_t* __restrict__ flagged, int f0,
                                                         int32_t* __restrict__ idx_out, double* __restrict__ dist_out,
                                                         int dev_cap = 0, int sq = 0) {
-    __shared__ double rd[256];
-    __shared__ int ri[256];
+    __shared__ double sd[XS2_CAP];
+    __shared__ int si[XS2_CAP];
+    __shared__ double tau_sh;
+    __shared__ int cnt_sh;
     if (dev_cap > 0 && (int)blockIdx.x >= min(flagged[0], dev_cap)) return;  // (see knn_exact_dist)
     const int tid = threadIdx.x;
     const int f = f0 + blockIdx.x;
     const int q = flagged ? flagged[1 + f] : f;
     const double* row = drow + (int64_t)blockIdx.x * nr;
+    if (k <= 256) {
+        double m = __builtin_inf();
+        for (int r = tid; r < nr; r += 256) m = fmin(m, row[r]);
+        sd[tid] = m;
+        if (tid == 0) cnt_sh = 0;
+        __syncthreads();
+        int rank = 0;
+        for (int t = 0; t < 256; ++t) rank += (sd[t] < m || (sd[t] == m && t < tid)) ? 1 : 0;
+        if (rank == k - 1) tau_sh = m;  // (k <= nr: at least k threads hold an entry)
+        __syncthreads();
+        const double tau = tau_sh;
+        __syncthreads();  // (sd is reused)
+        for (int r = tid; r < nr; r += 256) {
+            const double v = row[r];
+            if (v <= tau) {
+                const int at = atomicAdd(&cnt_sh, 1);
+                if (at < XS2_CAP) {
+                    sd[at] = v;
+                    si[at] = r;
+                }
+            }
+        }
+        __syncthreads();
+        const int n = cnt_sh;
+        if (n <= XS2_CAP) {
+            int np2 = 64;
+            while (np2 < n) np2 <<= 1;
+            for (int i = n + tid; i < np2; i += 256) {
+                sd[i] = __builtin_inf();
+                si[i] = 0x7FFFFFFF;
+            }
+            __syncthreads();
+            for (int size = 2; size <= np2; size <<= 1)
+                for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                    for (int t = tid; t < (np2 >> 1); t += 256) {
+                        const int i = 2 * t - (t & (stride - 1)), j = i + stride;
+                        const double a = sd[i], b = sd[j];
+                        const int ai = si[i], bi = si[j];
+                        if (key_less(b, bi, a, ai) == ((i & size) == 0)) {
+                            sd[i] = b;
+                            sd[j] = a;
+                            si[i] = bi;
+                            si[j] = ai;
+                        }
+                    }
+                    __syncthreads();
+                }
+            for (int j = tid; j < k; j += 256) {
+                idx_out[(int64_t)q * k + j] = si[j];
+                if (dist_out) dist_out[(int64_t)q * k + j] = sq ? sd[j] : sqrt(sd[j]);
+            }
+            return;
+        }
+        __syncthreads();
+    }
+    knn_exact_select_rounds(row, nr, k, q, idx_out, dist_out, sq, sd, si);
+}
+
+__device__ __forceinline__ void knn_exact_select_rounds(const double* __restrict__ row, int nr, int k, int q,
+                                                        int32_t* __restrict__ idx_out, double* __restrict__ dist_out, int sq,
+                                                        double* rd, int* ri) {
+    const int tid = threadIdx.x;
     double last_d = -1.0;  // squared distances are >= 0
     int last_i = -1;
     for (int jdx = 0; jdx < k; ++jdx) {
@@ -1267,10 +1394,10 @@ void exact_search(hipStream_t stream, KnnWorkspace& ws, const double* X, const i
         double* drow = ws.drow.reserve((size_t)batch * nr);
         for (int f0 = 0; f0 < count; f0 += batch) {
             const int nb = std::min(batch, count - f0);
-            hipLaunchKernelGGL(knn_exact_dist, dim3(cdiv(nr, 256), nb), dim3(256), 0, stream, X, ref_rows, nr, Qs, qrs, d,
-                               scan_list, f0, drow);
+            hipLaunchKernelGGL(knn_exact_dist, dim3(cdiv(nr, XDT), cdiv(nb, XDT)), dim3(256), 0, stream, X, ref_rows, nr, Qs, qrs,
+                               d, scan_list, f0, nb, drow);
             BMX_LAUNCH_CHECK();
-            if (k > 64 && k <= XSB_MAXK) {
+            if (k > 256 && k <= XSB_MAXK) {
                 int np2 = 128;
                 while (np2 < k) np2 <<= 1;
                 const size_t lds = (size_t)np2 * (sizeof(double) + sizeof(int));
@@ -1836,10 +1963,10 @@ bool large_k_search(hipStream_t stream, KnnWorkspace& ws, const double* X, const
         hipLaunchKernelGGL(lk_opt_overflow, dim3(1), dim3(1), 0, stream, (const int32_t*)flagged, opt);
         BMX_LAUNCH_CHECK();
         double* drow = ws.drow.reserve((size_t)LK_OPT_CAP * nr);
-        hipLaunchKernelGGL(knn_exact_dist, dim3(cdiv(nr, 256), LK_OPT_CAP), dim3(256), 0, stream, X, ref_rows, nr, Qs, qrs, d,
-                           (const int32_t*)flagged, 0, drow, LK_OPT_CAP);
+        hipLaunchKernelGGL(knn_exact_dist, dim3(cdiv(nr, XDT), cdiv(LK_OPT_CAP, XDT)), dim3(256), 0, stream, X, ref_rows, nr, Qs,
+                           qrs, d, (const int32_t*)flagged, 0, 0, drow, LK_OPT_CAP);
         BMX_LAUNCH_CHECK();
-        if (k > 64 && k <= XSB_MAXK) {
+        if (k > 256 && k <= XSB_MAXK) {
             int np2 = 128;
             while (np2 < k) np2 <<= 1;
             const size_t lds = (size_t)np2 * (sizeof(double) + sizeof(int));
