@@ -239,3 +239,11 @@ def test_large_k_queries_the_merge_cannot_certify(oracle, bx, outliers, retries)
     finally:
         eng.close()
     assert_same_result(bx.reducedMNN(B1, B2, k=100), oracle.reduced_mnn(B1, B2, k=100))
+
+
+@pytest.mark.parametrize("d,kw", [(140, {}), (131, {"k": 70}), (200, {"prop_k": 0.1})])
+def test_rows_beyond_125_columns(oracle, bx, d, kw):
+    """No candidate tier takes rows of more than 125 columns: every search of the run is the FP64 scan (knn.hip: knn_exact_dist in
+    LDS tiles, knn_exact_select in two sweeps / by bisection) -- same result as the oracle's, pairs bit for bit."""
+    B = synth_batches(41, [1500, 2000, 900], d)
+    assert_same_result(bx.reducedMNN(*B, **kw), oracle.reduced_mnn(*B, **kw))
