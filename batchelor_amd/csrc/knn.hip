@@ -1693,17 +1693,18 @@ __global__ __launch_bounds__(256) void lk_merge_wave(const double* __restrict__ 
 }
 
 // The merge for k beyond ~900 (`prop.k` = 0.05 of 100 000 cells is k = 5 000, R/MNN_tree.R:140-146): up to LKB_MAXE candidates a
-// query, one workgroup of 1 024 threads per query.  No rank counting (E x P binary searches would be 2e7 steps a query at
+// query, one workgroup per query (LKB_T threads: 256 up to 3 584 candidates, 1 024 beyond).  No rank counting (E x P binary searches would be 2e7 steps a query at
 // P = 358) and no sort of all E: every thread keeps its <= 14 candidates in registers; the k-th smallest (squared distance,
 // position) is found by bisection on the distances' bit patterns -- non-negative doubles order like unsigned integers; a round is
 // a count and a block reduction --, the k selected candidates are compacted into the LDS and only THEY are sorted (bitonic
 // network over the next power of two: 12 bytes an entry, 96 KB at k = 5 000).  The certificate is the partitioned search's: no
 // partition's last entry may be among the selected.
-constexpr int LKB_T = 1024;
 constexpr int LKB_PER = 14;                    // candidates a thread holds
-constexpr int LKB_MAXE = LKB_T * LKB_PER;      // 14 336
+constexpr int LKB_MAXE = 1024 * LKB_PER;       // 14 336 (1 024 threads; up to 3 584 candidates: 256 threads -- a block-wide
+                                               // barrier of 4 waves instead of 16, ~200 of them a query, and eight queries a CU)
 constexpr int LKB_MAXK = 8192;                 // the sort's entries: 12 B x 8 192 = 96 KB of LDS
 
+template <int LKB_T>
 __global__ __launch_bounds__(LKB_T) void lk_merge_big(const double* __restrict__ X, const int32_t* __restrict__ rows, int nr, int P,
                                                       int kp, const double* __restrict__ Q, const int32_t* __restrict__ qrs,
                                                       int nq, int d, int k, const int32_t* __restrict__ sub_idx,
@@ -1944,9 +1945,16 @@ bool large_k_search(hipStream_t stream, KnnWorkspace& ws, const double* X, const
         size_t np2 = 1;
         while (np2 < (size_t)k) np2 <<= 1;
         const size_t lds = np2 * 12;
-        ensure_dynamic_lds(reinterpret_cast<const void*>(&lk_merge_big), lds);
-        hipLaunchKernelGGL(lk_merge_big, dim3(nq), dim3(LKB_T), lds, stream, X, (const int32_t*)rows, nr, P, kp, Qs, qrs, nq, d, k,
-                           (const int32_t*)sub, io, dout, flagged, no_opt, kth_out, (const float*)seed, (const double*)sub_d2);
+        if (P * kp <= 256 * LKB_PER) {
+            ensure_dynamic_lds(reinterpret_cast<const void*>(&lk_merge_big<256>), lds);
+            hipLaunchKernelGGL(lk_merge_big<256>, dim3(nq), dim3(256), lds, stream, X, (const int32_t*)rows, nr, P, kp, Qs, qrs, nq, d,
+                               k, (const int32_t*)sub, io, dout, flagged, no_opt, kth_out, (const float*)seed, (const double*)sub_d2);
+        } else {
+            ensure_dynamic_lds(reinterpret_cast<const void*>(&lk_merge_big<1024>), lds);
+            hipLaunchKernelGGL(lk_merge_big<1024>, dim3(nq), dim3(1024), lds, stream, X, (const int32_t*)rows, nr, P, kp, Qs, qrs, nq,
+                               d, k, (const int32_t*)sub, io, dout, flagged, no_opt, kth_out, (const float*)seed,
+                               (const double*)sub_d2);
+        }
     } else if (P * kp <= 512)
         hipLaunchKernelGGL(lk_merge_wave, dim3(cdiv(nq, 4)), dim3(256), 0, stream, X, (const int32_t*)rows, nr, P, kp, Qs, qrs, nq,
                            d, k, (const int32_t*)sub, io, dout, flagged, no_opt, kth_out, (const float*)seed, (const double*)sub_d2);
