@@ -32,9 +32,10 @@ void exclusive_scan_i32(hipStream_t stream, ScanWorkspace& ws, const int32_t* in
 // of a selected left cell l (both nullptr: one row per left cell).  nL = number of rows of idxLR.
 // SortedRows (nullable; used where sorted_rows_apply(k1, k2): 64 < k2 <= 8192, k1 <= 8192): mutual_counts sorts each row of
 // both lists into it and answers every "does row x list y" by binary search instead of reading the row -- k1 * k2 words a
-// cell otherwise; emit_pairs handed the same object reuses the sorted right rows.  Results are identical.
+// cell otherwise; emit_pairs handed the same object reads the left rows' hits as bits instead of searching again.  Results are identical.
 struct SortedRows {
     DevBuf<int32_t> lr, rl;
+    DevBuf<unsigned long long> hits;  // [nL][ceil(k2 / 64)]: bit j of word w of row c = neighbour 64 w + j of row c is mutual
 };
 bool sorted_rows_apply(int k1, int k2);
 void mutual_counts(hipStream_t stream, const int32_t* idxLR, int nL, int k2, const int32_t* idxRL, int nR, int k1,

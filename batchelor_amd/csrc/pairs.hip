@@ -250,16 +250,20 @@ __device__ __forceinline__ bool sorted_contains(const int32_t* __restrict__ row,
 
 __global__ __launch_bounds__(256) void mutual_left_sorted(const int32_t* __restrict__ idxLR, int nL, int k2,
                                                           const int32_t* __restrict__ sortedRL, int k1,
-                                                          const int32_t* __restrict__ lsel, int32_t* __restrict__ cntL) {
+                                                          const int32_t* __restrict__ lsel, int32_t* __restrict__ cntL,
+                                                          unsigned long long* __restrict__ hits) {
     const int c0 = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c0 >= nL) return;
     const int l = lsel ? lsel[c0] : c0;
+    const int W = (k2 + 63) >> 6;
     int c = 0;
     for (int base = 0; base < k2; base += 64) {
         const int j = base + lane;
         const int32_t r = j < k2 ? idxLR[(int64_t)c0 * k2 + j] : -1;
         const bool hit = r >= 0 && sorted_contains(sortedRL + (int64_t)r * k1, k1, l);
-        c += __popcll(__ballot(hit));
+        const unsigned long long b = __ballot(hit);
+        c += __popcll(b);
+        if (lane == 0) hits[(int64_t)c0 * W + (base >> 6)] = b;  // (bit j of word base / 64: neighbour base + j is mutual -- for emit_pairs)
     }
     if (lane == 0) cntL[c0] = c;
 }
@@ -287,7 +291,7 @@ __global__ __launch_bounds__(256) void mutual_right_sorted(const int32_t* __rest
 }
 
 __global__ __launch_bounds__(256) void emit_pairs_sorted(const int32_t* __restrict__ idxLR, int nL, int k2,
-                                                         const int32_t* __restrict__ sortedRL, int k1,
+                                                         const unsigned long long* __restrict__ hits,
                                                          const int32_t* __restrict__ offL, const int32_t* __restrict__ lsel,
                                                          const int32_t* __restrict__ lrows, const int32_t* __restrict__ rrows,
                                                          int32_t* __restrict__ first, int32_t* __restrict__ second) {
@@ -297,11 +301,12 @@ __global__ __launch_bounds__(256) void emit_pairs_sorted(const int32_t* __restri
     if (o == offL[c + 1]) return;  // no pair starts at this left cell (uniform over the wave)
     const int l = lsel ? lsel[c] : c;
     const int32_t lid = (lrows ? lrows[l] : l) + 1;
+    const int W = (k2 + 63) >> 6;
     for (int base = 0; base < k2; base += 64) {
         const int j = base + lane;
-        const int32_t r = j < k2 ? idxLR[(int64_t)c * k2 + j] : -1;
-        const bool hit = r >= 0 && sorted_contains(sortedRL + (int64_t)r * k1, k1, l);
-        const unsigned long long b = __ballot(hit);
+        const unsigned long long b = hits[(int64_t)c * W + (base >> 6)];  // (what mutual_left_sorted found: no second search)
+        const bool hit = (b >> lane) & 1ull;
+        const int32_t r = hit ? idxLR[(int64_t)c * k2 + j] : -1;
         if (hit) {
             const int at = o + __popcll(b & ((1ull << lane) - 1ull));
             first[at] = lid;
@@ -395,7 +400,8 @@ void mutual_counts(hipStream_t stream, const int32_t* idxLR, int nL, int k2, con
         const int32_t* sLR = sort_rows(stream, idxLR, nL, k2, sorted->lr);
         const int32_t* sRL = sort_rows(stream, idxRL, nR, k1, sorted->rl);
         if (nL > 0) {
-            hipLaunchKernelGGL(mutual_left_sorted, dim3(cdiv(nL, 4)), dim3(256), 0, stream, idxLR, nL, k2, sRL, k1, lsel, cntL);
+            unsigned long long* hits = sorted->hits.reserve((size_t)nL * ((k2 + 63) / 64));
+            hipLaunchKernelGGL(mutual_left_sorted, dim3(cdiv(nL, 4)), dim3(256), 0, stream, idxLR, nL, k2, sRL, k1, lsel, cntL, hits);
             BMX_LAUNCH_CHECK();
         }
         if (nR > 0) {
@@ -437,9 +443,9 @@ void emit_pairs(hipStream_t stream, const int32_t* idxLR, int nL, int k2, const 
                 const int32_t* offL, const int32_t* lrows, const int32_t* rrows, int32_t* first, int32_t* second,
                 const int32_t* lsel, const unsigned long long* maskL, const SortedRows* sorted) {
     if (nL <= 0) return;
-    if (sorted && sorted_rows_apply(k1, k2)) {  // (sorted->rl: the rows mutual_counts sorted for this idxRL)
+    if (sorted && sorted_rows_apply(k1, k2)) {  // (sorted->hits: what mutual_counts found for these lists)
         hipLaunchKernelGGL(emit_pairs_sorted, dim3(cdiv(nL, 4)), dim3(256), 0, stream, idxLR, nL, k2,
-                           (const int32_t*)sorted->rl.p, k1, offL, lsel, lrows, rrows, first, second);
+                           (const unsigned long long*)sorted->hits.p, offL, lsel, lrows, rrows, first, second);
         BMX_LAUNCH_CHECK();
         return;
     }
