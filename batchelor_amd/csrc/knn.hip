@@ -1693,7 +1693,7 @@ __global__ __launch_bounds__(256) void lk_merge_wave(const double* __restrict__ 
 }
 
 // The merge for k beyond ~900 (`prop.k` = 0.05 of 100 000 cells is k = 5 000, R/MNN_tree.R:140-146): up to LKB_MAXE candidates a
-// query, one workgroup per query (LKB_T threads: 256 up to 3 584 candidates, 1 024 beyond).  No rank counting (E x P binary searches would be 2e7 steps a query at
+// query, one workgroup per query (LKB_T threads: 256 up to 3 584 candidates, 512 up to 7 168, 1 024 beyond).  No rank counting (E x P binary searches would be 2e7 steps a query at
 // P = 358) and no sort of all E: every thread keeps its <= 14 candidates in registers; the k-th smallest (squared distance,
 // position) is found by bisection on the distances' bit patterns -- non-negative doubles order like unsigned integers; a round is
 // a count and a block reduction --, the k selected candidates are compacted into the LDS and only THEY are sorted (bitonic
@@ -1948,6 +1948,10 @@ bool large_k_search(hipStream_t stream, KnnWorkspace& ws, const double* X, const
         if (P * kp <= 256 * LKB_PER) {
             ensure_dynamic_lds(reinterpret_cast<const void*>(&lk_merge_big<256>), lds);
             hipLaunchKernelGGL(lk_merge_big<256>, dim3(nq), dim3(256), lds, stream, X, (const int32_t*)rows, nr, P, kp, Qs, qrs, nq, d,
+                               k, (const int32_t*)sub, io, dout, flagged, no_opt, kth_out, (const float*)seed, (const double*)sub_d2);
+        } else if (P * kp <= 512 * LKB_PER) {
+            ensure_dynamic_lds(reinterpret_cast<const void*>(&lk_merge_big<512>), lds);
+            hipLaunchKernelGGL(lk_merge_big<512>, dim3(nq), dim3(512), lds, stream, X, (const int32_t*)rows, nr, P, kp, Qs, qrs, nq, d,
                                k, (const int32_t*)sub, io, dout, flagged, no_opt, kth_out, (const float*)seed, (const double*)sub_d2);
         } else {
             ensure_dynamic_lds(reinterpret_cast<const void*>(&lk_merge_big<1024>), lds);
