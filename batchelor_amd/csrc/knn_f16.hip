@@ -1251,39 +1251,29 @@ namespace {
 // error bound is a valid starting threshold (the margin form of the unsplit sample), taken if tighter than what stands there.
 __global__ __launch_bounds__(256) void sample_merge_kernel(const float* __restrict__ lists, int n, int len, int nq, int k,
                                                            const float* __restrict__ margin_g, uint32_t* __restrict__ tau_g) {
-    __shared__ float sv[4][512];
+    (void)len;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + w;
     if (q >= nq) return;  // (whole waves: nothing below synchronises the block)
-    float* v = sv[w];
-    for (int i = lane; i < n; i += 64) v[i] = lists[(int64_t)q * n + i];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    // the n values are n / len ascending lists of len (a range's two lanes each kept their len smallest, sorted): an entry's
-    // rank in the union = its place in its own list + a binary search in every other list (ties: the earlier list first)
-    const int nl = n / len;
-    float uk = __builtin_inff();
-    for (int i = lane; i < n; i += 64) {
-        const float x = v[i];
-        const int li = i / len;
-        int r = i - li * len;
-        for (int m = 0; m < nl; ++m) {
-            if (m == li) continue;
-            const float* lm = v + m * len;
-            int lo = 0, hi = len;  // entries of list m in front of x
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                const float y = lm[mid];
-                if (y < x || (y == x && m < li)) lo = mid + 1;
-                else hi = mid;
-            }
-            r += lo;
-        }
-        uk = r == k - 1 ? x : uk;
+    // the k-th smallest of the n <= 512 values (the ranges' lists, in any order): a lane holds up to eight of them as orderable
+    // bit patterns, a bisection over the 32 bits counts with ballots -- no LDS, no dependent look-ups.  (Until late in round 6:
+    // every entry's rank by a binary search in every other list, 36 dependent LDS reads an entry: 44 us a launch at 12 500 queries.)
+    uint32_t val[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int i = lane + 64 * u;
+        val[u] = i < n ? f32_orderable(lists[(int64_t)q * n + i]) : 0xFFFFFFFFu;
     }
-    for (int o = 32; o > 0; o >>= 1) uk = fminf(uk, __shfl_xor(uk, o));
+    uint32_t t = 0;  // the smallest pattern with at least k values at or below it
+    for (int b = 31; b >= 0; --b) {
+        const uint32_t trial = t | ((1u << b) - 1u);  // the largest pattern with the bits decided so far and this bit clear
+        int c = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c += __popcll(__builtin_amdgcn_ballot_w64(val[u] <= trial));
+        if (c < k) t |= 1u << b;
+    }
     if (lane == 0) {
+        const float uk = orderable_f32(t);
         const float tm = uk + margin_g[q] + fabsf(uk) * 2.384185791015625e-07f;  // (the f32 sum rounded up)
         if (tm == tm && tm < __builtin_inff()) atomicMin(&tau_g[q], f32_orderable(tm));
     }
